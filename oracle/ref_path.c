@@ -1,0 +1,692 @@
+/* TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.
+ *
+ * Plain-C restatement of the reference's CPU element-integration / assembly path
+ * ("restated reference path").  Same algorithm and loop structure as the
+ * reference; every function cites the reference lines it follows
+ * (paths relative to /root/reference/src/mimi/).  The reference itself cannot be
+ * compiled here: every translation unit includes <mfem.hpp> and
+ * third_party/mfem is an empty, un-pinned submodule, so the small dense MFEM
+ * kernels it calls (MultAtB, MultABt, AddMult_a_ABt, CalcInverse, Det) are
+ * restated inline from their published definitions.
+ *
+ * Parity pinning: tests/test_oracle_golden.py drives this file through an
+ * in-repo gen-alpha/Newton harness and reproduces the reference's golden
+ * fixtures tests/data/ref/{neohook,j2}_h1_p2/x_{0..9}.txt.
+ *
+ * Layout conventions (identical to the reference):
+ *   u, r        : fp64[n_vdofs], byVDIM  (u[node*dim + c])
+ *   v_dofs[e]   : [dofs*dim+0 ..., dofs*dim+1 ..., ...]      (precomputed.cpp:84)
+ *   element x   : (n_dof x dim) column-major                  (integrator_utils.cpp:27)
+ *   dN_dX[e][q] : (n_dof x dim) column-major                  (precomputed.cpp:316-321)
+ *   K_e         : (n_tdof x n_tdof) column-major              (nonlinear_solid.cpp:55-74)
+ *   A_ids[e]    : A_ids[c*n_tdof + r] -> CSR value position   (precomputed.cpp:185-199)
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define MAXD 3
+#define MAX_TDOF 192 /* 3-D p=3 */
+
+enum { MAT_NEOHOOKEAN = 0, MAT_J2 = 1 };
+enum { HARD_POWERLAW = 0, HARD_VOCE = 1, HARD_JC = 2, HARD_JC_RATE = 3, HARD_JC_TEMP_RATE = 4,
+       HARD_JC_CONST_TEMP = 5 };
+enum { TANGENT_FD = 0, TANGENT_EXACT = 1 };
+
+typedef struct {
+  int kind;
+  /* MaterialBase (materials.hpp:31-38) */
+  double density, lambda, mu, K, G;
+  /* J2 (materials.hpp:268-273) */
+  double heat_fraction, specific_heat, initial_temperature, melting_temperature;
+  /* hardening (material_hardening.hpp) */
+  int hard_kind;
+  double sigma_y, n, eps0;                 /* PowerLaw */
+  double sigma_sat, strain_constant;       /* Voce */
+  double A, B, C, eps0_dot;                /* JohnsonCook (+rate) */
+  double reference_temperature, m;         /* + temperature */
+  double const_temperature_contribution;   /* JohnsonCookConstantTemperature */
+} oracle_material;
+
+typedef struct {
+  int dim, n_el, n_dof, n_q, n_vdofs;
+  const int* v_dofs;      /* [n_el][n_tdof] */
+  const int* a_ids;       /* [n_el][n_tdof^2] or NULL */
+  const double* dN_dX;    /* [n_el][n_q][dim][n_dof] */
+  const double* weight;   /* [n_el][n_q]  integration_weight */
+  const double* det;      /* [n_el][n_q]  det_dX_dxi */
+  oracle_material mat;
+  /* J2 state (materials.hpp:278-286), one record per (element, quad point) */
+  double* plastic_strain; /* [n_el][n_q][dim*dim] column-major */
+  double* eqps;           /* [n_el][n_q] accumulated plastic strain */
+  double* temperature;    /* [n_el][n_q] */
+  double dt;              /* material_->dt_ (nonlinear_solid.cpp:154,167) */
+} oracle_domain;
+
+/* ---- utils/n_thread_exe.hpp:12-26 ---------------------------------------- */
+static void chunk_rule(long total, long nthread, long ithread, long* from, long* to) {
+  const long chunk = (total + nthread - 1) / nthread;
+  if (ithread < nthread - 1) {
+    *from = ithread * chunk;
+    *to = (ithread + 1) * chunk;
+  } else {
+    *from = (nthread - 1) * chunk;
+    *to = total;
+  }
+  if (*from > total) *from = total;
+  if (*to > total) *to = total;
+}
+
+/* ---- small dense helpers (column-major dim x dim) ------------------------- */
+static double det_d(const double* F, int dim) {
+  if (dim == 2) return F[0] * F[3] - F[1] * F[2];
+  return F[0] * (F[4] * F[8] - F[5] * F[7]) - F[3] * (F[1] * F[8] - F[2] * F[7])
+         + F[6] * (F[1] * F[5] - F[2] * F[4]);
+}
+
+static void inv_d(const double* F, int dim, double* Fi) {
+  const double d = det_d(F, dim);
+  const double t = 1.0 / d;
+  if (dim == 2) {
+    Fi[0] = F[3] * t;
+    Fi[1] = -F[1] * t;
+    Fi[2] = -F[2] * t;
+    Fi[3] = F[0] * t;
+    return;
+  }
+  Fi[0] = (F[4] * F[8] - F[5] * F[7]) * t;
+  Fi[1] = (F[2] * F[7] - F[1] * F[8]) * t;
+  Fi[2] = (F[1] * F[5] - F[2] * F[4]) * t;
+  Fi[3] = (F[5] * F[6] - F[3] * F[8]) * t;
+  Fi[4] = (F[0] * F[8] - F[2] * F[6]) * t;
+  Fi[5] = (F[2] * F[3] - F[0] * F[5]) * t;
+  Fi[6] = (F[3] * F[7] - F[4] * F[6]) * t;
+  Fi[7] = (F[1] * F[6] - F[0] * F[7]) * t;
+  Fi[8] = (F[0] * F[4] - F[1] * F[3]) * t;
+}
+
+#define M(A, i, j) (A)[(i) + (j) * dim]
+
+/* ---- hardening: ADScalar<double,1> restated as (value, derivative) -------- */
+typedef struct { double v, d; } dual;
+
+/* material_hardening.hpp:75-77,261-279,326-333 */
+static double thermo_contribution(const oracle_material* m, double T) {
+  if (m->hard_kind == HARD_JC_TEMP_RATE) {
+    double c = 1.0;
+    if (T < m->reference_temperature) {
+    } else if (T > m->melting_temperature) {
+      c = 0.0;
+    } else {
+      c -= pow((T - m->reference_temperature) / (m->melting_temperature - m->reference_temperature), m->m);
+    }
+    return c;
+  }
+  if (m->hard_kind == HARD_JC_CONST_TEMP) return m->const_temperature_contribution;
+  return 1.0;
+}
+
+/* material_hardening.hpp:62-64,162-173 */
+static double rate_contribution(const oracle_material* m, double rate) {
+  if (m->hard_kind >= HARD_JC_RATE) {
+    double v = 1.0;
+    if (rate > m->eps0_dot) v += m->C * log(rate / m->eps0_dot);
+    return v;
+  }
+  return 1.0;
+}
+
+/* d/d(rate) of the above (only for the exact tangent; the reference's return-map
+ * Newton does not differentiate it: material_hardening.hpp:69-71) */
+static double rate_contribution_derivative(const oracle_material* m, double rate) {
+  if (m->hard_kind >= HARD_JC_RATE && rate > m->eps0_dot) return m->C / rate;
+  return 0.0;
+}
+
+/* utils/ad.inl:263-279  pow(ADScalar, double) */
+static dual dual_pow(dual b, double power) {
+  const double tmp = pow(b.v, power - 1.0);
+  dual r;
+  r.v = b.v * tmp;
+  r.d = b.d * (power * tmp);
+  return r;
+}
+
+/* material_hardening.hpp:88-95 (PowerLaw), 108-116 (Voce), 131-140 (JohnsonCook) */
+static dual hardening_evaluate(const oracle_material* m, dual eqps) {
+  dual r;
+  switch (m->hard_kind) {
+  case HARD_POWERLAW: {
+    dual b = {1.0 + eqps.v / m->eps0, eqps.d / m->eps0};
+    dual p = dual_pow(b, 1.0 / m->n);
+    r.v = m->sigma_y * p.v;
+    r.d = m->sigma_y * p.d;
+    return r;
+  }
+  case HARD_VOCE: {
+    const double e = exp(-eqps.v / m->strain_constant);
+    r.v = m->sigma_sat - (m->sigma_sat - m->sigma_y) * e;
+    r.d = (m->sigma_sat - m->sigma_y) * e * (eqps.d / m->strain_constant);
+    return r;
+  }
+  default: {
+    if (fabs(eqps.v) < 1.e-13) {
+      r.v = m->A;
+      r.d = 0.0;
+      return r;
+    }
+    dual p = dual_pow(eqps, m->n);
+    r.v = m->A + m->B * p.v;
+    r.d = m->B * p.d;
+    return r;
+  }
+  }
+}
+
+static double sigma_y_of(const oracle_material* m) {
+  return (m->hard_kind == HARD_POWERLAW || m->hard_kind == HARD_VOCE) ? m->sigma_y : m->A;
+}
+
+/* materials.hpp:343-349  the return-mapping residual lambda */
+typedef struct {
+  const oracle_material* m;
+  double eqps_old, q, thermo, dt;
+} rm_ctx;
+
+static dual rm_residual(const rm_ctx* c, dual delta) {
+  dual e = {c->eqps_old + delta.v, delta.d};
+  dual H = hardening_evaluate(c->m, e);
+  const double fac = rate_contribution(c->m, delta.v / c->dt) * c->thermo;
+  dual r;
+  r.v = c->q - 3.0 * c->m->G * delta.v - H.v * fac;
+  r.d = -3.0 * c->m->G * delta.d - H.d * fac;
+  return r;
+}
+
+/* solvers/newton.hpp:53-169  ScalarSolve; returns x, *status != 0 on the
+ * reference's throw paths (not bracketed / not converged). */
+static double scalar_solve(const rm_ctx* c, double x0, double lower, double upper, double xtol,
+                           double rtol, unsigned max_iter, int* status) {
+  double x, df_dx;
+  dual a = {lower, 0.0}, b = {upper, 0.0};
+  double fl = rm_residual(c, a).v;
+  double fh = rm_residual(c, b).v;
+  unsigned iterations = 0;
+  int converged = 0;
+  *status = 0;
+  if (fabs(fl) < xtol) return lower;
+  if (fabs(fh) < xtol) return upper;
+  if (fl * fh > 0.) {
+    *status = 1;
+    return lower;
+  }
+  double xl = lower, xh = upper;
+  if (fl > 0) {
+    xl = upper;
+    xh = lower;
+  }
+  if (x0 < lower || x0 > upper) x0 = 0.5 * (lower + upper);
+  x = x0;
+  double delta_x_old = fabs(upper - lower);
+  double delta_x = delta_x_old;
+  dual xx = {x, 1.0};
+  dual R = rm_residual(c, xx);
+  double fval = R.v;
+  df_dx = R.d;
+  while (!converged) {
+    if (iterations == max_iter) {
+      *status = 2;
+      break;
+    }
+    if ((x - xh) * df_dx - fval > 0 || (x - xl) * df_dx - fval < 0
+        || fabs(2. * fval) > fabs(delta_x_old * df_dx)) {
+      delta_x_old = delta_x;
+      delta_x = 0.5 * (xh - xl);
+      x = xl + delta_x;
+    } else {
+      delta_x_old = delta_x;
+      delta_x = fval / df_dx;
+      x -= delta_x;
+    }
+    xx.v = x;
+    R = rm_residual(c, xx);
+    fval = R.v;
+    df_dx = R.d;
+    converged = converged || (fabs(delta_x) < xtol) || (fabs(fval) < rtol);
+    if (fval < 0) xl = x; else xh = x;
+    ++iterations;
+  }
+  return x;
+}
+
+/* ---- materials ------------------------------------------------------------ */
+typedef struct {
+  /* per-point scratch = NonlinearSolidWorkData (integrator_utils.hpp:14-115) */
+  double F[9], Finv[9], detF, P[9];
+  /* J2 by-products needed by the exact tangent */
+  double s_trial[9], q, delta, hprime, sigma[9];
+  int plastic;
+} point_work;
+
+/* materials.cpp:96-118 (EvaluateCauchy) + materials.cpp:60-71 (base EvaluatePK1) */
+static void neo_hookean_pk1(const oracle_material* m, int dim, point_work* w) {
+  double B[9], sigma[9];
+  const double detF = w->detF;
+  const double mu_over = m->mu / detF;
+  for (int i = 0; i < dim; ++i)
+    for (int j = 0; j < dim; ++j) {
+      double s = 0;
+      for (int k = 0; k < dim; ++k) s += M(w->F, i, k) * M(w->F, j, k);
+      M(B, i, j) = s;
+    }
+  const double diag = -mu_over + m->lambda * (detF - 1.);
+  for (int i = 0; i < dim; ++i)
+    for (int j = 0; j < dim; ++j) M(sigma, i, j) = mu_over * M(B, i, j) + (i == j ? diag : 0.0);
+  /* P = det(F) * sigma * F^-T */
+  for (int i = 0; i < dim; ++i)
+    for (int J = 0; J < dim; ++J) {
+      double s = 0;
+      for (int k = 0; k < dim; ++k) s += M(sigma, i, k) * M(w->Finv, J, k);
+      M(w->P, i, J) = s * detF;
+    }
+  memcpy(w->sigma, sigma, sizeof(sigma));
+}
+
+/* materials.hpp:311-391  J2::PlasticStress<accumulate>, then base EvaluatePK1.
+ * state pointers address ONE quadrature point.  Returns non-zero on the
+ * reference's ScalarSolve throw paths. */
+static int j2_plastic_stress(const oracle_material* m, int dim, double dt, int accumulate,
+                             double* plastic_strain, double* eqps, double* temperature,
+                             point_work* w) {
+  double eps[9], s[9], Np[9];
+  const int dd = dim * dim;
+  /* material_utils.hpp:60-84 ElasticStrain: sym(F) - I - eps_p */
+  for (int i = 0; i < dim; ++i)
+    for (int j = 0; j < dim; ++j) M(eps, i, j) = 0.5 * (M(w->F, i, j) + M(w->F, j, i));
+  for (int i = 0; i < dim; ++i) M(eps, i, i) -= 1.;
+  for (int i = 0; i < dd; ++i) eps[i] -= plastic_strain[i];
+  double tr = 0;
+  for (int i = 0; i < dim; ++i) tr += M(eps, i, i);
+  const double p = m->K * tr;
+  /* material_utils.hpp:22-56 Dev(eps, dim, 2G, s): trace divided by dim */
+  const double tr_over_dim = tr / (double)dim;
+  for (int i = 0; i < dd; ++i) s[i] = eps[i] * (2.0 * m->G);
+  for (int i = 0; i < dim; ++i) M(s, i, i) = (M(eps, i, i) - tr_over_dim) * (2.0 * m->G);
+  double nrm = 0;
+  for (int i = 0; i < dd; ++i) nrm += s[i] * s[i];
+  nrm = sqrt(nrm);
+  const double q = sqrt(3.0 / 2.0) * nrm;
+  memcpy(w->s_trial, s, sizeof(s));
+  w->q = q;
+  w->plastic = 0;
+  w->delta = 0;
+  w->hprime = 0;
+
+  rm_ctx c;
+  c.m = m;
+  c.eqps_old = *eqps;
+  c.q = q;
+  c.thermo = thermo_contribution(m, *temperature);
+  c.dt = dt;
+  const double tolerance = sigma_y_of(m) * 1.e-10;
+  dual zero = {0.0, 0.0};
+  int status = 0;
+  if (rm_residual(&c, zero).v > tolerance) {
+    dual e0 = {c.eqps_old, 0.0};
+    const double upper = (q - hardening_evaluate(m, e0).v * c.thermo) / (3.0 * m->G);
+    const double delta = scalar_solve(&c, 0.0, 0.0, upper, 1.e-10, tolerance, 100, &status);
+    for (int i = 0; i < dd; ++i) Np[i] = (1.5 / q) * s[i];
+    w->plastic = 1;
+    w->delta = delta;
+    {
+      /* total derivative of H(eqps+D)*rate(D/dt)*thermo wrt D, for the exact tangent */
+      dual e1 = {c.eqps_old + delta, 1.0};
+      dual H = hardening_evaluate(m, e1);
+      const double rc = rate_contribution(m, delta / dt);
+      w->hprime = H.d * rc * c.thermo + H.v * rate_contribution_derivative(m, delta / dt) / dt * c.thermo;
+    }
+    if (!accumulate) {
+      for (int i = 0; i < dd; ++i) s[i] += -2.0 * m->G * delta * Np[i];
+    } else {
+      *eqps += delta;
+      for (int i = 0; i < dd; ++i) plastic_strain[i] += delta * Np[i];
+      if (m->hard_kind == HARD_JC_TEMP_RATE) {
+        *temperature += m->heat_fraction * q * delta / (m->density * m->specific_heat);
+      }
+    }
+  }
+  if (!accumulate) {
+    double sigma[9];
+    for (int i = 0; i < dd; ++i) sigma[i] = s[i];
+    for (int i = 0; i < dim; ++i) M(sigma, i, i) += p;
+    memcpy(w->sigma, sigma, sizeof(sigma));
+    /* materials.cpp:60-71: P = det(F) * sigma * F^-T */
+    for (int i = 0; i < dim; ++i)
+      for (int J = 0; J < dim; ++J) {
+        double t = 0;
+        for (int k = 0; k < dim; ++k) t += M(sigma, i, k) * M(w->Finv, J, k);
+        M(w->P, i, J) = t * w->detF;
+      }
+  }
+  return status;
+}
+
+/* dP_iJ/dF_jL, exact, stored A[((i*dim+J)*dim+j)*dim+L]  (not in the reference: the
+ * reference differentiates numerically, nonlinear_solid.cpp:48-76) */
+static void exact_tangent(const oracle_material* m, int dim, const point_work* w, double* A) {
+  const double J = w->detF;
+  const double* Fi = w->Finv; /* Finv(J,k) ; F^-T(k,J) = Finv(J,k) */
+  if (m->kind == MAT_NEOHOOKEAN) {
+    const double c1 = m->lambda * J * (J - 1.) - m->mu;
+    const double c2 = m->lambda * (2. * J - 1.) * J;
+    for (int i = 0; i < dim; ++i)
+      for (int Jx = 0; Jx < dim; ++Jx)
+        for (int j = 0; j < dim; ++j)
+          for (int L = 0; L < dim; ++L) {
+            double v = (i == j && Jx == L) ? m->mu : 0.0;
+            v += -c1 * M(Fi, L, i) * M(Fi, Jx, j);
+            v += c2 * M(Fi, L, j) * M(Fi, Jx, i);
+            A[((i * dim + Jx) * dim + j) * dim + L] = v;
+          }
+    return;
+  }
+  /* J2: P_iJ = J sigma_ik Finv_Jk ; sigma from small-strain radial return */
+  double beta = 1.0, gamma = 0.0;
+  if (w->plastic) {
+    const double q = w->q, G = m->G;
+    beta = 1.0 - 3.0 * G * w->delta / q;
+    gamma = 3.0 * G * (1.5 / q) * (1.0 / ((3.0 * G + w->hprime) * q) - w->delta / (q * q));
+  }
+  const double G2 = 2.0 * m->G;
+  for (int i = 0; i < dim; ++i)
+    for (int Jx = 0; Jx < dim; ++Jx)
+      for (int j = 0; j < dim; ++j)
+        for (int L = 0; L < dim; ++L) {
+          double v = 0.0;
+          for (int k = 0; k < dim; ++k) {
+            /* sigma_ik d(J Finv_Jk)/dF_jL */
+            v += M(w->sigma, i, k) * J * (M(Fi, L, j) * M(Fi, Jx, k) - M(Fi, Jx, j) * M(Fi, L, k));
+            /* J dsigma_ik/dF_jL Finv_Jk */
+            double C = (i == k && j == L ? m->K : 0.0);
+            C += beta * G2 * (0.5 * ((i == j && k == L ? 1.0 : 0.0) + (i == L && k == j ? 1.0 : 0.0))
+                              - (i == k && j == L ? 1.0 / (double)dim : 0.0));
+            C -= G2 * gamma * M(w->s_trial, i, k) * M(w->s_trial, j, L);
+            v += J * C * M(Fi, Jx, k);
+          }
+          A[((i * dim + Jx) * dim + j) * dim + L] = v;
+        }
+}
+
+/* ---- integrator ----------------------------------------------------------- */
+/* integrator_utils.cpp:33-40  ComputeF: F = x_e^T dN_dX + I */
+static void compute_F(int dim, int n_dof, const double* x_e, const double* dNdX, point_work* w) {
+  for (int i = 0; i < dim; ++i)
+    for (int J = 0; J < dim; ++J) {
+      double s = 0;
+      for (int a = 0; a < n_dof; ++a) s += x_e[a + i * n_dof] * dNdX[a + J * n_dof];
+      M(w->F, i, J) = s;
+    }
+  for (int i = 0; i < dim; ++i) M(w->F, i, i) += 1.0;
+  w->detF = det_d(w->F, dim);
+  inv_d(w->F, dim, w->Finv);
+}
+
+static int evaluate_pk1(const oracle_domain* D, int e, int q, point_work* w) {
+  if (D->mat.kind == MAT_NEOHOOKEAN) {
+    neo_hookean_pk1(&D->mat, D->dim, w);
+    return 0;
+  }
+  const long pt = (long)e * D->n_q + q;
+  return j2_plastic_stress(&D->mat, D->dim, D->dt, 0, D->plastic_strain + pt * D->dim * D->dim,
+                           D->eqps + pt, D->temperature + pt, w);
+}
+
+/* nonlinear_solid.hpp:65-87  ElementResidual<false>:
+ *   R_e = sum_q (w_q det_q) dN_dX_q P(F_q)^T   (AddMult_a_ABt) */
+static int element_residual(const oracle_domain* D, int e, const double* x_e, double* R_e) {
+  const int dim = D->dim, n_dof = D->n_dof;
+  int status = 0;
+  memset(R_e, 0, sizeof(double) * n_dof * dim);
+  for (int q = 0; q < D->n_q; ++q) {
+    const long pt = (long)e * D->n_q + q;
+    const double* dNdX = D->dN_dX + pt * n_dof * dim;
+    point_work w;
+    compute_F(dim, n_dof, x_e, dNdX, &w);
+    status |= evaluate_pk1(D, e, q, &w);
+    const double a = D->weight[pt] * D->det[pt];
+    for (int i = 0; i < dim; ++i)
+      for (int J = 0; J < dim; ++J) {
+        const double aP = a * M(w.P, i, J);
+        for (int n = 0; n < n_dof; ++n) R_e[n + i * n_dof] += dNdX[n + J * n_dof] * aP;
+      }
+  }
+  return status;
+}
+
+/* nonlinear_solid.cpp:48-76  ElementResidualAndGrad: forward finite differences,
+ * step |u_i|*1e-8 or 1e-10, K_e column i = (R(u+h e_i) - R(u))/h */
+static int element_residual_and_grad_fd(const oracle_domain* D, int e, double* x_e, double* R_e,
+                                        double* K_e) {
+  const int n_tdof = D->n_dof * D->dim;
+  double fwd[MAX_TDOF];
+  int status = element_residual(D, e, x_e, R_e);
+  double* g = K_e;
+  for (int i = 0; i < n_tdof; ++i) {
+    const double orig = x_e[i];
+    const double step = (orig != 0.0) ? fabs(orig) * 1.0e-8 : 1.0e-10;
+    const double step_inv = 1. / step;
+    x_e[i] = orig + step;
+    status |= element_residual(D, e, x_e, fwd);
+    for (int j = 0; j < n_tdof; ++j) *g++ = (fwd[j] - R_e[j]) * step_inv;
+    x_e[i] = orig;
+  }
+  return status;
+}
+
+/* exact tangent counterpart: K_e[(a,i),(b,j)] = sum_q w det dN_aJ A_iJjL dN_bL */
+static int element_residual_and_grad_exact(const oracle_domain* D, int e, const double* x_e,
+                                           double* R_e, double* K_e) {
+  const int dim = D->dim, n_dof = D->n_dof, n_tdof = n_dof * dim;
+  int status = 0;
+  memset(R_e, 0, sizeof(double) * n_tdof);
+  memset(K_e, 0, sizeof(double) * n_tdof * n_tdof);
+  for (int q = 0; q < D->n_q; ++q) {
+    const long pt = (long)e * D->n_q + q;
+    const double* dNdX = D->dN_dX + pt * n_dof * dim;
+    point_work w;
+    double A[81];
+    compute_F(dim, n_dof, x_e, dNdX, &w);
+    status |= evaluate_pk1(D, e, q, &w);
+    exact_tangent(&D->mat, dim, &w, A);
+    const double wd = D->weight[pt] * D->det[pt];
+    for (int i = 0; i < dim; ++i)
+      for (int J = 0; J < dim; ++J) {
+        const double aP = wd * M(w.P, i, J);
+        for (int n = 0; n < n_dof; ++n) R_e[n + i * n_dof] += dNdX[n + J * n_dof] * aP;
+      }
+    for (int j = 0; j < dim; ++j)
+      for (int b = 0; b < n_dof; ++b) {
+        /* t[i][J] = sum_L A_iJjL dN_bL */
+        double t[9];
+        for (int i = 0; i < dim; ++i)
+          for (int J = 0; J < dim; ++J) {
+            double s = 0;
+            for (int L = 0; L < dim; ++L) s += A[((i * dim + J) * dim + j) * dim + L] * dNdX[b + L * n_dof];
+            t[i * dim + J] = s * wd;
+          }
+        double* col = K_e + (long)(b + j * n_dof) * n_tdof;
+        for (int i = 0; i < dim; ++i)
+          for (int a = 0; a < n_dof; ++a) {
+            double s = 0;
+            for (int J = 0; J < dim; ++J) s += dNdX[a + J * n_dof] * t[i * dim + J];
+            col[a + i * n_dof] += s;
+          }
+      }
+  }
+  return status;
+}
+
+/* element-level entry for tests */
+int oracle_element_residual_and_grad(const oracle_domain* D, int e, const double* u, int mode,
+                                     double* R_e, double* K_e) {
+  const int n_tdof = D->n_dof * D->dim;
+  double x_e[MAX_TDOF];
+  const int* vd = D->v_dofs + (long)e * n_tdof;
+  for (int k = 0; k < n_tdof; ++k) x_e[k] = u[vd[k]];
+  if (mode == TANGENT_FD) return element_residual_and_grad_fd(D, e, x_e, R_e, K_e);
+  return element_residual_and_grad_exact(D, e, x_e, R_e, K_e);
+}
+
+/* nonlinear_solid.cpp:78-105 ThreadLocalResidual + nonlinear_base.hpp:90-107
+ * AddThreadLocalResidual: per-thread full-size vectors, then a chunked reduction */
+int oracle_add_domain_residual(const oracle_domain* D, const double* u, double* r, int n_threads) {
+  const int n_tdof = D->n_dof * D->dim;
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > D->n_el) n_threads = D->n_el;
+  double* tl = (double*)malloc(sizeof(double) * (size_t)n_threads * D->n_vdofs);
+  if (!tl) return -1;
+  int status = 0;
+#pragma omp parallel for num_threads(n_threads) reduction(| : status)
+  for (int t = 0; t < n_threads; ++t) {
+    long b, en;
+    chunk_rule(D->n_el, n_threads, t, &b, &en);
+    double* tr = tl + (size_t)t * D->n_vdofs;
+    memset(tr, 0, sizeof(double) * D->n_vdofs);
+    double x_e[MAX_TDOF], R_e[MAX_TDOF];
+    for (long e = b; e < en; ++e) {
+      const int* vd = D->v_dofs + e * n_tdof;
+      for (int k = 0; k < n_tdof; ++k) x_e[k] = u[vd[k]];
+      status |= element_residual(D, (int)e, x_e, R_e);
+      for (int k = 0; k < n_tdof; ++k) tr[vd[k]] += R_e[k];
+    }
+  }
+#pragma omp parallel for num_threads(n_threads)
+  for (int t = 0; t < n_threads; ++t) {
+    long b, en;
+    chunk_rule(D->n_vdofs, n_threads, t, &b, &en);
+    for (int s = 0; s < n_threads; ++s) {
+      const double* tr = tl + (size_t)s * D->n_vdofs;
+      for (long j = b; j < en; ++j) r[j] += tr[j];
+    }
+  }
+  free(tl);
+  return status;
+}
+
+/* nonlinear_solid.cpp:107-149 ThreadLocalResidualAndGrad + nonlinear_base.hpp:112-151
+ * AddThreadLocalResidualAndGrad: per-thread full-size residual AND nnz-sized value
+ * arrays, zeroed every call, A[A_ids[k]] += K_e[k], then
+ * A += grad_factor * sum_t A_t in chunks.  mode selects FD (reference) or exact. */
+int oracle_add_domain_residual_and_grad(const oracle_domain* D, const double* u, double grad_factor,
+                                        double* r, double* A, long nnz, int n_threads, int mode) {
+  const int n_tdof = D->n_dof * D->dim;
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > D->n_el) n_threads = D->n_el;
+  double* tlr = (double*)malloc(sizeof(double) * (size_t)n_threads * D->n_vdofs);
+  double* tlA = (double*)malloc(sizeof(double) * (size_t)n_threads * nnz);
+  if (!tlr || !tlA) {
+    free(tlr);
+    free(tlA);
+    return -1;
+  }
+  int status = 0;
+#pragma omp parallel for num_threads(n_threads) reduction(| : status)
+  for (int t = 0; t < n_threads; ++t) {
+    long b, en;
+    chunk_rule(D->n_el, n_threads, t, &b, &en);
+    double* tr = tlr + (size_t)t * D->n_vdofs;
+    double* tA = tlA + (size_t)t * nnz;
+    memset(tr, 0, sizeof(double) * D->n_vdofs);
+    memset(tA, 0, sizeof(double) * nnz);
+    double x_e[MAX_TDOF], R_e[MAX_TDOF];
+    double* K_e = (double*)malloc(sizeof(double) * n_tdof * n_tdof);
+    for (long e = b; e < en; ++e) {
+      const int* vd = D->v_dofs + e * n_tdof;
+      for (int k = 0; k < n_tdof; ++k) x_e[k] = u[vd[k]];
+      if (mode == TANGENT_FD)
+        status |= element_residual_and_grad_fd(D, (int)e, x_e, R_e, K_e);
+      else
+        status |= element_residual_and_grad_exact(D, (int)e, x_e, R_e, K_e);
+      for (int k = 0; k < n_tdof; ++k) tr[vd[k]] += R_e[k];
+      const int* ids = D->a_ids + e * (long)n_tdof * n_tdof;
+      for (int k = 0; k < n_tdof * n_tdof; ++k) tA[ids[k]] += K_e[k];
+    }
+    free(K_e);
+  }
+#pragma omp parallel for num_threads(n_threads)
+  for (int t = 0; t < n_threads; ++t) {
+    long rb, re, gb, ge;
+    chunk_rule(D->n_vdofs, n_threads, t, &rb, &re);
+    chunk_rule(nnz, n_threads, t, &gb, &ge);
+    for (int s = 0; s < n_threads; ++s) {
+      const double* tr = tlr + (size_t)s * D->n_vdofs;
+      for (long j = rb; j < re; ++j) r[j] += tr[j];
+      const double* tA = tlA + (size_t)s * nnz;
+      for (long j = gb; j < ge; ++j) A[j] += grad_factor * tA[j];
+    }
+  }
+  free(tlr);
+  free(tlA);
+  return status;
+}
+
+/* nonlinear_solid.cpp:179-199 DomainPostTimeAdvance -> ElementResidual<true> ->
+ * J2::Accumulate (materials.hpp:399-402) */
+int oracle_domain_post_time_advance(const oracle_domain* D, const double* u, int n_threads) {
+  if (D->mat.kind != MAT_J2) return 0;
+  const int dim = D->dim, n_dof = D->n_dof, n_tdof = n_dof * dim;
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > D->n_el) n_threads = D->n_el;
+  int status = 0;
+#pragma omp parallel for num_threads(n_threads) reduction(| : status)
+  for (int t = 0; t < n_threads; ++t) {
+    long b, en;
+    chunk_rule(D->n_el, n_threads, t, &b, &en);
+    double x_e[MAX_TDOF];
+    for (long e = b; e < en; ++e) {
+      const int* vd = D->v_dofs + e * n_tdof;
+      for (int k = 0; k < n_tdof; ++k) x_e[k] = u[vd[k]];
+      for (int q = 0; q < D->n_q; ++q) {
+        const long pt = e * D->n_q + q;
+        point_work w;
+        compute_F(dim, n_dof, x_e, D->dN_dX + pt * n_dof * dim, &w);
+        status |= j2_plastic_stress(&D->mat, dim, D->dt, 1, D->plastic_strain + pt * dim * dim,
+                                    D->eqps + pt, D->temperature + pt, &w);
+      }
+    }
+  }
+  return status;
+}
+
+/* point-level entry for tests: F (column-major dim x dim) -> P and exact dP/dF */
+int oracle_point_pk1(const oracle_material* m, int dim, double dt, const double* F,
+                     const double* plastic_strain, double eqps, double temperature, double* P,
+                     double* A) {
+  point_work w;
+  memcpy(w.F, F, sizeof(double) * dim * dim);
+  w.detF = det_d(w.F, dim);
+  inv_d(w.F, dim, w.Finv);
+  int status = 0;
+  if (m->kind == MAT_NEOHOOKEAN) {
+    neo_hookean_pk1(m, dim, &w);
+  } else {
+    double ps[9];
+    memcpy(ps, plastic_strain, sizeof(double) * dim * dim);
+    status = j2_plastic_stress(m, dim, dt, 0, ps, &eqps, &temperature, &w);
+  }
+  memcpy(P, w.P, sizeof(double) * dim * dim);
+  if (A) exact_tangent(m, dim, &w, A);
+  return status;
+}
+
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

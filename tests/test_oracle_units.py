@@ -1,0 +1,153 @@
+"""Unit checks of the oracle itself (CPU only): its exact tangent against high-order
+finite differences, the reference-rule FD against the exact tangent within the FD's
+own error, tables against closed forms, CSR/A_ids conventions."""
+import numpy as np
+import pytest
+
+from _cases import oracle_material, synthetic_u
+
+
+def _richardson_tangent(mat, F, h=1e-4, **kw):
+    from oracle import ref_path as rp
+    dim = F.shape[0]
+    A = np.zeros((dim,) * 4)
+    for j in range(dim):
+        for L in range(dim):
+            def P(s):
+                G = F.copy()
+                G[j, L] += s
+                return rp.point_pk1(mat, G, **kw)[0]
+            d1 = (P(h) - P(-h)) / (2 * h)
+            d2 = (P(h / 2) - P(-h / 2)) / h
+            A[:, :, j, L] = (4 * d2 - d1) / 3
+    return A
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_neohookean_point(dim):
+    from oracle import ref_path as rp
+    mat = oracle_material("neohook")
+    rng = np.random.default_rng(1)
+    F = np.eye(dim) + 0.1 * rng.standard_normal((dim, dim))
+    P, A = rp.point_pk1(mat, F)
+    J = np.linalg.det(F)
+    lam, mu = mat.lambda_, mat.mu
+    # closed form of materials.cpp:96-118 + :60-71
+    Pref = mu * F + (lam * J * (J - 1) - mu) * np.linalg.inv(F).T
+    assert np.allclose(P, Pref, rtol=1e-13, atol=1e-10)
+    Afd = _richardson_tangent(mat, F)
+    assert np.abs(A - Afd).max() < 1e-6 * np.abs(A).max()
+    # major symmetry of a hyperelastic tangent
+    assert np.allclose(A, np.transpose(A, (2, 3, 0, 1)), atol=1e-9)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_j2_point_elastic_and_plastic(dim):
+    from oracle import ref_path as rp
+    mat = oracle_material("j2")
+    rng = np.random.default_rng(2)
+    # elastic: tiny strain
+    F = np.eye(dim) + 1e-4 * rng.standard_normal((dim, dim))
+    P, A = rp.point_pk1(mat, F, dt=0.5)
+    Afd = _richardson_tangent(mat, F, h=1e-6, dt=0.5)
+    assert np.abs(A - Afd).max() < 1e-6 * np.abs(A).max()
+    # plastic: large shear, with prior plastic strain / eqps
+    F = np.eye(dim) + 0.08 * rng.standard_normal((dim, dim))
+    ep = 0.01 * rng.standard_normal((dim, dim))
+    ep = 0.5 * (ep + ep.T)
+    kw = dict(dt=0.5, plastic_strain=ep, eqps=0.02, temperature=25.0)
+    P, A = rp.point_pk1(mat, F, **kw)
+    Afd = _richardson_tangent(mat, F, h=1e-5, **kw)
+    assert np.abs(A - Afd).max() < 1e-5 * np.abs(A).max()
+    # yield consistency: q(sigma_dev) == H(eqps+D)*theta at the returned state
+    sig = P @ F.T / np.linalg.det(F)
+    s = sig - np.trace(sig) / dim * np.eye(dim)
+    q = np.sqrt(1.5) * np.linalg.norm(s)
+    assert q > mat.A
+
+
+@pytest.mark.parametrize("case", [((2, 2), 3), ((3, 2, 2), 2), ((2, 2, 1), 3), ((3, 3), 2)])
+@pytest.mark.parametrize("matname", ["neohook", "j2"])
+def test_element_exact_vs_reference_fd(case, matname):
+    """Jacobian parity contract: the reference's forward-FD K_e equals the
+    exact tangent within the FD's own truncation/round-off error."""
+    from oracle import iga, ref_path as rp
+    n_el, p = case
+    P = iga.Patch.block(n_el, p)
+    D = rp.DomainOracle(P, oracle_material(matname))
+    D.set_dt(0.5)
+    u = synthetic_u(P, scale=0.05 if matname == "neohook" else 0.01)
+    worst = 0.0
+    for e in range(min(P.n_el, 3)):
+        R0, Kfd = D.element_residual_and_grad(e, u, rp.TANGENT_FD)
+        R1, Kex = D.element_residual_and_grad(e, u, rp.TANGENT_EXACT)
+        assert np.array_equal(R0, R1) or np.allclose(R0, R1, rtol=1e-14, atol=1e-12)
+        worst = max(worst, np.linalg.norm(Kfd - Kex) / np.linalg.norm(Kex))
+    # SURVEY 8c measured 8e-6 (|u|~0.05h) .. 4e-3 (|u|~1e-4h) for this FD rule
+    assert worst < 5e-4, worst
+
+
+def test_tables_partition_of_unity_and_volume():
+    from oracle import iga
+    for n_el, p in [((3, 2), 2), ((2, 3, 2), 2), ((2, 2, 2), 3)]:
+        P = iga.Patch.block(n_el, p)
+        t = P.tables()
+        assert np.abs(t["N"].sum(-1) - 1).max() < 1e-13
+        assert np.abs(t["dN_dX"].sum(2)).max() < 1e-12
+        assert np.isclose((t["weight"] * t["det"]).sum(), np.prod(n_el))
+        nq = P.quad_points_per_dir()
+        assert nq == [p + 2] * len(n_el)          # order 2p+3 -> (2p+3)//2+1 points
+
+
+def test_rational_tables_reduce_to_bspline_and_differ():
+    from oracle import iga
+    P = iga.Patch.block((2, 2), 2)
+    w = np.ones(P.n_nodes)
+    w[5] = 0.7
+    Q = iga.Patch(P.p, P.knots, P.ctrl, w)
+    t = Q.tables()
+    assert np.abs(t["N"].sum(-1) - 1).max() < 1e-13
+    assert np.abs(t["dN_dX"].sum(2)).max() < 1e-12
+    assert np.abs(t["N"] - P.tables()["N"]).max() > 1e-3
+
+
+def test_sparsity_and_a_ids_convention():
+    from oracle import iga
+    P = iga.Patch.block((8, 8, 2), 2)
+    rowptr, col = P.sparsity()
+    assert rowptr[-1] == 243936
+    P = iga.Patch.block((2, 2), 3, [5.0, 1.0])
+    rowptr, col = P.sparsity()
+    ids = P.a_ids(rowptr, col)
+    vd = P.vdofs()
+    nt = vd.shape[1]
+    e, r, c = 2, 5, 17
+    pos = ids[e, c * nt + r]                     # column-major (precomputed.cpp:185-199)
+    assert rowptr[vd[e, r]] <= pos < rowptr[vd[e, r] + 1] and col[pos] == vd[e, c]
+    for i in range(len(rowptr) - 1):
+        assert np.all(np.diff(col[rowptr[i]:rowptr[i + 1]]) > 0)
+
+
+def test_assembly_fd_matches_dense_reference_sum():
+    """global FD assembly == sum of element blocks scattered by hand."""
+    from oracle import iga, ref_path as rp
+    P = iga.Patch.block((2, 2, 2), 2)
+    D = rp.DomainOracle(P, oracle_material("neohook"), n_threads=3)
+    u = synthetic_u(P)
+    r = np.zeros(P.n_vdofs)
+    A = np.zeros(D.nnz)
+    D.add_domain_residual_and_grad(u, 0.7, r, A, rp.TANGENT_FD)
+    n = P.n_vdofs
+    dense = np.zeros((n, n))
+    rr = np.zeros(n)
+    for e in range(P.n_el):
+        Re, Ke = D.element_residual_and_grad(e, u, rp.TANGENT_FD)
+        vd = D.v_dofs[e]
+        rr[vd] += Re
+        dense[np.ix_(vd, vd)] += 0.7 * Ke
+    rows = np.repeat(np.arange(n), np.diff(D.rowptr))
+    assert np.allclose(A, dense[rows, D.col], rtol=1e-12, atol=1e-9)
+    assert np.allclose(r, rr, rtol=1e-13, atol=1e-12)
+    r2 = np.zeros(n)
+    D.add_domain_residual(u, r2)
+    assert np.allclose(r2, rr, rtol=1e-13, atol=1e-12)
