@@ -1,0 +1,215 @@
+/* mimi_hip.h -- C ABI of libmimi_hip.so: MI355X (gfx950) element integration and
+ * assembly for mimi's NURBS nonlinear solids.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one virtual of the
+ * reference's `mimi::integrators::NonlinearBase` (or the setup that feeds it); the
+ * reference interface it stands in for is cited as path:line under
+ * /root/reference/src/mimi/.  INTEGRATION.md shows the C++ subclass a mimi maintainer
+ * would add to bind these.
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in any signature.
+ *  - every `const double*` / `double*` / index pointer argument may be a HOST or a
+ *    DEVICE pointer; the library detects which (hipPointerGetAttributes).  Host
+ *    buffers are staged through device scratch and the call is synchronous; device
+ *    buffers are used in place and the call only enqueues work on the handle's
+ *    stream (mimi_hip_*_set_stream / mimi_hip_*_synchronize).
+ *  - u, r: fp64[n_vdofs], byVDIM ordering u[node*dim + c]   (py_nonlinear_solid.cpp:63,74)
+ *  - A_values: fp64[nnz] of a CSR matrix with sorted columns whose structure
+ *    (rowptr, col) was given at create time and never changes (precomputed.cpp:151-174,
+ *    nonlinear_base.hpp:130).  Outputs are ACCUMULATED (+=), never overwritten.
+ *  - return value: 0 on success, non-zero on error; mimi_hip_last_error() then holds
+ *    the message the reference would have thrown as std::runtime_error
+ *    (utils/print.hpp:47-56).  Not re-entrant per handle (like the reference:
+ *    mutable work data, nonlinear_solid.hpp:42).
+ */
+#ifndef MIMI_HIP_H
+#define MIMI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIMI_HIP_ABI_VERSION 1
+
+/* ---- errors ---------------------------------------------------------------- */
+const char* mimi_hip_last_error(void);
+int mimi_hip_abi_version(void);
+/* number of visible HIP devices (0 on a CPU-only host; never throws) */
+int mimi_hip_device_count(void);
+
+/* ---- materials (materials/materials.hpp, materials/material_hardening.hpp) -- */
+enum mimi_hip_material_kind {
+  MIMI_HIP_MAT_NEOHOOKEAN = 0, /* CompressibleOgdenNeoHookean  materials.hpp:118-140, materials.cpp:96-118 */
+  MIMI_HIP_MAT_J2 = 1          /* J2 (small strain, nonlinear isotropic hardening) materials.hpp:259-403 */
+};
+
+enum mimi_hip_hardening_kind {
+  MIMI_HIP_HARD_POWERLAW = 0,      /* material_hardening.hpp:79-98  */
+  MIMI_HIP_HARD_VOCE = 1,          /* :100-121 */
+  MIMI_HIP_HARD_JC = 2,            /* JohnsonCookHardening :123-143 */
+  MIMI_HIP_HARD_JC_RATE = 3,       /* JohnsonCookRateDependentHardening :145-187 */
+  MIMI_HIP_HARD_JC_TEMP_RATE = 4,  /* JohnsonCookTemperatureAndRateDependentHardening :189-280 */
+  MIMI_HIP_HARD_JC_CONST_TEMP = 5  /* JohnsonCookConstantTemperatureHardening :282-346 */
+};
+
+typedef struct mimi_hip_material {
+  int32_t kind;                 /* mimi_hip_material_kind */
+  int32_t hardening;            /* mimi_hip_hardening_kind (J2 only) */
+  /* MaterialBase (materials.hpp:31-38); set lambda/mu/K/G with mimi_hip_material_set_young_poisson */
+  double density, lambda, mu, K, G;
+  /* J2 thermo members (materials.hpp:268-273) */
+  double heat_fraction, specific_heat, initial_temperature, melting_temperature;
+  /* hardening parameters; unused ones are ignored */
+  double sigma_y, n, eps0;                  /* PowerLaw (n shared with JohnsonCook) */
+  double sigma_sat, strain_constant;        /* Voce */
+  double A, B, C, eps0_dot;                 /* JohnsonCook: A + B eqps^n, rate term 1 + C ln(rate/eps0_dot) */
+  double reference_temperature, m;          /* thermal softening exponent m */
+} mimi_hip_material;
+
+/* MaterialBase::SetYoungPoisson (materials.cpp:7-14) */
+void mimi_hip_material_set_young_poisson(mimi_hip_material* mat, double young, double poisson);
+
+/* ---- tangent mode ------------------------------------------------------------ */
+enum mimi_hip_tangent_mode {
+  MIMI_HIP_TANGENT_ANALYTIC = 0,     /* consistent tangent dP/dF, closed form (default) */
+  MIMI_HIP_TANGENT_REFERENCE_FD = 1  /* the reference's element-level forward difference,
+                                        step |u_i|*1e-8 or 1e-10 (nonlinear_solid.cpp:48-76) */
+};
+
+/* ---- domain integrator: integrators::NonlinearSolid ---------------------------- */
+typedef struct mimi_hip_domain_s* mimi_hip_domain_t;
+
+/* Flat form of what PrecomputedData hands the reference integrator
+ * (utils/precomputed.hpp:58-130, utils/precomputed.cpp:39-330). */
+typedef struct mimi_hip_domain_tables {
+  int32_t dim;           /* 2 or 3 */
+  int32_t n_elements;
+  int32_t n_dof;         /* ElementData::n_dof, basis functions per element, <= 64 */
+  int32_t n_quad;        /* ElementQuadData::n_quad, <= 125 */
+  int64_t n_nodes;       /* global scalar dofs; n_vdofs = n_nodes*dim */
+  const int32_t* dofs;   /* [n_elements][n_dof]   ElementData::dofs (precomputed.cpp:83) */
+  const double* dN_dX;   /* [n_elements][n_quad][dim][n_dof]  QuadData::dN_dX, (n_dof x dim)
+                            column-major per point (precomputed.cpp:316-321) */
+  const double* weight_det; /* [n_elements][n_quad] integration_weight*det_dX_dxi (nonlinear_solid.hpp:79) */
+  const int64_t* csr_rowptr; /* [n_vdofs+1] */
+  const int32_t* csr_col;    /* [nnz], sorted within each row */
+} mimi_hip_domain_tables;
+
+/* NonlinearSolid ctor + Prepare() (nonlinear_solid.hpp:45-50, nonlinear_solid.cpp:31-46)
+ * from flat per-point tables: works for any mesh / numbering / rational weights. */
+int mimi_hip_domain_create(const mimi_hip_domain_tables* tables, const mimi_hip_material* material,
+                           int device, mimi_hip_domain_t* out);
+
+/* Tensor-product B-spline patch description (weights all 1): the library builds the
+ * 1-D basis tables, per-point inverse geometry Jacobians and weights itself
+ * (replaces PrepareElementData + PrecomputeElementQuadData, precomputed.cpp:39-149,264-330)
+ * and integrates by sum factorisation.  Lexicographic conventions: node
+ * A = A0 + n0*(A1 + n1*A2), element e = e0 + m0*(e1 + m1*e2). */
+typedef struct mimi_hip_bspline_patch {
+  int32_t dim;
+  int32_t degree[3];
+  int32_t n_knots[3];
+  const double* knots[3];        /* host pointers */
+  const double* control_points;  /* host, [n_nodes][dim], lexicographic */
+  const int64_t* node_ids;       /* host, [n_nodes] lexicographic -> global node id, or NULL (identity) */
+  int32_t quadrature_order;      /* < 0: 2*p+3 (precomputed.cpp:284-286) */
+  int32_t element_begin[3];      /* half-open element box [begin,end) integrated by THIS handle  */
+  int32_t element_end[3];        /* (element sharding across GPUs); all zeros = whole patch       */
+  const int64_t* csr_rowptr;     /* [n_vdofs+1] host or device */
+  const int32_t* csr_col;        /* [nnz]       host or device */
+} mimi_hip_bspline_patch;
+
+int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* patch, const mimi_hip_material* material,
+                                   int device, mimi_hip_domain_t* out);
+
+int mimi_hip_domain_destroy(mimi_hip_domain_t h);
+
+/* public members dt_, first_effective_dt_, second_effective_dt_ that forms::Nonlinear
+ * pushes before every call (nonlinear_base.hpp:23-25, forms/nonlinear.hpp:63-65) */
+int mimi_hip_domain_set_dt(mimi_hip_domain_t h, double dt, double first_effective_dt,
+                           double second_effective_dt);
+int mimi_hip_domain_set_tangent_mode(mimi_hip_domain_t h, int mode);
+/* stream = hipStream_t as void*; NULL = the handle's own stream */
+int mimi_hip_domain_set_stream(mimi_hip_domain_t h, void* stream);
+int mimi_hip_domain_synchronize(mimi_hip_domain_t h);
+
+/* AddDomainResidual(current_u, residual): r += R(u)   (nonlinear_solid.cpp:151-160) */
+int mimi_hip_domain_add_residual(mimi_hip_domain_t h, const double* u, double* r);
+/* AddDomainResidualAndGrad(current_u, grad_factor, residual, grad):
+ * r += R(u); A_values += grad_factor * K(u)            (nonlinear_solid.cpp:162-177) */
+int mimi_hip_domain_add_residual_and_grad(mimi_hip_domain_t h, const double* u, double grad_factor,
+                                          double* r, double* A_values);
+/* DomainPostTimeAdvance(converged_u): commit material state (nonlinear_solid.cpp:179-199) */
+int mimi_hip_domain_post_time_advance(mimi_hip_domain_t h, const double* u);
+
+/* material state access (MaterialState of materials.hpp:278-286), for tests / output:
+ * what = 0 accumulated plastic strain [n_el][n_q]; 1 temperature [n_el][n_q];
+ *        2 plastic strain [n_el][n_q][dim*dim] (column-major per point) */
+int mimi_hip_domain_get_state(mimi_hip_domain_t h, int what, double* out, int64_t capacity);
+int mimi_hip_domain_reset_state(mimi_hip_domain_t h);
+/* sizes: what = 0 n_elements, 1 n_quad, 2 n_dof, 3 nnz, 4 n_vdofs, 5 path (0 general, 1 tensor) */
+int64_t mimi_hip_domain_info(mimi_hip_domain_t h, int what);
+
+/* ---- structured sparsity: PrecomputedData::PrepareSparsity (precomputed.cpp:151-174) ----
+ * CSR pattern of a single B-spline patch with lexicographic node numbering, built on the
+ * device.  Call once with col == NULL to fill rowptr ([n_vdofs+1], device or host) and get
+ * nnz, then again with col ([nnz], device or host). */
+int mimi_hip_bspline_sparsity(int32_t dim, const int32_t n_nodes_dir[3], const int32_t degree[3],
+                              int device, int64_t* rowptr, int32_t* col, int64_t* nnz);
+
+/* ---- contact integrator: integrators::MortarContact ------------------------------ */
+typedef struct mimi_hip_contact_s* mimi_hip_contact_t;
+
+enum mimi_hip_rigid_body_kind {
+  MIMI_HIP_BODY_SPHERE = 0, /* params: centre[3], radius */
+  MIMI_HIP_BODY_PLANE = 1   /* params: point[3], unit normal[3] pointing out of the rigid half space */
+};
+
+/* Flat form of the boundary-element tables MortarContact::Prepare builds
+ * (mortar_contact.cpp:19-133) plus the analytic rigid body standing in for
+ * NearestDistanceBase (coefficients/nearest_distance.hpp:14-213). */
+typedef struct mimi_hip_contact_tables {
+  int32_t dim;
+  int32_t n_faces;
+  int32_t n_dof;        /* per face, <= 16 */
+  int32_t n_quad;       /* <= 25 */
+  int64_t n_nodes;
+  const int32_t* dofs;  /* [n_faces][n_dof] global node ids of the marked boundary elements */
+  const double* N;      /* [n_faces][n_quad][n_dof]          QuadData::N */
+  const double* dN_dxi; /* [n_faces][n_quad][dim-1][n_dof]   QuadData::dN_dxi */
+  const double* weight; /* [n_faces][n_quad]                 QuadData::integration_weight */
+  const double* x_ref;  /* [n_nodes][dim] reference coordinates of the control points (byVDIM) */
+  int32_t body_kind;
+  double body[8];
+  double penalty;       /* NearestDistanceBase::coefficient_ (nearest_distance.hpp:18) */
+  const int64_t* csr_rowptr;
+  const int32_t* csr_col;
+} mimi_hip_contact_tables;
+
+int mimi_hip_contact_create(const mimi_hip_contact_tables* tables, int device, mimi_hip_contact_t* out);
+int mimi_hip_contact_destroy(mimi_hip_contact_t h);
+int mimi_hip_contact_set_tangent_mode(mimi_hip_contact_t h, int mode);
+int mimi_hip_contact_set_stream(mimi_hip_contact_t h, void* stream);
+int mimi_hip_contact_synchronize(mimi_hip_contact_t h);
+/* AddBoundaryResidual (mortar_contact.cpp:297-351) */
+int mimi_hip_contact_add_residual(mimi_hip_contact_t h, const double* u, double* r);
+/* AddBoundaryResidualAndGrad (mortar_contact.cpp:353-421) */
+int mimi_hip_contact_add_residual_and_grad(mimi_hip_contact_t h, const double* u, double grad_factor,
+                                           double* r, double* A_values);
+/* GapNorm (mortar_contact.cpp:423-467) */
+int mimi_hip_contact_gap_norm(mimi_hip_contact_t h, const double* u, double* out);
+/* last_area_, last_pressure_, last_force_[dim] of the latest Add* call
+ * (mortar_contact.hpp:33-35; BoundaryPostTimeAdvance mortar_contact.cpp:469-488):
+ * out[0] = area, out[1] = pressure integral, out[2..2+dim) = force */
+int mimi_hip_contact_last_history(mimi_hip_contact_t h, double* out5);
+/* nodal average_pressure_ (mortar_contact.hpp:59), [n_marked]; returns n_marked via *n */
+int mimi_hip_contact_get_pressure(mimi_hip_contact_t h, double* out, int64_t capacity, int64_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIMI_HIP_H */

@@ -1,0 +1,12 @@
+"""mimi_amd -- MI355X-native element integration / assembly for mimi's NURBS nonlinear
+solids.  The compute path is libmimi_hip.so (hand-written HIP for gfx950, C ABI in
+include/mimi_hip.h); this package is the host-side mirror of the reference's operator
+surface.  There is no CPU fallback."""
+from .materials import (CompressibleOgdenNeoHookean, J2, Material, HardeningBase, PowerLawHardening,
+                        VoceHardening, JohnsonCookHardening, JohnsonCookRateDependentHardening,
+                        JohnsonCookTemperatureAndRateDependentHardening,
+                        JohnsonCookConstantTemperatureHardening)
+from .splines import BSplinePatch
+from . import integrators
+
+__all__ = ["CompressibleOgdenNeoHookean", "J2", "Material", "BSplinePatch", "integrators"]

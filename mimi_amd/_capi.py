@@ -1,0 +1,143 @@
+"""ctypes binding of libmimi_hip.so (include/mimi_hip.h).  There is no CPU fallback:
+if the library is missing or no HIP device is visible, calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_lib = None
+
+
+class Material(C.Structure):
+    """mimi_hip_material"""
+    _fields_ = [("kind", C.c_int32), ("hardening", C.c_int32),
+                ("density", C.c_double), ("lambda_", C.c_double), ("mu", C.c_double),
+                ("K", C.c_double), ("G", C.c_double),
+                ("heat_fraction", C.c_double), ("specific_heat", C.c_double),
+                ("initial_temperature", C.c_double), ("melting_temperature", C.c_double),
+                ("sigma_y", C.c_double), ("n", C.c_double), ("eps0", C.c_double),
+                ("sigma_sat", C.c_double), ("strain_constant", C.c_double),
+                ("A", C.c_double), ("B", C.c_double), ("C", C.c_double), ("eps0_dot", C.c_double),
+                ("reference_temperature", C.c_double), ("m", C.c_double)]
+
+
+class DomainTables(C.Structure):
+    """mimi_hip_domain_tables"""
+    _fields_ = [("dim", C.c_int32), ("n_elements", C.c_int32), ("n_dof", C.c_int32), ("n_quad", C.c_int32),
+                ("n_nodes", C.c_int64),
+                ("dofs", C.c_void_p), ("dN_dX", C.c_void_p), ("weight_det", C.c_void_p),
+                ("csr_rowptr", C.c_void_p), ("csr_col", C.c_void_p)]
+
+
+class BSplinePatch(C.Structure):
+    """mimi_hip_bspline_patch"""
+    _fields_ = [("dim", C.c_int32), ("degree", C.c_int32 * 3), ("n_knots", C.c_int32 * 3),
+                ("knots", C.c_void_p * 3), ("control_points", C.c_void_p), ("node_ids", C.c_void_p),
+                ("quadrature_order", C.c_int32),
+                ("element_begin", C.c_int32 * 3), ("element_end", C.c_int32 * 3),
+                ("csr_rowptr", C.c_void_p), ("csr_col", C.c_void_p)]
+
+
+class ContactTables(C.Structure):
+    """mimi_hip_contact_tables"""
+    _fields_ = [("dim", C.c_int32), ("n_faces", C.c_int32), ("n_dof", C.c_int32), ("n_quad", C.c_int32),
+                ("n_nodes", C.c_int64),
+                ("dofs", C.c_void_p), ("N", C.c_void_p), ("dN_dxi", C.c_void_p), ("weight", C.c_void_p),
+                ("x_ref", C.c_void_p),
+                ("body_kind", C.c_int32), ("body", C.c_double * 8), ("penalty", C.c_double),
+                ("csr_rowptr", C.c_void_p), ("csr_col", C.c_void_p)]
+
+
+EXPORTS = [
+    "mimi_hip_last_error", "mimi_hip_abi_version", "mimi_hip_device_count",
+    "mimi_hip_material_set_young_poisson",
+    "mimi_hip_domain_create", "mimi_hip_domain_create_bspline", "mimi_hip_domain_destroy",
+    "mimi_hip_domain_set_dt", "mimi_hip_domain_set_tangent_mode", "mimi_hip_domain_set_stream",
+    "mimi_hip_domain_synchronize", "mimi_hip_domain_add_residual",
+    "mimi_hip_domain_add_residual_and_grad", "mimi_hip_domain_post_time_advance",
+    "mimi_hip_domain_get_state", "mimi_hip_domain_reset_state", "mimi_hip_domain_info",
+    "mimi_hip_bspline_sparsity",
+    "mimi_hip_contact_create", "mimi_hip_contact_destroy", "mimi_hip_contact_set_tangent_mode",
+    "mimi_hip_contact_set_stream", "mimi_hip_contact_synchronize", "mimi_hip_contact_add_residual",
+    "mimi_hip_contact_add_residual_and_grad", "mimi_hip_contact_gap_norm",
+    "mimi_hip_contact_last_history", "mimi_hip_contact_get_pressure",
+]
+
+
+def library_path():
+    return _build.LIB
+
+
+def lib():
+    """Load libmimi_hip.so (building it if hipcc is around and the file is stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: run `python -m mimi_amd.build` (hipcc --offload-arch=gfx950). "
+            "mimi_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7; when it is
+    # loaded first our NEEDED entry resolves to that same copy (same soname), and device
+    # pointers / streams can be shared with torch.  Loading ours first would hand torch a
+    # runtime it was not built against.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(path)
+    L.mimi_hip_last_error.restype = C.c_char_p
+    L.mimi_hip_domain_info.restype = C.c_int64
+    L.mimi_hip_domain_info.argtypes = [C.c_void_p, C.c_int]
+    L.mimi_hip_domain_add_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mimi_hip_domain_add_residual_and_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    L.mimi_hip_domain_post_time_advance.argtypes = [C.c_void_p, C.c_void_p]
+    L.mimi_hip_domain_set_dt.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+    L.mimi_hip_domain_set_tangent_mode.argtypes = [C.c_void_p, C.c_int]
+    L.mimi_hip_domain_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.mimi_hip_domain_synchronize.argtypes = [C.c_void_p]
+    L.mimi_hip_domain_destroy.argtypes = [C.c_void_p]
+    L.mimi_hip_domain_get_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    L.mimi_hip_domain_reset_state.argtypes = [C.c_void_p]
+    L.mimi_hip_domain_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.mimi_hip_domain_create_bspline.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.mimi_hip_bspline_sparsity.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mimi_hip_material_set_young_poisson.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.mimi_hip_material_set_young_poisson.restype = None
+    L.mimi_hip_contact_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.mimi_hip_contact_destroy.argtypes = [C.c_void_p]
+    L.mimi_hip_contact_set_tangent_mode.argtypes = [C.c_void_p, C.c_int]
+    L.mimi_hip_contact_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.mimi_hip_contact_synchronize.argtypes = [C.c_void_p]
+    L.mimi_hip_contact_add_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mimi_hip_contact_add_residual_and_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    L.mimi_hip_contact_gap_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mimi_hip_contact_last_history.argtypes = [C.c_void_p, C.c_void_p]
+    L.mimi_hip_contact_get_pressure.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    _lib = L
+    return L
+
+
+def check(status):
+    """non-zero status -> RuntimeError carrying the library's message (the reference throws
+    std::runtime_error -> Python RuntimeError through pybind11, utils/print.hpp:47-56)."""
+    if status != 0:
+        raise RuntimeError(lib().mimi_hip_last_error().decode())
+
+
+def ptr(x):
+    """void* of a numpy array (host) or a torch tensor (host or device) or None."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        assert x.flags.c_contiguous
+        return x.ctypes.data_as(C.c_void_p)
+    if hasattr(x, "data_ptr"):
+        assert x.is_contiguous()
+        return C.c_void_p(x.data_ptr())
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    raise TypeError(type(x))

@@ -1,0 +1,40 @@
+"""In-tree build of libmimi_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libmimi_hip.so")
+SOURCES = ["domain.hip", "contact.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
+         "-Wno-unused-result"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "mimi_hip.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source of the package into mimi_amd/lib/libmimi_hip.so."""
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    cmd = [hipcc] + FLAGS + ["-o", LIB + ".tmp"] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,572 @@
+// C ABI of the domain integrator (include/mimi_hip.h): handle life cycle, table upload /
+// generation, kernel dispatch.  Reference counterparts:
+//   NonlinearSolid::Prepare                      integrators/nonlinear_solid.cpp:31-46
+//   NonlinearSolid::AddDomainResidual            integrators/nonlinear_solid.cpp:151-160
+//   NonlinearSolid::AddDomainResidualAndGrad     integrators/nonlinear_solid.cpp:162-177
+//   NonlinearSolid::DomainPostTimeAdvance        integrators/nonlinear_solid.cpp:179-199
+#include "domain.hpp"
+#include "kernels_general.hpp"
+#include "kernels_setup.hpp"
+#include "kernels_tensor.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <mutex>
+
+namespace mimi_hip {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+
+MaterialDev make_material_dev(const mimi_hip_material& m) {
+  MaterialDev d{};
+  d.m = m;
+  d.const_temperature_contribution = 1.0;
+  if (m.kind == MIMI_HIP_MAT_J2) {
+    if (m.hardening < MIMI_HIP_HARD_POWERLAW || m.hardening > MIMI_HIP_HARD_JC_CONST_TEMP)
+      fail("hardening missing for J2");  // materials.cpp:139-148
+    d.sigma_y_ref = (m.hardening == MIMI_HIP_HARD_POWERLAW || m.hardening == MIMI_HIP_HARD_VOCE) ? m.sigma_y : m.A;
+    if (m.hardening >= MIMI_HIP_HARD_JC_TEMP_RATE && m.reference_temperature > m.melting_temperature)
+      fail("reference temperature, %g ,can't be bigger than melting temperature, %g .",
+           m.reference_temperature, m.melting_temperature);  // material_hardening.hpp:228-238
+    if (m.hardening == MIMI_HIP_HARD_JC_CONST_TEMP) {
+      d.const_temperature_contribution =
+          1.0 - std::pow((m.initial_temperature - m.reference_temperature)
+                             / (m.melting_temperature - m.reference_temperature), m.m);
+      if (d.const_temperature_contribution <= 0.0)
+        fail("Invalid temperature contribution %g", d.const_temperature_contribution);
+    }
+  } else if (m.kind != MIMI_HIP_MAT_NEOHOOKEAN) {
+    fail("unknown material kind %d", m.kind);
+  }
+  return d;
+}
+
+template<typename F>
+static int guarded(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return 1;
+  } catch (...) {
+    set_last_error("unknown error");
+    return 1;
+  }
+}
+
+static void check_status(mimi_hip_domain_s* h) {
+  MH_HIP(hipMemcpyAsync(h->status_host, h->status_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  MH_HIP(hipStreamSynchronize(h->stream));
+  const int s = *h->status_host;
+  if (s) {
+    MH_HIP(hipMemsetAsync(h->status_dev, 0, sizeof(int), h->stream));
+    if (s & 1) fail("ScalarSolve: root not bracketed by input bounds.");          // solvers/newton.hpp:81-93
+    if (s & 2) fail("ScalarSolve: failed to converge in allotted iterations.");   // solvers/newton.hpp:120-132
+    if (s & 4) fail("CSR pattern does not contain an element's dof block");
+    if (s & 8) fail("geometry map has a non-positive Jacobian determinant");
+    fail("device status %d", s);
+  }
+}
+
+static void init_common(mimi_hip_domain_s* h, int device, const mimi_hip_material* material) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    fail("libmimi_hip: no HIP device visible -- this library has no CPU fallback");
+  if (device < 0 || device >= count) fail("device %d out of range (%d visible)", device, count);
+  h->device = device;
+  MH_HIP(hipSetDevice(device));
+  MH_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
+  h->mat = make_material_dev(*material);
+  MH_HIP(hipMalloc(reinterpret_cast<void**>(&h->status_dev), sizeof(int)));
+  MH_HIP(hipMemsetAsync(h->status_dev, 0, sizeof(int), h->stream));
+  MH_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->status_host), sizeof(int), hipHostMallocDefault));
+  *h->status_host = 0;
+}
+
+static void init_state(mimi_hip_domain_s* h) {
+  h->n_pts = (int64_t)h->n_el * h->n_q;
+  if (h->mat.m.kind != MIMI_HIP_MAT_J2) return;
+  // J2::CreateState (materials.cpp:151-166): zero plastic strain / eqps, T = initial
+  h->eqps.resize(h->n_pts);
+  h->temperature.resize(h->n_pts);
+  h->plastic_strain.resize(h->n_pts * h->dim * h->dim);
+  MH_HIP(hipMemsetAsync(h->eqps.ptr, 0, h->n_pts * sizeof(double), h->stream));
+  MH_HIP(hipMemsetAsync(h->plastic_strain.ptr, 0, h->n_pts * h->dim * h->dim * sizeof(double), h->stream));
+  std::vector<double> T(h->n_pts, h->mat.m.initial_temperature);
+  MH_HIP(hipMemcpyAsync(h->temperature.ptr, T.data(), h->n_pts * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  MH_HIP(hipStreamSynchronize(h->stream));
+}
+
+static void setup_csr(mimi_hip_domain_s* h, const int64_t* rowptr, const int32_t* col, bool need_pair_pos) {
+  if (!rowptr || !col) fail("csr_rowptr / csr_col must be given");
+  // rowptr: keep a device copy unless it already lives there
+  if (is_device_pointer(rowptr)) {
+    h->rowptr = rowptr;
+  } else {
+    h->rowptr_own.assign(rowptr, h->n_vdofs + 1, h->stream);
+    h->rowptr = h->rowptr_own.ptr;
+  }
+  int64_t nnz = 0;
+  MH_HIP(hipMemcpyAsync(&nnz, h->rowptr + h->n_vdofs, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  MH_HIP(hipStreamSynchronize(h->stream));
+  h->nnz = nnz;
+  if (!need_pair_pos) return;
+  DeviceBuffer<int32_t> col_tmp;
+  const int32_t* col_dev = col;
+  if (!is_device_pointer(col)) {
+    col_tmp.assign(col, nnz, h->stream);
+    col_dev = col_tmp.ptr;
+  }
+  const int64_t total = (int64_t)h->n_el * h->n_dof * h->n_dof;
+  h->pair_pos.resize(total);
+  const int threads = 256;
+  const int64_t blocks = (total + threads - 1) / threads;
+  hipLaunchKernelGGL(pair_pos_kernel, dim3((unsigned)blocks), dim3(threads), 0, h->stream, h->n_el, h->n_dof,
+                     h->dim, h->dofs.ptr, h->rowptr, col_dev, h->pair_pos.ptr, h->status_dev);
+  MH_HIP(hipGetLastError());
+  check_status(h);
+}
+
+static GeneralArgs general_args(mimi_hip_domain_s* h, const double* u, double* r, double* A, double gf) {
+  GeneralArgs a{};
+  a.n_el = h->n_el;
+  a.n_dof = h->n_dof;
+  a.n_q = h->n_q;
+  a.dofs = h->dofs.ptr;
+  a.dN_dX = h->dN_dX.ptr;
+  a.wdet = h->wdet.ptr;
+  a.rowptr = h->rowptr;
+  a.pair_pos = h->pair_pos.ptr;
+  a.u = u;
+  a.r = r;
+  a.A = A;
+  a.grad_factor = gf;
+  a.dt = h->dt;
+  a.mat = h->mat;
+  a.state = StateView{h->eqps.ptr, h->temperature.ptr, h->plastic_strain.ptr, h->n_pts};
+  a.status = h->status_dev;
+  return a;
+}
+
+template<int DIM>
+static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a) {
+  const size_t lds = general_lds_bytes(DIM, h->n_dof, h->n_q, grad);
+  if (lds > 160 * 1024) fail("element too large for LDS (%zu bytes)", lds);
+  auto go = [&](auto kernel) {
+    if (lds > 64 * 1024)
+      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(h->n_el), dim3(256), lds, h->stream, a);
+    MH_HIP(hipGetLastError());
+  };
+  if (grad == 0) go(domain_general_kernel<DIM, 0>);
+  else if (grad == 1) go(domain_general_kernel<DIM, 1>);
+  else go(domain_general_kernel<DIM, 2>);
+}
+
+static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double* A, double gf, bool with_grad) {
+  MH_HIP(hipSetDevice(h->device));
+  if (!u || !r || (with_grad && !A)) fail("null vector argument");
+  Mirror<double> mu = Mirror<double>::in(u, h->n_vdofs, h->stage_u, h->stream);
+  Mirror<double> mr = Mirror<double>::inout(r, h->n_vdofs, h->stage_r, h->stream);
+  Mirror<double> mA;
+  if (with_grad) mA = Mirror<double>::inout(A, h->nnz, h->stage_A, h->stream);
+  const int grad = !with_grad ? 0 : (h->tangent_mode == MIMI_HIP_TANGENT_REFERENCE_FD ? 2 : 1);
+  if (h->path == 1 && grad != 2) {
+    launch_tensor(h, grad, mu.dev, mr.dev, mA.dev, gf);
+  } else {
+    if (!h->dN_dX.ptr) fail("reference-FD tangent needs the general tables (create with MIMI_HIP_KEEP_GENERAL=1)");
+    GeneralArgs a = general_args(h, mu.dev, mr.dev, mA.dev, gf);
+    if (h->dim == 2) launch_general<2>(h, grad, a); else launch_general<3>(h, grad, a);
+  }
+  mr.finish(h->stream);
+  if (with_grad) mA.finish(h->stream);
+  const bool any_host = mu.host || mr.host || (with_grad && mA.host);
+  if (any_host) check_status(h);  // synchronous for host-resident arguments
+}
+
+}  // namespace mimi_hip
+
+using namespace mimi_hip;
+
+mimi_hip_domain_s::~mimi_hip_domain_s() {
+  if (status_dev) (void)hipFree(status_dev);
+  if (status_host) (void)hipHostFree(status_host);
+  if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+extern "C" {
+
+const char* mimi_hip_last_error(void) { return g_last_error.c_str(); }
+int mimi_hip_abi_version(void) { return MIMI_HIP_ABI_VERSION; }
+
+int mimi_hip_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return count;
+}
+
+void mimi_hip_material_set_young_poisson(mimi_hip_material* mat, double young, double poisson) {
+  // MaterialBase::SetYoungPoisson (materials.cpp:7-14)
+  mat->lambda = young * poisson / ((1 + poisson) * (1 - 2 * poisson));
+  mat->mu = young / (2.0 * (1.0 + poisson));
+  mat->G = mat->mu;
+  mat->K = young / (3.0 * (1.0 - (2.0 * poisson)));
+}
+
+int mimi_hip_domain_create(const mimi_hip_domain_tables* t, const mimi_hip_material* material, int device,
+                           mimi_hip_domain_t* out) {
+  return guarded([&] {
+    if (!t || !material || !out) fail("null argument");
+    if (t->dim != 2 && t->dim != 3) fail("Unsupported Dim: %d", t->dim);
+    if (t->n_dof < 1 || t->n_dof > 64) fail("n_dof %d out of range [1,64]", t->n_dof);
+    if (t->n_quad < 1 || t->n_quad > 125) fail("n_quad %d out of range [1,125]", t->n_quad);
+    if (t->n_elements < 1) fail("no elements");
+    auto h = std::make_unique<mimi_hip_domain_s>();
+    init_common(h.get(), device, material);
+    h->dim = t->dim;
+    h->n_el = t->n_elements;
+    h->n_dof = t->n_dof;
+    h->n_q = t->n_quad;
+    h->n_nodes = t->n_nodes;
+    h->n_vdofs = t->n_nodes * t->dim;
+    h->path = 0;
+    const size_t n_tdof = (size_t)t->n_dof * t->dim;
+    h->dofs.assign(t->dofs, (size_t)t->n_elements * t->n_dof, h->stream);
+    h->dN_dX.assign(t->dN_dX, (size_t)t->n_elements * t->n_quad * n_tdof, h->stream);
+    h->wdet.assign(t->weight_det, (size_t)t->n_elements * t->n_quad, h->stream);
+    setup_csr(h.get(), t->csr_rowptr, t->csr_col, true);
+    init_state(h.get());
+    *out = h.release();
+  });
+}
+
+int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_hip_material* material, int device,
+                                   mimi_hip_domain_t* out) {
+  return guarded([&] {
+    if (!p || !material || !out) fail("null argument");
+    if (p->dim != 2 && p->dim != 3) fail("Unsupported Dim: %d", p->dim);
+    auto h = std::make_unique<mimi_hip_domain_s>();
+    init_common(h.get(), device, material);
+    const int dim = p->dim;
+    h->dim = dim;
+    Tables1D t1[3];
+    int pmax = 0;
+    for (int d = 0; d < dim; ++d) pmax = std::max(pmax, p->degree[d]);
+    if (pmax < 1 || pmax > 3) fail("degree %d unsupported (1..3)", pmax);
+    // precomputed.cpp:284-290: order = 2*GetOrder()+3 when negative; order/2+1 points / direction
+    const int order = p->quadrature_order < 0 ? 2 * pmax + 3 : p->quadrature_order;
+    const int nq = order / 2 + 1;
+    int64_t n_nodes = 1;
+    h->n_dof = 1;
+    h->n_q = 1;
+    for (int d = 0; d < dim; ++d) {
+      if (p->degree[d] < 1 || p->degree[d] > 3) fail("degree %d unsupported (1..3)", p->degree[d]);
+      t1[d] = make_tables_1d(p->knots[d], p->n_knots[d], p->degree[d], nq);
+      h->degree[d] = p->degree[d];
+      h->nq1[d] = nq;
+      h->n_ctrl[d] = t1[d].n_ctrl;
+      h->el_total[d] = t1[d].n_spans;
+      n_nodes *= t1[d].n_ctrl;
+      h->n_dof *= p->degree[d] + 1;
+      h->n_q *= nq;
+    }
+    if (h->n_q > 125) fail("n_quad %d out of range", h->n_q);
+    bool whole = true;
+    for (int d = 0; d < 3; ++d) whole = whole && p->element_begin[d] == 0 && p->element_end[d] == 0;
+    h->n_el = 1;
+    for (int d = 0; d < dim; ++d) {
+      h->el_begin[d] = whole ? 0 : p->element_begin[d];
+      h->el_end[d] = whole ? h->el_total[d] : p->element_end[d];
+      if (h->el_begin[d] < 0 || h->el_end[d] > h->el_total[d] || h->el_begin[d] >= h->el_end[d])
+        fail("element box [%d,%d) invalid in direction %d (%d spans)", h->el_begin[d], h->el_end[d], d, h->el_total[d]);
+      h->n_el *= h->el_end[d] - h->el_begin[d];
+    }
+    h->n_nodes = n_nodes;
+    h->n_vdofs = n_nodes * dim;
+
+    // 1-D tables -> one device buffer:  per direction B, D, W ; first[] in a second buffer
+    std::vector<double> tab;
+    std::vector<int32_t> first;
+    size_t offW[3] = {0, 0, 0};
+    for (int d = 0; d < dim; ++d) {
+      h->tab_off_B[d] = tab.size();
+      tab.insert(tab.end(), t1[d].B.begin(), t1[d].B.end());
+      h->tab_off_D[d] = tab.size();
+      tab.insert(tab.end(), t1[d].D.begin(), t1[d].D.end());
+      offW[d] = tab.size();
+      tab.insert(tab.end(), t1[d].w.begin(), t1[d].w.end());
+      h->first_off[d] = first.size();
+      first.insert(first.end(), t1[d].first.begin(), t1[d].first.end());
+    }
+    h->tab1d.assign(tab.data(), tab.size(), h->stream);
+    h->first1d.assign(first.data(), first.size(), h->stream);
+    DeviceBuffer<double> ctrl;
+    ctrl.assign(p->control_points, (size_t)n_nodes * dim, h->stream);
+    if (p->node_ids) h->node_ids.assign(p->node_ids, (size_t)n_nodes, h->stream);
+
+    PatchDev P{};
+    P.dim = dim;
+    for (int d = 0; d < 3; ++d) {
+      P.p[d] = d < dim ? h->degree[d] : 0;
+      P.nq[d] = d < dim ? nq : 1;
+      P.n_ctrl[d] = d < dim ? h->n_ctrl[d] : 1;
+      P.box_begin[d] = d < dim ? h->el_begin[d] : 0;
+      P.box_n[d] = d < dim ? h->el_end[d] - h->el_begin[d] : 1;
+      P.B[d] = d < dim ? h->tab1d.ptr + h->tab_off_B[d] : nullptr;
+      P.D[d] = d < dim ? h->tab1d.ptr + h->tab_off_D[d] : nullptr;
+      P.W[d] = d < dim ? h->tab1d.ptr + offW[d] : nullptr;
+      P.first[d] = d < dim ? h->first1d.ptr + h->first_off[d] : nullptr;
+    }
+    P.ctrl = ctrl.ptr;
+    P.node_ids = p->node_ids ? h->node_ids.ptr : nullptr;
+    P.n_dof = h->n_dof;
+    P.n_q = h->n_q;
+    P.n_el = h->n_el;
+
+    const int64_t npts = (int64_t)h->n_el * h->n_q;
+    h->geo.resize((size_t)npts * (dim * dim + 1));
+    {
+      const int threads = 256;
+      const int64_t blocks = (npts + threads - 1) / threads;
+      if (dim == 2)
+        hipLaunchKernelGGL(geometry_kernel<2>, dim3((unsigned)blocks), dim3(threads), 0, h->stream, P, h->geo.ptr, h->status_dev);
+      else
+        hipLaunchKernelGGL(geometry_kernel<3>, dim3((unsigned)blocks), dim3(threads), 0, h->stream, P, h->geo.ptr, h->status_dev);
+      MH_HIP(hipGetLastError());
+      check_status(h.get());
+    }
+    // element connectivity (always) + reference-layout tables (general path / FD mode only)
+    const char* keep_env = getenv("MIMI_HIP_KEEP_GENERAL");
+    const char* path_env = getenv("MIMI_HIP_FORCE_GENERAL");
+    const bool force_general = path_env && path_env[0] == '1';
+    const bool tensor_ok = tensor_supported(dim, h->degree, nq);
+    const bool keep_general = force_general || !tensor_ok || (keep_env && keep_env[0] == '1');
+    h->path = (tensor_ok && !force_general) ? 1 : 0;
+    h->dofs.resize((size_t)h->n_el * h->n_dof);
+    {
+      const size_t n_tdof = (size_t)h->n_dof * dim;
+      DeviceBuffer<double> scratch_g, scratch_w;
+      double* gptr = nullptr;
+      double* wptr = nullptr;
+      if (keep_general) {
+        h->dN_dX.resize((size_t)npts * n_tdof);
+        h->wdet.resize((size_t)npts);
+        gptr = h->dN_dX.ptr;
+        wptr = h->wdet.ptr;
+      }
+      // connectivity-only launch when the tables are not kept: reuse the kernel per element chunk
+      const int threads = 256;
+      if (keep_general) {
+        const int64_t total = npts * h->n_dof;
+        const int64_t blocks = (total + threads - 1) / threads;
+        if (dim == 2)
+          hipLaunchKernelGGL(expand_tables_kernel<2>, dim3((unsigned)blocks), dim3(threads), 0, h->stream, P, h->geo.ptr, h->dofs.ptr, gptr, wptr);
+        else
+          hipLaunchKernelGGL(expand_tables_kernel<3>, dim3((unsigned)blocks), dim3(threads), 0, h->stream, P, h->geo.ptr, h->dofs.ptr, gptr, wptr);
+      } else {
+        const int64_t total = (int64_t)h->n_el * h->n_dof;
+        const int64_t blocks = (total + threads - 1) / threads;
+        hipLaunchKernelGGL(connectivity_kernel, dim3((unsigned)blocks), dim3(threads), 0, h->stream, P, h->dofs.ptr);
+      }
+      MH_HIP(hipGetLastError());
+      MH_HIP(hipStreamSynchronize(h->stream));
+    }
+    setup_csr(h.get(), p->csr_rowptr, p->csr_col, true);
+    init_state(h.get());
+    MH_HIP(hipStreamSynchronize(h->stream));
+    *out = h.release();
+  });
+}
+
+int mimi_hip_domain_destroy(mimi_hip_domain_t h) {
+  return guarded([&] {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+  });
+}
+
+int mimi_hip_domain_set_dt(mimi_hip_domain_t h, double dt, double first_effective_dt, double second_effective_dt) {
+  return guarded([&] {
+    if (!h) fail("null handle");
+    h->dt = dt;
+    h->first_effective_dt = first_effective_dt;
+    h->second_effective_dt = second_effective_dt;
+  });
+}
+
+int mimi_hip_domain_set_tangent_mode(mimi_hip_domain_t h, int mode) {
+  return guarded([&] {
+    if (!h) fail("null handle");
+    if (mode != MIMI_HIP_TANGENT_ANALYTIC && mode != MIMI_HIP_TANGENT_REFERENCE_FD) fail("bad tangent mode %d", mode);
+    h->tangent_mode = mode;
+  });
+}
+
+int mimi_hip_domain_set_stream(mimi_hip_domain_t h, void* stream) {
+  return guarded([&] {
+    if (!h) fail("null handle");
+    h->stream = stream ? reinterpret_cast<hipStream_t>(stream) : h->own_stream;
+  });
+}
+
+int mimi_hip_domain_synchronize(mimi_hip_domain_t h) {
+  return guarded([&] {
+    if (!h) fail("null handle");
+    MH_HIP(hipSetDevice(h->device));
+    check_status(h);
+  });
+}
+
+int mimi_hip_domain_add_residual(mimi_hip_domain_t h, const double* u, double* r) {
+  return guarded([&] {
+    if (!h) fail("null handle");
+    run_domain(h, u, r, nullptr, 0.0, false);
+  });
+}
+
+int mimi_hip_domain_add_residual_and_grad(mimi_hip_domain_t h, const double* u, double grad_factor, double* r,
+                                          double* A_values) {
+  return guarded([&] {
+    if (!h) fail("null handle");
+    run_domain(h, u, r, A_values, grad_factor, true);
+  });
+}
+
+int mimi_hip_domain_post_time_advance(mimi_hip_domain_t h, const double* u) {
+  return guarded([&] {
+    if (!h) fail("null handle");
+    if (h->mat.m.kind != MIMI_HIP_MAT_J2) return;  // has_states_ == false (nonlinear_solid.cpp:182-183)
+    MH_HIP(hipSetDevice(h->device));
+    Mirror<double> mu = Mirror<double>::in(u, h->n_vdofs, h->stage_u, h->stream);
+    if (h->path == 1) {
+      launch_tensor_post(h, mu.dev);
+    } else {
+      GeneralArgs a = general_args(h, mu.dev, nullptr, nullptr, 0.0);
+      const size_t lds = (size_t)h->n_dof * h->dim * sizeof(double);
+      if (h->dim == 2)
+        hipLaunchKernelGGL(post_time_advance_general_kernel<2>, dim3(h->n_el), dim3(256), lds, h->stream, a);
+      else
+        hipLaunchKernelGGL(post_time_advance_general_kernel<3>, dim3(h->n_el), dim3(256), lds, h->stream, a);
+      MH_HIP(hipGetLastError());
+    }
+    if (mu.host) check_status(h);
+  });
+}
+
+int mimi_hip_domain_get_state(mimi_hip_domain_t h, int what, double* out, int64_t capacity) {
+  return guarded([&] {
+    if (!h || !out) fail("null argument");
+    MH_HIP(hipSetDevice(h->device));
+    if (h->mat.m.kind != MIMI_HIP_MAT_J2) fail("material has no state");
+    const int dd = h->dim * h->dim;
+    const int64_t need = what == 2 ? h->n_pts * dd : h->n_pts;
+    if (capacity < need) fail("state buffer too small (%lld < %lld)", (long long)capacity, (long long)need);
+    MH_HIP(hipStreamSynchronize(h->stream));
+    if (what == 0) {
+      MH_HIP(hipMemcpy(out, h->eqps.ptr, need * sizeof(double), hipMemcpyDeviceToHost));
+    } else if (what == 1) {
+      MH_HIP(hipMemcpy(out, h->temperature.ptr, need * sizeof(double), hipMemcpyDeviceToHost));
+    } else if (what == 2) {
+      std::vector<double> soa(need);
+      MH_HIP(hipMemcpy(soa.data(), h->plastic_strain.ptr, need * sizeof(double), hipMemcpyDeviceToHost));
+      for (int64_t pt = 0; pt < h->n_pts; ++pt)
+        for (int c = 0; c < dd; ++c) out[pt * dd + c] = soa[(int64_t)c * h->n_pts + pt];
+    } else {
+      fail("unknown state id %d", what);
+    }
+  });
+}
+
+int mimi_hip_domain_reset_state(mimi_hip_domain_t h) {
+  return guarded([&] {
+    if (!h) fail("null handle");
+    MH_HIP(hipSetDevice(h->device));
+    init_state(h);
+  });
+}
+
+int64_t mimi_hip_domain_info(mimi_hip_domain_t h, int what) {
+  if (!h) return -1;
+  switch (what) {
+  case 0: return h->n_el;
+  case 1: return h->n_q;
+  case 2: return h->n_dof;
+  case 3: return h->nnz;
+  case 4: return h->n_vdofs;
+  case 5: return h->path;
+  default: return -1;
+  }
+}
+
+int mimi_hip_bspline_sparsity(int32_t dim, const int32_t n_nodes_dir[3], const int32_t degree[3], int device,
+                              int64_t* rowptr, int32_t* col, int64_t* nnz_out) {
+  return guarded([&] {
+    if (dim != 2 && dim != 3) fail("Unsupported Dim: %d", dim);
+    if (!rowptr || !nnz_out) fail("null argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) fail("libmimi_hip: no HIP device visible");
+    MH_HIP(hipSetDevice(device));
+    SparsityDev S{};
+    S.dim = dim;
+    int64_t n_nodes = 1;
+    DeviceBuffer<int64_t> prefix[3];
+    for (int d = 0; d < 3; ++d) {
+      S.n[d] = d < dim ? n_nodes_dir[d] : 1;
+      S.p[d] = d < dim ? degree[d] : 0;
+      n_nodes *= S.n[d];
+      std::vector<int64_t> pre(S.n[d] + 1, 0);
+      for (int A = 0; A < S.n[d]; ++A) {
+        const int lo = std::max(A - S.p[d], 0), hi = std::min(A + S.p[d], S.n[d] - 1);
+        pre[A + 1] = pre[A] + (hi - lo + 1);
+      }
+      prefix[d].assign(pre.data(), pre.size(), nullptr);
+      S.prefix[d] = prefix[d].ptr;
+    }
+    const int64_t n_rows = n_nodes * dim;
+    DeviceBuffer<int64_t> rp_tmp;
+    int64_t* rp_dev = rowptr;
+    const bool rp_host = !is_device_pointer(rowptr);
+    if (rp_host) {
+      rp_tmp.resize(n_rows + 1);
+      rp_dev = rp_tmp.ptr;
+    }
+    {
+      const int threads = 256;
+      const int64_t blocks = (n_nodes + 1 + threads - 1) / threads;
+      hipLaunchKernelGGL(structured_rowptr_kernel, dim3((unsigned)blocks), dim3(threads), 0, nullptr, S, n_nodes, rp_dev);
+      MH_HIP(hipGetLastError());
+    }
+    int64_t nnz = 0;
+    MH_HIP(hipMemcpy(&nnz, rp_dev + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost));
+    *nnz_out = nnz;
+    if (rp_host) MH_HIP(hipMemcpy(rowptr, rp_dev, (n_rows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (col) {
+      DeviceBuffer<int32_t> col_tmp;
+      int32_t* col_dev = col;
+      const bool col_host = !is_device_pointer(col);
+      if (col_host) {
+        col_tmp.resize(nnz);
+        col_dev = col_tmp.ptr;
+      }
+      const int threads = 256;
+      const int64_t blocks = (n_rows + 3) / 4;
+      hipLaunchKernelGGL(structured_col_kernel, dim3((unsigned)blocks), dim3(threads), 0, nullptr, S, n_rows, rp_dev,
+                         col_dev, 0, (int*)nullptr);
+      MH_HIP(hipGetLastError());
+      MH_HIP(hipDeviceSynchronize());
+      if (col_host) MH_HIP(hipMemcpy(col, col_dev, nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    MH_HIP(hipDeviceSynchronize());
+  });
+}
+
+}  // extern "C"

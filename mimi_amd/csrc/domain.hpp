@@ -1,0 +1,48 @@
+// Host-side state of one domain integrator handle (= one integrators::NonlinearSolid,
+// integrators/nonlinear_solid.hpp:15-50, bound to one HIP device and stream).
+#pragma once
+
+#include "bspline_host.hpp"
+#include "common.hpp"
+
+struct mimi_hip_domain_s {
+  int device = 0;
+  int dim = 0, n_el = 0, n_dof = 0, n_q = 0;
+  int64_t n_nodes = 0, n_vdofs = 0, nnz = 0, n_pts = 0;
+  int path = 0;  // 0 general tables, 1 tensor-product (sum factorisation)
+  hipStream_t own_stream = nullptr, stream = nullptr;
+
+  mimi_hip::MaterialDev mat{};
+  double dt = 0.0, first_effective_dt = 0.0, second_effective_dt = 0.0;
+  int tangent_mode = MIMI_HIP_TANGENT_ANALYTIC;
+
+  // general path tables
+  mimi_hip::DeviceBuffer<int32_t> dofs;      // [n_el][n_dof]
+  mimi_hip::DeviceBuffer<double> dN_dX;      // [n_el][n_q][dim][n_dof]
+  mimi_hip::DeviceBuffer<double> wdet;       // [n_el][n_q]
+  mimi_hip::DeviceBuffer<int32_t> pair_pos;  // [n_el][n_dof][n_dof]
+  mimi_hip::DeviceBuffer<int64_t> rowptr_own;
+  const int64_t* rowptr = nullptr;           // device
+
+  // tensor path tables
+  int degree[3] = {0, 0, 0}, nq1[3] = {1, 1, 1}, n_ctrl[3] = {1, 1, 1};
+  int el_begin[3] = {0, 0, 0}, el_end[3] = {1, 1, 1}, el_total[3] = {1, 1, 1};
+  mimi_hip::DeviceBuffer<double> tab1d;      // per direction B then D: [n_spans][p+1][nq]
+  mimi_hip::DeviceBuffer<int32_t> first1d;   // per direction [n_spans]
+  size_t tab_off_B[3] = {0, 0, 0}, tab_off_D[3] = {0, 0, 0}, first_off[3] = {0, 0, 0};
+  mimi_hip::DeviceBuffer<double> geo;        // [n_el][dim*dim+1][n_q]: dxi/dX (d,J) then w*det
+  mimi_hip::DeviceBuffer<int64_t> node_ids;  // lexicographic -> global, empty = identity
+  bool structured_csr = false;               // CSR positions computable arithmetically
+
+  // J2 state, SoA over points
+  mimi_hip::DeviceBuffer<double> eqps, temperature, plastic_strain;
+
+  // status word raised by kernels (ScalarSolve failures, bad pattern)
+  int* status_dev = nullptr;
+  int* status_host = nullptr;  // pinned
+
+  // staging for host-resident u / r / A
+  mimi_hip::DeviceBuffer<double> stage_u, stage_r, stage_A;
+
+  ~mimi_hip_domain_s();
+};

@@ -1,0 +1,264 @@
+// General-table domain kernels: one workgroup per element, any node numbering, any
+// (rational or not) basis -- the tables are the caller's QuadData flattened
+// (utils/precomputed.hpp:58-71).  Replaces
+//   NonlinearSolid::ElementResidual / ElementResidualAndGrad / ThreadLocalResidual[AndGrad]
+//   (integrators/nonlinear_solid.hpp:65-87, nonlinear_solid.cpp:48-149)
+//   and the AddThreadLocal* reductions (integrators/nonlinear_base.hpp:90-151):
+// instead of per-thread global copies + a reduction pass, element contributions go
+// straight into r / CSR values with fp64 hardware atomics.
+//
+// Work split inside a workgroup (256 threads = 4 waves):
+//   phase 0  gather u_e = u[dofs] into LDS (integrator_utils.cpp:44-51)
+//   phase 1  one lane per quadrature point: F = u_e^T dN_dX + I, P(F) [, dP/dF]
+//            scaled by w*det -> LDS
+//   phase 2  one lane per element dof (a,i): R_e(a,i) = sum_q dN_dX(a,:) . P(i,:)  -> r
+//   phase 3  one lane per node pair (a,b): the dim x dim block
+//            K(ai,bj) = sum_q dN_aJ A_iJjL dN_bL                                   -> A
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include "materials.hpp"
+
+namespace mimi_hip {
+
+struct GeneralArgs {
+  int n_el, n_dof, n_q;
+  const int32_t* dofs;      // [n_el][n_dof]
+  const double* dN_dX;      // [n_el][n_q][DIM][n_dof]
+  const double* wdet;       // [n_el][n_q]
+  const int64_t* rowptr;    // [n_vdofs+1]
+  const int32_t* pair_pos;  // [n_el][n_dof][n_dof]: offset of column (B*dim) inside row (A*dim)
+  const double* u;
+  double* r;
+  double* A;
+  double grad_factor;
+  double dt;
+  MaterialDev mat;
+  StateView state;
+  int* status;
+};
+
+MH_DEV void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// setup: pair_pos[e][a][b] by binary search of column dofs[b]*dim in row dofs[a]*dim
+__global__ void pair_pos_kernel(int n_el, int n_dof, int dim, const int32_t* __restrict__ dofs,
+                                const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                int32_t* __restrict__ pair_pos, int* __restrict__ status) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)n_el * n_dof * n_dof;
+  if (idx >= total) return;
+  const int b = idx % n_dof;
+  const int a = (idx / n_dof) % n_dof;
+  const int64_t e = idx / ((int64_t)n_dof * n_dof);
+  const int64_t row = (int64_t)dofs[e * n_dof + a] * dim;
+  const int32_t target = dofs[e * n_dof + b] * dim;
+  int64_t lo = rowptr[row], hi = rowptr[row + 1];
+  const int64_t base = lo;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (col[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= rowptr[row + 1] || col[lo] != target) {
+    atomicOr(status, 4);  // pattern does not contain the element block
+    pair_pos[idx] = 0;
+    return;
+  }
+  pair_pos[idx] = (int32_t)(lo - base);
+}
+
+template<int DIM>
+MH_DEV void compute_F_general(int n_dof, const double* __restrict__ g /* [DIM][n_dof] */,
+                              const double* u_e /* LDS [DIM][n_dof] */, double* F) {
+#pragma unroll
+  for (int k = 0; k < DIM * DIM; ++k) F[k] = 0.0;
+  for (int a = 0; a < n_dof; ++a) {
+    double ga[DIM], ua[DIM];
+#pragma unroll
+    for (int J = 0; J < DIM; ++J) ga[J] = g[J * n_dof + a];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) ua[i] = u_e[i * n_dof + a];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i)
+#pragma unroll
+      for (int J = 0; J < DIM; ++J) MH_M(F, i, J) += ua[i] * ga[J];
+  }
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) MH_M(F, i, i) += 1.0;
+}
+
+// GRAD: 0 residual only, 1 analytic tangent, 2 reference forward difference
+template<int DIM, int GRAD>
+__global__ __launch_bounds__(256) void domain_general_kernel(GeneralArgs p) {
+  constexpr int DD = DIM * DIM;
+  constexpr int D4 = DD * DD;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int e = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int n_dof = p.n_dof, n_q = p.n_q, n_tdof = n_dof * DIM;
+
+  double* u_e = reinterpret_cast<double*>(smem_raw);  // [DIM][n_dof]
+  double* Pw = u_e + n_tdof;                          // [n_q][DD]   w*det*P
+  double* Aw = Pw + n_q * DD;                         // [n_q][D4]   w*det*dP/dF   (GRAD==1)
+  double* R_e = Aw + (GRAD == 1 ? n_q * D4 : 0);      // [n_tdof]                  (GRAD==2)
+  int32_t* node = reinterpret_cast<int32_t*>(R_e + (GRAD == 2 ? n_tdof : 0));  // [n_dof]
+
+  const double* gE = p.dN_dX + (int64_t)e * n_q * n_tdof;
+  const double* wE = p.wdet + (int64_t)e * n_q;
+
+  for (int t = tid; t < n_dof; t += blockDim.x) node[t] = p.dofs[(int64_t)e * n_dof + t];
+  __syncthreads();
+  for (int t = tid; t < n_tdof; t += blockDim.x) {
+    const int a = t % n_dof, i = t / n_dof;
+    u_e[t] = p.u[(int64_t)node[a] * DIM + i];
+  }
+  __syncthreads();
+
+  // phase 1: constitutive update per quadrature point
+  int status = 0;
+  for (int q = tid; q < n_q; q += blockDim.x) {
+    double F[DD];
+    compute_F_general<DIM>(n_dof, gE + (int64_t)q * n_tdof, u_e, F);
+    PointResult<DIM> w;
+    status |= evaluate_pk1<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F, w);
+    const double wd = wE[q];
+#pragma unroll
+    for (int k = 0; k < DD; ++k) Pw[q * DD + k] = wd * w.P[k];
+    if constexpr (GRAD == 1) {
+      double A[D4];
+      tangent_of<DIM>(p.mat.m, w, A);
+#pragma unroll
+      for (int k = 0; k < D4; ++k) Aw[q * D4 + k] = wd * A[k];
+    }
+  }
+  __syncthreads();
+
+  // phase 2: residual (AddMult_a_ABt, nonlinear_solid.hpp:79-82)
+  for (int t = tid; t < n_tdof; t += blockDim.x) {
+    const int a = t % n_dof, i = t / n_dof;
+    double s = 0.0;
+    for (int q = 0; q < n_q; ++q) {
+      const double* g = gE + (int64_t)q * n_tdof;
+#pragma unroll
+      for (int J = 0; J < DIM; ++J) s += g[J * n_dof + a] * Pw[q * DD + i + J * DIM];
+    }
+    if constexpr (GRAD == 2) R_e[t] = s;
+    atomic_add_f64(&p.r[(int64_t)node[a] * DIM + i], s);
+  }
+
+  if constexpr (GRAD == 1) {
+    // phase 3: node-pair blocks
+    const int n_pairs = n_dof * n_dof;
+    const int32_t* pp = p.pair_pos + (int64_t)e * n_pairs;
+    for (int pr = tid; pr < n_pairs; pr += blockDim.x) {
+      const int b = pr % n_dof, a = pr / n_dof;
+      double acc[DD];  // acc[i*DIM + j]
+#pragma unroll
+      for (int k = 0; k < DD; ++k) acc[k] = 0.0;
+      for (int q = 0; q < n_q; ++q) {
+        const double* g = gE + (int64_t)q * n_tdof;
+        double ga[DIM], gb[DIM];
+#pragma unroll
+        for (int J = 0; J < DIM; ++J) {
+          ga[J] = g[J * n_dof + a];
+          gb[J] = g[J * n_dof + b];
+        }
+        const double* Aq = Aw + q * D4;
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+#pragma unroll
+          for (int j = 0; j < DIM; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int J = 0; J < DIM; ++J)
+#pragma unroll
+              for (int L = 0; L < DIM; ++L) s += ga[J] * Aq[((i * DIM + J) * DIM + j) * DIM + L] * gb[L];
+            acc[i * DIM + j] += s;
+          }
+      }
+      const int64_t rowA = (int64_t)node[a] * DIM;
+      const int32_t off = pp[pr];
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) {
+        double* dst = p.A + p.rowptr[rowA + i] + off;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) atomic_add_f64(dst + j, p.grad_factor * acc[i * DIM + j]);
+      }
+    }
+  }
+
+  if constexpr (GRAD == 2) {
+    // reference rule (nonlinear_solid.cpp:48-76): column c = (R_e(u_e + h e_c) - R_e(u_e)) / h,
+    // h = |u_c|*1e-8 or 1e-10; one column at a time, all quadrature points re-evaluated.
+    const int n_pairs = n_dof * n_dof;
+    const int32_t* pp = p.pair_pos + (int64_t)e * n_pairs;
+    for (int c = 0; c < n_tdof; ++c) {
+      __syncthreads();
+      const double orig = u_e[c];
+      const double step = (orig != 0.0) ? fabs(orig) * 1.0e-8 : 1.0e-10;
+      const double step_inv = 1. / step;
+      __syncthreads();
+      if (tid == 0) u_e[c] = orig + step;
+      __syncthreads();
+      for (int q = tid; q < n_q; q += blockDim.x) {
+        double F[DD];
+        compute_F_general<DIM>(n_dof, gE + (int64_t)q * n_tdof, u_e, F);
+        PointResult<DIM> w;
+        status |= evaluate_pk1<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F, w);
+        const double wd = wE[q];
+#pragma unroll
+        for (int k = 0; k < DD; ++k) Pw[q * DD + k] = wd * w.P[k];
+      }
+      __syncthreads();
+      if (tid == 0) u_e[c] = orig;
+      const int b = c % n_dof, j = c / n_dof;
+      for (int t = tid; t < n_tdof; t += blockDim.x) {
+        const int a = t % n_dof, i = t / n_dof;
+        double s = 0.0;
+        for (int q = 0; q < n_q; ++q) {
+          const double* g = gE + (int64_t)q * n_tdof;
+#pragma unroll
+          for (int J = 0; J < DIM; ++J) s += g[J * n_dof + a] * Pw[q * DD + i + J * DIM];
+        }
+        const double k_entry = (s - R_e[t]) * step_inv;
+        const int64_t rowA = (int64_t)node[a] * DIM + i;
+        atomic_add_f64(p.A + p.rowptr[rowA] + pp[a * n_dof + b] + j, p.grad_factor * k_entry);
+      }
+    }
+  }
+
+  if (status) atomicOr(p.status, status);
+}
+
+// DomainPostTimeAdvance (nonlinear_solid.cpp:179-199): one lane per quadrature point
+template<int DIM>
+__global__ __launch_bounds__(256) void post_time_advance_general_kernel(GeneralArgs p) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const int e = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int n_dof = p.n_dof, n_q = p.n_q, n_tdof = n_dof * DIM;
+  double* u_e = reinterpret_cast<double*>(smem_raw);
+  for (int t = tid; t < n_tdof; t += blockDim.x) {
+    const int a = t % n_dof, i = t / n_dof;
+    u_e[t] = p.u[(int64_t)p.dofs[(int64_t)e * n_dof + a] * DIM + i];
+  }
+  __syncthreads();
+  int status = 0;
+  for (int q = tid; q < n_q; q += blockDim.x) {
+    double F[DIM * DIM];
+    compute_F_general<DIM>(n_dof, p.dN_dX + ((int64_t)e * n_q + q) * n_tdof, u_e, F);
+    status |= accumulate_state<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F);
+  }
+  if (status) atomicOr(p.status, status);
+}
+
+inline size_t general_lds_bytes(int dim, int n_dof, int n_q, int grad) {
+  const int dd = dim * dim, n_tdof = n_dof * dim;
+  size_t doubles = n_tdof + (size_t)n_q * dd;
+  if (grad == 1) doubles += (size_t)n_q * dd * dd;
+  if (grad == 2) doubles += n_tdof;
+  return doubles * sizeof(double) + (size_t)n_dof * sizeof(int32_t);
+}
+
+}  // namespace mimi_hip

@@ -1,0 +1,391 @@
+// Device-side constitutive updates: PK1 stress P(F) and consistent tangent dP/dF at one
+// quadrature point, fp64, everything in registers.
+//
+// Follows the arithmetic of the reference (paths under /root/reference/src/mimi/):
+//   CompressibleOgdenNeoHookean::EvaluateCauchy        materials/materials.cpp:96-118
+//   MaterialBase::EvaluatePK1 (P = J sigma F^-T)       materials/materials.cpp:60-71
+//   J2::PlasticStress<accumulate>                      materials/materials.hpp:311-391
+//   ElasticStrain / Dev / Norm                         materials/material_utils.hpp:22-84,117-127
+//   hardening laws (value + d/d eqps)                  materials/material_hardening.hpp:79-346
+//   ScalarSolve (safeguarded Newton / bisection)       solvers/newton.hpp:53-169
+// The reference has no analytic tangent (it differentiates the element residual
+// numerically, integrators/nonlinear_solid.cpp:48-76); the closed forms below are new.
+//
+// Storage: all DIM x DIM tensors column-major, T(i,J) = T[i + J*DIM] (mfem::DenseMatrix).
+// Tangent: A[((i*DIM + J)*DIM + j)*DIM + L] = dP_iJ / dF_jL.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace mimi_hip {
+
+#define MH_DEV __device__ __forceinline__
+
+template<int DIM>
+MH_DEV double det_of(const double* F) {
+  if constexpr (DIM == 2) {
+    return F[0] * F[3] - F[1] * F[2];
+  } else {
+    return F[0] * (F[4] * F[8] - F[5] * F[7]) - F[3] * (F[1] * F[8] - F[2] * F[7])
+           + F[6] * (F[1] * F[5] - F[2] * F[4]);
+  }
+}
+
+template<int DIM>
+MH_DEV void inverse_of(const double* F, double det, double* Fi) {
+  const double t = 1.0 / det;
+  if constexpr (DIM == 2) {
+    Fi[0] = F[3] * t;
+    Fi[1] = -F[1] * t;
+    Fi[2] = -F[2] * t;
+    Fi[3] = F[0] * t;
+  } else {
+    Fi[0] = (F[4] * F[8] - F[5] * F[7]) * t;
+    Fi[1] = (F[2] * F[7] - F[1] * F[8]) * t;
+    Fi[2] = (F[1] * F[5] - F[2] * F[4]) * t;
+    Fi[3] = (F[5] * F[6] - F[3] * F[8]) * t;
+    Fi[4] = (F[0] * F[8] - F[2] * F[6]) * t;
+    Fi[5] = (F[2] * F[3] - F[0] * F[5]) * t;
+    Fi[6] = (F[3] * F[7] - F[4] * F[6]) * t;
+    Fi[7] = (F[1] * F[6] - F[0] * F[7]) * t;
+    Fi[8] = (F[0] * F[4] - F[1] * F[3]) * t;
+  }
+}
+
+// ---- hardening -------------------------------------------------------------------
+struct Dual {
+  double v, d;
+};
+
+MH_DEV double thermo_contribution(const MaterialDev& md, double T) {
+  const mimi_hip_material& m = md.m;
+  if (m.hardening == MIMI_HIP_HARD_JC_TEMP_RATE) {
+    double c = 1.0;
+    if (T < m.reference_temperature) {
+    } else if (T > m.melting_temperature) {
+      c = 0.0;
+    } else {
+      c -= pow((T - m.reference_temperature) / (m.melting_temperature - m.reference_temperature), m.m);
+    }
+    return c;
+  }
+  if (m.hardening == MIMI_HIP_HARD_JC_CONST_TEMP) return md.const_temperature_contribution;
+  return 1.0;
+}
+
+MH_DEV double rate_contribution(const mimi_hip_material& m, double rate) {
+  if (m.hardening >= MIMI_HIP_HARD_JC_RATE) {
+    double v = 1.0;
+    if (rate > m.eps0_dot) v += m.C * log(rate / m.eps0_dot);
+    return v;
+  }
+  return 1.0;
+}
+
+MH_DEV double rate_contribution_derivative(const mimi_hip_material& m, double rate) {
+  if (m.hardening >= MIMI_HIP_HARD_JC_RATE && rate > m.eps0_dot) return m.C / rate;
+  return 0.0;
+}
+
+// utils/ad.inl:263-279: pow(x, n) = x * x^(n-1), derivative n * x^(n-1) * x'
+MH_DEV Dual dual_pow(Dual b, double power) {
+  const double tmp = pow(b.v, power - 1.0);
+  return Dual{b.v * tmp, b.d * (power * tmp)};
+}
+
+MH_DEV Dual hardening_evaluate(const mimi_hip_material& m, Dual eqps) {
+  switch (m.hardening) {
+  case MIMI_HIP_HARD_POWERLAW: {
+    Dual p = dual_pow(Dual{1.0 + eqps.v / m.eps0, eqps.d / m.eps0}, 1.0 / m.n);
+    return Dual{m.sigma_y * p.v, m.sigma_y * p.d};
+  }
+  case MIMI_HIP_HARD_VOCE: {
+    const double e = exp(-eqps.v / m.strain_constant);
+    return Dual{m.sigma_sat - (m.sigma_sat - m.sigma_y) * e,
+                (m.sigma_sat - m.sigma_y) * e * (eqps.d / m.strain_constant)};
+  }
+  default: {
+    if (fabs(eqps.v) < 1.e-13) return Dual{m.A, 0.0};
+    Dual p = dual_pow(eqps, m.n);
+    return Dual{m.A + m.B * p.v, m.B * p.d};
+  }
+  }
+}
+
+struct ReturnMapCtx {
+  double eqps_old, q, thermo, dt;
+};
+
+// materials.hpp:343-349
+MH_DEV Dual rm_residual(const mimi_hip_material& m, const ReturnMapCtx& c, Dual delta) {
+  const Dual H = hardening_evaluate(m, Dual{c.eqps_old + delta.v, delta.d});
+  const double fac = rate_contribution(m, delta.v / c.dt) * c.thermo;
+  return Dual{c.q - 3.0 * m.G * delta.v - H.v * fac, -3.0 * m.G * delta.d - H.d * fac};
+}
+
+// solvers/newton.hpp:53-169; status bit 1 = root not bracketed, bit 2 = not converged
+MH_DEV double scalar_solve(const mimi_hip_material& m, const ReturnMapCtx& c, double x0, double lower,
+                           double upper, double xtol, double rtol, int max_iter, int& status) {
+  const double fl = rm_residual(m, c, Dual{lower, 0.0}).v;
+  const double fh = rm_residual(m, c, Dual{upper, 0.0}).v;
+  if (fabs(fl) < xtol) return lower;
+  if (fabs(fh) < xtol) return upper;
+  if (fl * fh > 0.) {
+    status |= 1;
+    return lower;
+  }
+  double xl = lower, xh = upper;
+  if (fl > 0) {
+    xl = upper;
+    xh = lower;
+  }
+  if (x0 < lower || x0 > upper) x0 = 0.5 * (lower + upper);
+  double x = x0;
+  double delta_x_old = fabs(upper - lower);
+  double delta_x = delta_x_old;
+  Dual R = rm_residual(m, c, Dual{x, 1.0});
+  double fval = R.v, df_dx = R.d;
+  bool converged = false;
+  int iterations = 0;
+  while (!converged) {
+    if (iterations == max_iter) {
+      status |= 2;
+      break;
+    }
+    if ((x - xh) * df_dx - fval > 0 || (x - xl) * df_dx - fval < 0
+        || fabs(2. * fval) > fabs(delta_x_old * df_dx)) {
+      delta_x_old = delta_x;
+      delta_x = 0.5 * (xh - xl);
+      x = xl + delta_x;
+    } else {
+      delta_x_old = delta_x;
+      delta_x = fval / df_dx;
+      x -= delta_x;
+    }
+    R = rm_residual(m, c, Dual{x, 1.0});
+    fval = R.v;
+    df_dx = R.d;
+    converged = (fabs(delta_x) < xtol) || (fabs(fval) < rtol);
+    if (fval < 0) xl = x; else xh = x;
+    ++iterations;
+  }
+  return x;
+}
+
+// ---- per-point state view ---------------------------------------------------------
+// J2 MaterialState (materials.hpp:278-286) stored SoA over points:
+//   eqps[pt], temperature[pt], plastic_strain[c*n_pts + pt]
+struct StateView {
+  double* eqps;
+  double* temperature;
+  double* plastic_strain;
+  int64_t n_pts;
+};
+
+template<int DIM>
+struct PointResult {
+  double P[DIM * DIM];
+  // by-products used by the tangent
+  double Finv[DIM * DIM], detF;
+  double sigma[DIM * DIM], s_trial[DIM * DIM];
+  double q, delta, hprime;
+  bool plastic;
+};
+
+#define MH_M(T, i, j) (T)[(i) + (j) * DIM]
+
+template<int DIM>
+MH_DEV void pk1_from_cauchy(PointResult<DIM>& w) {
+  // materials.cpp:60-71: P = det(F) * sigma * F^-T
+#pragma unroll
+  for (int i = 0; i < DIM; ++i)
+#pragma unroll
+    for (int J = 0; J < DIM; ++J) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) s += MH_M(w.sigma, i, k) * MH_M(w.Finv, J, k);
+      MH_M(w.P, i, J) = s * w.detF;
+    }
+}
+
+template<int DIM>
+MH_DEV void neo_hookean_stress(const mimi_hip_material& m, const double* F, PointResult<DIM>& w) {
+  w.detF = det_of<DIM>(F);
+  inverse_of<DIM>(F, w.detF, w.Finv);
+  const double mu_over = m.mu / w.detF;
+  const double diag = -mu_over + m.lambda * (w.detF - 1.);
+#pragma unroll
+  for (int i = 0; i < DIM; ++i)
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+      double b = 0;
+#pragma unroll
+      for (int k = 0; k < DIM; ++k) b += MH_M(F, i, k) * MH_M(F, j, k);
+      MH_M(w.sigma, i, j) = mu_over * b + (i == j ? diag : 0.0);
+    }
+  pk1_from_cauchy<DIM>(w);
+}
+
+// J2::PlasticStress<false> when ACCUMULATE == false; <true> otherwise (then the state
+// arguments are updated in place and no stress is produced).
+template<int DIM, bool ACCUMULATE>
+MH_DEV int j2_stress(const MaterialDev& md, double dt, const double* F, double* ep, double& eqps,
+                     double& temperature, PointResult<DIM>& w) {
+  const mimi_hip_material& m = md.m;
+  constexpr int DD = DIM * DIM;
+  double eps[DD], s[DD];
+  w.detF = det_of<DIM>(F);
+  inverse_of<DIM>(F, w.detF, w.Finv);
+#pragma unroll
+  for (int i = 0; i < DIM; ++i)
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) MH_M(eps, i, j) = 0.5 * (MH_M(F, i, j) + MH_M(F, j, i));
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) MH_M(eps, i, i) -= 1.;
+#pragma unroll
+  for (int i = 0; i < DD; ++i) eps[i] -= ep[i];
+  double tr = 0;
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) tr += MH_M(eps, i, i);
+  const double p = m.K * tr;
+  const double tr_over_dim = tr / (double)DIM;  // Dev(): trace / dim (material_utils.hpp:33,44)
+#pragma unroll
+  for (int i = 0; i < DD; ++i) s[i] = eps[i] * (2.0 * m.G);
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) MH_M(s, i, i) = (MH_M(eps, i, i) - tr_over_dim) * (2.0 * m.G);
+  double nrm = 0;
+#pragma unroll
+  for (int i = 0; i < DD; ++i) nrm += s[i] * s[i];
+  nrm = sqrt(nrm);
+  const double q = sqrt(3.0 / 2.0) * nrm;
+#pragma unroll
+  for (int i = 0; i < DD; ++i) w.s_trial[i] = s[i];
+  w.q = q;
+  w.plastic = false;
+  w.delta = 0;
+  w.hprime = 0;
+
+  ReturnMapCtx c{eqps, q, thermo_contribution(md, temperature), dt};
+  const double tolerance = md.sigma_y_ref * 1.e-10;
+  int status = 0;
+  if (rm_residual(m, c, Dual{0.0, 0.0}).v > tolerance) {
+    const double upper = (q - hardening_evaluate(m, Dual{c.eqps_old, 0.0}).v * c.thermo) / (3.0 * m.G);
+    const double delta = scalar_solve(m, c, 0.0, 0.0, upper, 1.e-10, tolerance, 100, status);
+    w.plastic = true;
+    w.delta = delta;
+    const double npf = 1.5 / q;
+    if constexpr (!ACCUMULATE) {
+      const Dual H = hardening_evaluate(m, Dual{c.eqps_old + delta, 1.0});
+      const double rc = rate_contribution(m, delta / dt);
+      w.hprime = H.d * rc * c.thermo + H.v * rate_contribution_derivative(m, delta / dt) / dt * c.thermo;
+#pragma unroll
+      for (int i = 0; i < DD; ++i) s[i] += -2.0 * m.G * delta * (npf * s[i]);
+    } else {
+      eqps += delta;
+#pragma unroll
+      for (int i = 0; i < DD; ++i) ep[i] += delta * (npf * s[i]);
+      if (m.hardening == MIMI_HIP_HARD_JC_TEMP_RATE) {
+        temperature += m.heat_fraction * q * delta / (m.density * m.specific_heat);
+      }
+    }
+  }
+  if constexpr (!ACCUMULATE) {
+#pragma unroll
+    for (int i = 0; i < DD; ++i) w.sigma[i] = s[i];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) MH_M(w.sigma, i, i) += p;
+    pk1_from_cauchy<DIM>(w);
+  }
+  return status;
+}
+
+// A_iJjL for the state left in `w` by the stress routines
+template<int DIM>
+MH_DEV void tangent_of(const mimi_hip_material& m, const PointResult<DIM>& w, double* A) {
+  const double J = w.detF;
+  const double* Fi = w.Finv;
+  if (m.kind == MIMI_HIP_MAT_NEOHOOKEAN) {
+    // P = mu F + (lambda J (J-1) - mu) F^-T
+    const double c1 = m.lambda * J * (J - 1.) - m.mu;
+    const double c2 = m.lambda * (2. * J - 1.) * J;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i)
+#pragma unroll
+      for (int Jx = 0; Jx < DIM; ++Jx)
+#pragma unroll
+        for (int j = 0; j < DIM; ++j)
+#pragma unroll
+          for (int L = 0; L < DIM; ++L) {
+            double v = (i == j && Jx == L) ? m.mu : 0.0;
+            v += -c1 * MH_M(Fi, L, i) * MH_M(Fi, Jx, j);
+            v += c2 * MH_M(Fi, L, j) * MH_M(Fi, Jx, i);
+            A[((i * DIM + Jx) * DIM + j) * DIM + L] = v;
+          }
+    return;
+  }
+  // J2: P_iJ = J sigma_ik Finv_Jk, sigma = radial return of the small-strain trial state
+  double beta = 1.0, gamma = 0.0;
+  if (w.plastic) {
+    const double q = w.q, G = m.G;
+    beta = 1.0 - 3.0 * G * w.delta / q;
+    gamma = 3.0 * G * (1.5 / q) * (1.0 / ((3.0 * G + w.hprime) * q) - w.delta / (q * q));
+  }
+  const double G2 = 2.0 * m.G;
+#pragma unroll
+  for (int i = 0; i < DIM; ++i)
+#pragma unroll
+    for (int Jx = 0; Jx < DIM; ++Jx)
+#pragma unroll
+      for (int j = 0; j < DIM; ++j)
+#pragma unroll
+        for (int L = 0; L < DIM; ++L) {
+          double v = 0.0;
+#pragma unroll
+          for (int k = 0; k < DIM; ++k) {
+            v += MH_M(w.sigma, i, k) * J * (MH_M(Fi, L, j) * MH_M(Fi, Jx, k) - MH_M(Fi, Jx, j) * MH_M(Fi, L, k));
+            double C = (i == k && j == L ? m.K : 0.0);
+            C += beta * G2 * (0.5 * ((i == j && k == L ? 1.0 : 0.0) + (i == L && k == j ? 1.0 : 0.0))
+                              - (i == k && j == L ? 1.0 / (double)DIM : 0.0));
+            C -= G2 * gamma * MH_M(w.s_trial, i, k) * MH_M(w.s_trial, j, L);
+            v += J * C * MH_M(Fi, Jx, k);
+          }
+          A[((i * DIM + Jx) * DIM + j) * DIM + L] = v;
+        }
+}
+
+// One call per quadrature point.  pt indexes the SoA state; F is (i,J) column-major.
+template<int DIM>
+MH_DEV int evaluate_pk1(const MaterialDev& md, double dt, const StateView& st, int64_t pt, const double* F,
+                        PointResult<DIM>& w) {
+  if (md.m.kind == MIMI_HIP_MAT_NEOHOOKEAN) {
+    neo_hookean_stress<DIM>(md.m, F, w);
+    return 0;
+  }
+  double ep[DIM * DIM];
+#pragma unroll
+  for (int c = 0; c < DIM * DIM; ++c) ep[c] = st.plastic_strain[c * st.n_pts + pt];
+  double eqps = st.eqps[pt], T = st.temperature[pt];
+  return j2_stress<DIM, false>(md, dt, F, ep, eqps, T, w);
+}
+
+template<int DIM>
+MH_DEV int accumulate_state(const MaterialDev& md, double dt, const StateView& st, int64_t pt, const double* F) {
+  if (md.m.kind != MIMI_HIP_MAT_J2) return 0;
+  double ep[DIM * DIM];
+#pragma unroll
+  for (int c = 0; c < DIM * DIM; ++c) ep[c] = st.plastic_strain[c * st.n_pts + pt];
+  double eqps = st.eqps[pt], T = st.temperature[pt];
+  PointResult<DIM> w;
+  const int status = j2_stress<DIM, true>(md, dt, F, ep, eqps, T, w);
+  if (w.plastic) {
+#pragma unroll
+    for (int c = 0; c < DIM * DIM; ++c) st.plastic_strain[c * st.n_pts + pt] = ep[c];
+    st.eqps[pt] = eqps;
+    st.temperature[pt] = T;
+  }
+  return status;
+}
+
+}  // namespace mimi_hip

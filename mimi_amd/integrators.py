@@ -1,0 +1,201 @@
+"""Host-side mirror of the reference's integrator interface
+(src/mimi/integrators/nonlinear_base.hpp:14-154) on top of the C ABI of libmimi_hip.so.
+
+Method names, argument meaning and accumulate-into semantics are the reference's:
+  Prepare(); AddDomainResidual(u, r); AddDomainResidualAndGrad(u, grad_factor, r, A);
+  DomainPostTimeAdvance(u); public members dt_, first_effective_dt_, second_effective_dt_
+(snake_case aliases are provided as well).  `u`, `r`, `A` may be numpy arrays (host) or
+torch tensors on the handle's device (used in place, call is asynchronous on the stream).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import check, ptr
+
+TANGENT_ANALYTIC = 0
+TANGENT_REFERENCE_FD = 1
+
+
+class CSRPattern:
+    """(rowptr int64[n_vdofs+1], col int32[nnz]) of PrepareSparsity (utils/precomputed.cpp:151-174)."""
+
+    def __init__(self, rowptr, col, nnz):
+        self.rowptr, self.col, self.nnz = rowptr, col, int(nnz)
+
+    @classmethod
+    def of_bspline_patch(cls, patch, device=0, on_device=False):
+        """Structured pattern of a lexicographically numbered patch, built on the GPU."""
+        L = _capi.lib()
+        n = (C.c_int32 * 3)(*(patch.n_ctrl + [1] * (3 - patch.dim)))
+        p = (C.c_int32 * 3)(*(patch.degrees + [0] * (3 - patch.dim)))
+        nnz = C.c_int64(0)
+        nrows = patch.n_vdofs
+        if on_device:
+            import torch
+            dev = torch.device("cuda", device)
+            rowptr = torch.empty(nrows + 1, dtype=torch.int64, device=dev)
+            check(L.mimi_hip_bspline_sparsity(patch.dim, n, p, device, ptr(rowptr), None, C.byref(nnz)))
+            col = torch.empty(nnz.value, dtype=torch.int32, device=dev)
+            check(L.mimi_hip_bspline_sparsity(patch.dim, n, p, device, ptr(rowptr), ptr(col), C.byref(nnz)))
+        else:
+            rowptr = np.empty(nrows + 1, dtype=np.int64)
+            check(L.mimi_hip_bspline_sparsity(patch.dim, n, p, device, ptr(rowptr), None, C.byref(nnz)))
+            col = np.empty(nnz.value, dtype=np.int32)
+            check(L.mimi_hip_bspline_sparsity(patch.dim, n, p, device, ptr(rowptr), ptr(col), C.byref(nnz)))
+        return cls(rowptr, col, nnz.value)
+
+
+class NonlinearBase:
+    """integrators/nonlinear_base.hpp:14-154"""
+    dt_ = 0.0
+    first_effective_dt_ = 0.0
+    second_effective_dt_ = 0.0
+
+    def __init__(self, name):
+        self.name_ = name
+
+    def Name(self):
+        return self.name_
+
+
+class NonlinearSolid(NonlinearBase):
+    """integrators::NonlinearSolid (integrators/nonlinear_solid.hpp:15-128) on one MI355X.
+
+    Either `patch` (a splines.BSplinePatch: tables are generated on the device and the
+    tensor-product kernels are used) or `tables` (dict with the reference's flattened
+    PrecomputedData: dim, n_nodes, dofs[e,a], dN_dX[e,q,J,a], weight_det[e,q]) must be given.
+    """
+
+    def __init__(self, name, material, pattern, patch=None, tables=None, device=0, quadrature_order=-1,
+                 element_box=None, node_ids=None):
+        super().__init__(name)
+        self.material_ = material
+        self.pattern_ = pattern
+        self.patch_, self.tables_ = patch, tables
+        self.device_ = device
+        self.quadrature_order_ = quadrature_order
+        self.element_box_ = element_box
+        self.node_ids_ = node_ids
+        self._h = None
+        self._keep = []
+
+    # -- NonlinearSolid::Prepare (nonlinear_solid.cpp:31-46) --------------------------
+    def Prepare(self):
+        L = _capi.lib()
+        mat = self.material_._c_struct()
+        h = C.c_void_p()
+        if self.patch_ is not None:
+            p = self.patch_
+            d = _capi.BSplinePatch()
+            d.dim = p.dim
+            for i in range(p.dim):
+                d.degree[i] = p.degrees[i]
+                d.n_knots[i] = len(p.knots[i])
+                d.knots[i] = p.knots[i].ctypes.data
+            d.control_points = p.control_points.ctypes.data
+            if self.node_ids_ is not None:
+                ids = np.ascontiguousarray(self.node_ids_, dtype=np.int64)
+                self._keep.append(ids)
+                d.node_ids = ids.ctypes.data
+            d.quadrature_order = self.quadrature_order_
+            if self.element_box_ is not None:
+                b, e = self.element_box_
+                for i in range(3):
+                    d.element_begin[i] = b[i]
+                    d.element_end[i] = e[i]
+            d.csr_rowptr = ptr(self.pattern_.rowptr).value
+            d.csr_col = ptr(self.pattern_.col).value
+            check(L.mimi_hip_domain_create_bspline(C.byref(d), C.byref(mat), self.device_, C.byref(h)))
+        else:
+            t = self.tables_
+            d = _capi.DomainTables()
+            dofs = np.ascontiguousarray(t["dofs"], dtype=np.int32)
+            g = np.ascontiguousarray(t["dN_dX"], dtype=np.float64)
+            wd = np.ascontiguousarray(t["weight_det"], dtype=np.float64)
+            self._keep += [dofs, g, wd]
+            d.dim = t["dim"]
+            d.n_elements, d.n_dof = dofs.shape
+            d.n_quad = wd.shape[1]
+            d.n_nodes = t["n_nodes"]
+            assert g.shape == (d.n_elements, d.n_quad, d.dim, d.n_dof)
+            d.dofs, d.dN_dX, d.weight_det = dofs.ctypes.data, g.ctypes.data, wd.ctypes.data
+            d.csr_rowptr = ptr(self.pattern_.rowptr).value
+            d.csr_col = ptr(self.pattern_.col).value
+            check(L.mimi_hip_domain_create(C.byref(d), C.byref(mat), self.device_, C.byref(h)))
+        self._h = h
+        self.n_elements_ = int(L.mimi_hip_domain_info(h, 0))
+        self.n_quad_ = int(L.mimi_hip_domain_info(h, 1))
+        self.n_dof_ = int(L.mimi_hip_domain_info(h, 2))
+        self.nnz_ = int(L.mimi_hip_domain_info(h, 3))
+        self.n_vdofs_ = int(L.mimi_hip_domain_info(h, 4))
+        self.path_ = int(L.mimi_hip_domain_info(h, 5))
+        self.has_states_ = self.material_._kind == 1
+        return self
+
+    def _handle(self):
+        if self._h is None:
+            raise RuntimeError("Prepare() has not been called")
+        return self._h
+
+    def _push_dt(self):
+        # forms::Nonlinear pushes these public members before each call (forms/nonlinear.hpp:63-65)
+        check(_capi.lib().mimi_hip_domain_set_dt(self._handle(), self.dt_, self.first_effective_dt_,
+                                                 self.second_effective_dt_))
+
+    def SetTangentMode(self, mode):
+        check(_capi.lib().mimi_hip_domain_set_tangent_mode(self._handle(), mode))
+
+    def SetStream(self, stream):
+        check(_capi.lib().mimi_hip_domain_set_stream(self._handle(), C.c_void_p(stream) if stream else None))
+
+    def Synchronize(self):
+        check(_capi.lib().mimi_hip_domain_synchronize(self._handle()))
+
+    # -- nonlinear_solid.cpp:151-160 ---------------------------------------------------
+    def AddDomainResidual(self, current_u, residual):
+        self._push_dt()
+        check(_capi.lib().mimi_hip_domain_add_residual(self._handle(), ptr(current_u), ptr(residual)))
+
+    # -- nonlinear_solid.cpp:162-177 ---------------------------------------------------
+    def AddDomainResidualAndGrad(self, current_u, grad_factor, residual, grad_values):
+        self._push_dt()
+        check(_capi.lib().mimi_hip_domain_add_residual_and_grad(self._handle(), ptr(current_u), float(grad_factor),
+                                                                ptr(residual), ptr(grad_values)))
+
+    # -- nonlinear_solid.cpp:179-199 ---------------------------------------------------
+    def DomainPostTimeAdvance(self, converged_u):
+        # the reference's material keeps the dt_ of the latest Add* call (nonlinear_solid.cpp:154,167)
+        self._push_dt()
+        check(_capi.lib().mimi_hip_domain_post_time_advance(self._handle(), ptr(converged_u)))
+
+    def AddDomainGrad(self, current_u, grad):
+        raise RuntimeError("Currently not implemented, use AddDomainResidualAndGrad")  # nonlinear_solid.hpp:108-113
+
+    # -- material state (MaterialState, materials.hpp:278-286) --------------------------
+    def State(self, what):
+        ids = {"accumulated_plastic_strain": 0, "temperature": 1, "plastic_strain": 2}
+        n = self.n_elements_ * self.n_quad_
+        dim = self.patch_.dim if self.patch_ is not None else self.tables_["dim"]
+        shape = (self.n_elements_, self.n_quad_, dim * dim) if what == "plastic_strain" else (self.n_elements_, self.n_quad_)
+        out = np.empty(shape)
+        check(_capi.lib().mimi_hip_domain_get_state(self._handle(), ids[what], ptr(out), out.size))
+        return out
+
+    def ResetState(self):
+        check(_capi.lib().mimi_hip_domain_reset_state(self._handle()))
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _capi.lib().mimi_hip_domain_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # snake_case aliases
+    prepare = Prepare
+    add_domain_residual = AddDomainResidual
+    add_domain_residual_and_grad = AddDomainResidualAndGrad
+    domain_post_time_advance = DomainPostTimeAdvance

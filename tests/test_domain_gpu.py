@@ -1,0 +1,153 @@
+"""Parity of the HIP domain integrator (through the C ABI) against the oracle on the same
+seeded inputs.  Bars: residual <= 1e-12 relative (max-norm); analytic tangent
+vs the oracle's exact tangent <= 1e-11 relative; reference-FD mode vs the oracle's
+reference-FD restatement within the FD round-off amplification (5e-4 relative, measured 1e-5)."""
+import numpy as np
+import pytest
+
+from _cases import JC_TEST, oracle_material, synthetic_u
+
+pytestmark = pytest.mark.gpu
+
+CASES = [((2, 2), 3, [5.0, 1.0]), ((3, 4), 2, None), ((3, 2, 2), 2, None), ((2, 2, 1), 3, None),
+         ((4, 3, 2), 1, None), ((8, 8, 2), 2, None)]
+
+
+def product_material(name):
+    import mimi_amd
+    if name == "neohook":
+        m = mimi_amd.CompressibleOgdenNeoHookean()
+        m.density = 1.0
+        m.set_young_poisson(2100, 0.3)
+        return m
+    m = mimi_amd.J2()
+    m.density = 1.0
+    m.set_young_poisson(2100, 0.3)
+    m.heat_fraction, m.specific_heat = 0.9, 450
+    m.initial_temperature, m.melting_temperature = 20, 1500
+    h = mimi_amd.JohnsonCookTemperatureAndRateDependentHardening()
+    for k, v in JC_TEST.items():
+        if k != "kind":
+            setattr(h, k, v)
+    m.hardening = h
+    return m
+
+
+def make_pair(n_el, p, lengths, matname, creator):
+    """(oracle integrator, product integrator) on the same patch."""
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    from oracle import iga, ref_path as rp
+    P = iga.Patch.block(n_el, p, lengths)
+    D = rp.DomainOracle(P, oracle_material(matname), n_threads=2)
+    pattern = CSRPattern(D.rowptr.astype(np.int64), D.col.astype(np.int32), D.nnz)
+    if creator == "tables":
+        tables = dict(dim=P.dim, n_nodes=P.n_nodes, dofs=D.conn, dN_dX=D.dN_dX, weight_det=D.weight * D.det)
+        G = NonlinearSolid("domain", product_material(matname), pattern, tables=tables).Prepare()
+    else:
+        patch = mimi_amd.BSplinePatch.block(n_el, p, lengths)
+        G = NonlinearSolid("domain", product_material(matname), pattern, patch=patch).Prepare()
+    return P, D, G
+
+
+def relmax(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("creator", ["tables", "bspline"])
+@pytest.mark.parametrize("matname", ["neohook", "j2"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c[0])) + f"p{c[1]}")
+def test_residual_and_tangent_parity(case, matname, creator):
+    from oracle import ref_path as rp
+    n_el, p, lengths = case
+    P, D, G = make_pair(n_el, p, lengths, matname, creator)
+    dt = 0.5
+    D.set_dt(dt)
+    G.dt_ = dt
+    hmin = min((lengths[i] if lengths else n_el[i]) / n_el[i] for i in range(len(n_el)))
+    scale = 0.05 if matname == "neohook" else 0.02 * hmin
+    u = synthetic_u(P, scale=scale)
+    if matname == "j2":
+        # commit a plastic state first so that eps_p, eqps, T are non-trivial (20-77 % of the
+        # points yield with these amplitudes)
+        u0 = synthetic_u(P, scale=0.03 * hmin, seed=7)
+        D.domain_post_time_advance(u0)
+        G.DomainPostTimeAdvance(u0)
+        assert D.eqps.max() > 1e-4
+        assert np.allclose(G.State("accumulated_plastic_strain"), D.eqps, rtol=1e-9, atol=1e-13)
+        assert np.allclose(G.State("temperature"), D.temperature, rtol=1e-12, atol=1e-12)
+        assert np.allclose(G.State("plastic_strain"), D.plastic_strain, rtol=1e-9, atol=1e-13)
+    # residual only, accumulate semantics (+=)
+    r0 = np.random.default_rng(3).standard_normal(P.n_vdofs)
+    r_o, r_g = r0.copy(), r0.copy()
+    D.add_domain_residual(u, r_o)
+    G.AddDomainResidual(u, r_g)
+    assert relmax(r_g - r0, r_o - r0) < 1e-12
+    # residual + analytic tangent
+    gf = 0.37
+    A0 = np.random.default_rng(4).standard_normal(D.nnz)
+    r_o, r_g, A_o, A_g = r0.copy(), r0.copy(), A0.copy(), A0.copy()
+    D.add_domain_residual_and_grad(u, gf, r_o, A_o, rp.TANGENT_EXACT)
+    G.AddDomainResidualAndGrad(u, gf, r_g, A_g)
+    assert relmax(r_g - r0, r_o - r0) < 1e-12
+    assert relmax(A_g - A0, A_o - A0) < 1e-11
+    # reference finite-difference mode, like for like
+    if P.n_el <= 32:
+        G.SetTangentMode(1)
+        r_o, r_g, A_o, A_g = r0.copy(), r0.copy(), A0.copy(), A0.copy()
+        D.add_domain_residual_and_grad(u, gf, r_o, A_o, rp.TANGENT_FD)
+        G.AddDomainResidualAndGrad(u, gf, r_g, A_g)
+        assert relmax(r_g - r0, r_o - r0) < 1e-12
+        # both sides are forward differences with steps down to 1e-10: the round-off of the two
+        # residual evaluations (1e-16 |R|) is amplified by 1/h, so they agree to ~1e-5..1e-4
+        assert relmax(A_g - A0, A_o - A0) < 5e-4
+        G.SetTangentMode(0)
+
+
+def test_device_pointers_and_stream():
+    """u / r / A as torch tensors on the GPU: used in place, asynchronous on the given stream."""
+    import torch
+    from oracle import ref_path as rp
+    P, D, G = make_pair((3, 2, 2), 2, None, "neohook", "bspline")
+    u = synthetic_u(P)
+    dev = torch.device("cuda", 0)
+    tu = torch.from_numpy(u).to(dev)
+    tr = torch.zeros(P.n_vdofs, dtype=torch.float64, device=dev)
+    tA = torch.zeros(D.nnz, dtype=torch.float64, device=dev)
+    G.SetStream(torch.cuda.current_stream().cuda_stream)
+    G.AddDomainResidualAndGrad(tu, 1.0, tr, tA)
+    G.AddDomainResidual(tu, tr)
+    G.Synchronize()
+    r_o = np.zeros(P.n_vdofs)
+    A_o = np.zeros(D.nnz)
+    D.add_domain_residual_and_grad(u, 1.0, r_o, A_o, rp.TANGENT_EXACT)
+    assert relmax(tr.cpu().numpy(), 2 * r_o) < 1e-12
+    assert relmax(tA.cpu().numpy(), A_o) < 1e-11
+
+
+def test_structured_sparsity_matches_oracle():
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern
+    from oracle import iga
+    for n_el, p in [((3, 4), 2), ((2, 2), 3), ((3, 2, 2), 2), ((2, 3, 2), 3), ((5, 4, 3), 1)]:
+        P = iga.Patch.block(n_el, p)
+        rowptr, col = P.sparsity()
+        pat = CSRPattern.of_bspline_patch(mimi_amd.BSplinePatch.block(n_el, p))
+        assert pat.nnz == rowptr[-1]
+        assert np.array_equal(pat.rowptr, rowptr)
+        assert np.array_equal(pat.col, col)
+
+
+def test_errors_surface_as_runtime_error():
+    """ScalarSolve's throw paths / bad input arrive as RuntimeError (utils/print.hpp:47-56)."""
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    patch = mimi_amd.BSplinePatch.block((2, 2), 2)
+    pat = CSRPattern.of_bspline_patch(patch)
+    m = mimi_amd.J2()
+    m.set_young_poisson(2100, 0.3)
+    with pytest.raises(RuntimeError, match="hardening missing"):
+        NonlinearSolid("domain", m, pat, patch=patch).Prepare()
+    bad = CSRPattern(pat.rowptr, np.zeros_like(pat.col), pat.nnz)
+    with pytest.raises(RuntimeError, match="CSR pattern"):
+        NonlinearSolid("domain", product_material("neohook"), bad, patch=patch).Prepare()
