@@ -120,10 +120,10 @@ class DomainOracle:
     """integrators::NonlinearSolid restated (nonlinear_solid.{hpp,cpp}) over the
     tables of a Patch."""
 
-    def __init__(self, patch, material, quadrature_order=-1, n_threads=1, with_a_ids=True):
+    def __init__(self, patch, material, quadrature_order=-1, n_threads=1, with_a_ids=True, elements=None):
         self.patch = patch
         self.n_threads = n_threads
-        t = patch.tables(quadrature_order)
+        t = patch.tables(quadrature_order, elements=elements)
         self.tables = t
         self.conn = np.ascontiguousarray(t["conn"], dtype=np.int32)
         self.v_dofs = np.ascontiguousarray(patch.vdofs(self.conn), dtype=np.int32)
@@ -136,6 +136,8 @@ class DomainOracle:
         self.a_ids = None
         if with_a_ids:
             ids = patch.a_ids(self.rowptr, self.col)
+            if elements is not None:
+                ids = ids[elements]
             assert ids.max() < 2 ** 31
             self.a_ids = np.ascontiguousarray(ids, dtype=np.int32)
         ne, nq = self.weight.shape

@@ -1,0 +1,89 @@
+"""N > 1 path on CPU: world_size-2 (and 3) `gloo` processes, each holding the assembly of its
+element slab (produced here by the oracle, which is only the data source / checker), run the
+product's interface exchange; every rank must end up with the fully assembled rows of all
+nodes its slab touches."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_el, p, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mimi_amd
+        from mimi_amd import parallel
+        from mimi_amd.integrators import CSRPattern
+        from oracle import iga, ref_path as rp
+        from _cases import oracle_material, synthetic_u
+        P = iga.Patch.block(n_el, p)
+        rowptr, col = P.sparsity()
+        patch = mimi_amd.BSplinePatch.block(n_el, p)
+        pattern = CSRPattern(rowptr, col, rowptr[-1])
+        shard = parallel.SlabShard(patch, pattern, rank, world)
+        (b, e) = shard.element_box
+        em = P.element_multi_index()
+        sel = np.ones(P.n_el, dtype=bool)
+        for d in range(P.dim):
+            sel &= (em[d] >= b[d]) & (em[d] < e[d])
+        elements = np.nonzero(sel)[0]
+        assert len(elements) == shard.n_local_elements
+        u = synthetic_u(P)
+        D = rp.DomainOracle(P, oracle_material("neohook"), elements=elements)
+        r = np.zeros(P.n_vdofs)
+        A = np.zeros(D.nnz)
+        D.add_domain_residual_and_grad(u, 1.0, r, A, rp.TANGENT_EXACT)
+        tr, tA = torch.from_numpy(r), torch.from_numpy(A)
+        ex = parallel.InterfaceExchange(shard, tr, tA)
+        ex.sum_residual_and_grad()
+        # full assembly for comparison
+        Dfull = rp.DomainOracle(P, oracle_material("neohook"))
+        rf = np.zeros(P.n_vdofs)
+        Af = np.zeros(D.nnz)
+        Dfull.add_domain_residual_and_grad(u, 1.0, rf, Af, rp.TANGENT_EXACT)
+        touched = np.unique(D.conn)
+        rows = (touched[:, None] * P.dim + np.arange(P.dim)[None, :]).ravel()
+        ok = np.allclose(r[rows], rf[rows], rtol=1e-12, atol=1e-12)
+        for row in rows:
+            s, t = rowptr[row], rowptr[row + 1]
+            ok = ok and np.allclose(A[s:t], Af[s:t], rtol=1e-12, atol=1e-10)
+        q.put((rank, bool(ok), len(elements)))
+    except Exception as exc:  # pragma: no cover
+        q.put((rank, False, repr(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_el,p", [(2, (3, 2, 6), 2), (3, (2, 9), 3), (2, (4, 5, 3), 1)])
+def test_interface_exchange_gloo(world, n_el, p):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_el, p, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(ok is True for _, ok, _ in results), results
+    assert sum(n for _, _, n in results) == int(np.prod(n_el))
+
+
+def test_slab_shard_boxes():
+    import mimi_amd
+    from mimi_amd import parallel
+    patch = mimi_amd.BSplinePatch.block((128, 128, 16), 2)
+    boxes = [parallel.SlabShard(patch, None, r, 8).element_box for r in range(8)]
+    assert boxes[0] == ([0, 0, 0], [128, 16, 16]) and boxes[7] == ([0, 112, 0], [128, 128, 16])
+    with pytest.raises(RuntimeError):
+        parallel.SlabShard(mimi_amd.BSplinePatch.block((2, 2, 3), 2), None, 0, 3)
