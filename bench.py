@@ -140,7 +140,9 @@ def main():
     integ = NonlinearSolid("domain", make_material(material), pattern, patch=patch, device=local_rank,
                            element_box=shard.element_box).Prepare()
     integ.dt_ = 0.5
-    stream = torch.cuda.current_stream()
+    # a non-default stream: the library launches on it and the events below are recorded on it
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     integ.SetStream(stream.cuda_stream)
 
     u = torch.from_numpy(synthetic_u(patch)).to(dev)

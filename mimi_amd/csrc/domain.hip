@@ -131,6 +131,48 @@ static void setup_csr(mimi_hip_domain_s* h, const int64_t* rowptr, const int32_t
   check_status(h);
 }
 
+
+static PatchDev patch_dev(mimi_hip_domain_s* h, const double* ctrl) {
+  PatchDev P{};
+  const int dim = h->dim;
+  P.dim = dim;
+  for (int d = 0; d < 3; ++d) {
+    P.p[d] = d < dim ? h->degree[d] : 0;
+    P.nq[d] = d < dim ? h->nq1[d] : 1;
+    P.n_ctrl[d] = d < dim ? h->n_ctrl[d] : 1;
+    P.box_begin[d] = d < dim ? h->el_begin[d] : 0;
+    P.box_n[d] = d < dim ? h->el_end[d] - h->el_begin[d] : 1;
+    P.B[d] = d < dim ? h->tab1d.ptr + h->tab_off_B[d] : nullptr;
+    P.D[d] = d < dim ? h->tab1d.ptr + h->tab_off_D[d] : nullptr;
+    P.W[d] = d < dim ? h->tab1d.ptr + h->tab_off_W[d] : nullptr;
+    P.first[d] = d < dim ? h->first1d.ptr + h->first_off[d] : nullptr;
+  }
+  P.ctrl = ctrl;
+  P.node_ids = h->node_ids.ptr;
+  P.n_dof = h->n_dof;
+  P.n_q = h->n_q;
+  P.n_el = h->n_el;
+  return P;
+}
+
+// reference-layout tables (utils/precomputed.cpp:316-321) from the compact geometry, on demand
+static void ensure_general_tables(mimi_hip_domain_s* h) {
+  if (h->dN_dX.ptr) return;
+  if (!h->geo.ptr) fail("no tables to integrate with");
+  const int64_t npts = (int64_t)h->n_el * h->n_q;
+  h->dN_dX.resize((size_t)npts * h->n_dof * h->dim);
+  h->wdet.resize((size_t)npts);
+  PatchDev P = patch_dev(h, nullptr);
+  const int threads = 256;
+  const int64_t total = npts * h->n_dof;
+  const int64_t blocks = (total + threads - 1) / threads;
+  if (h->dim == 2)
+    hipLaunchKernelGGL(expand_tables_kernel<2>, dim3((unsigned)blocks), dim3(threads), 0, h->stream, P, h->geo.ptr, h->dofs.ptr, h->dN_dX.ptr, h->wdet.ptr);
+  else
+    hipLaunchKernelGGL(expand_tables_kernel<3>, dim3((unsigned)blocks), dim3(threads), 0, h->stream, P, h->geo.ptr, h->dofs.ptr, h->dN_dX.ptr, h->wdet.ptr);
+  MH_HIP(hipGetLastError());
+}
+
 static GeneralArgs general_args(mimi_hip_domain_s* h, const double* u, double* r, double* A, double gf) {
   GeneralArgs a{};
   a.n_el = h->n_el;
@@ -178,7 +220,7 @@ static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double*
   if (h->path == 1 && grad != 2) {
     launch_tensor(h, grad, mu.dev, mr.dev, mA.dev, gf);
   } else {
-    if (!h->dN_dX.ptr) fail("reference-FD tangent needs the general tables (create with MIMI_HIP_KEEP_GENERAL=1)");
+    ensure_general_tables(h);
     GeneralArgs a = general_args(h, mu.dev, mr.dev, mA.dev, gf);
     if (h->dim == 2) launch_general<2>(h, grad, a); else launch_general<3>(h, grad, a);
   }
@@ -311,24 +353,8 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
     ctrl.assign(p->control_points, (size_t)n_nodes * dim, h->stream);
     if (p->node_ids) h->node_ids.assign(p->node_ids, (size_t)n_nodes, h->stream);
 
-    PatchDev P{};
-    P.dim = dim;
-    for (int d = 0; d < 3; ++d) {
-      P.p[d] = d < dim ? h->degree[d] : 0;
-      P.nq[d] = d < dim ? nq : 1;
-      P.n_ctrl[d] = d < dim ? h->n_ctrl[d] : 1;
-      P.box_begin[d] = d < dim ? h->el_begin[d] : 0;
-      P.box_n[d] = d < dim ? h->el_end[d] - h->el_begin[d] : 1;
-      P.B[d] = d < dim ? h->tab1d.ptr + h->tab_off_B[d] : nullptr;
-      P.D[d] = d < dim ? h->tab1d.ptr + h->tab_off_D[d] : nullptr;
-      P.W[d] = d < dim ? h->tab1d.ptr + offW[d] : nullptr;
-      P.first[d] = d < dim ? h->first1d.ptr + h->first_off[d] : nullptr;
-    }
-    P.ctrl = ctrl.ptr;
-    P.node_ids = p->node_ids ? h->node_ids.ptr : nullptr;
-    P.n_dof = h->n_dof;
-    P.n_q = h->n_q;
-    P.n_el = h->n_el;
+    for (int d = 0; d < dim; ++d) h->tab_off_W[d] = offW[d];
+    PatchDev P = patch_dev(h.get(), ctrl.ptr);
 
     const int64_t npts = (int64_t)h->n_el * h->n_q;
     h->geo.resize((size_t)npts * (dim * dim + 1));
@@ -450,6 +476,7 @@ int mimi_hip_domain_post_time_advance(mimi_hip_domain_t h, const double* u) {
     if (h->path == 1) {
       launch_tensor_post(h, mu.dev);
     } else {
+      ensure_general_tables(h);
       GeneralArgs a = general_args(h, mu.dev, nullptr, nullptr, 0.0);
       const size_t lds = (size_t)h->n_dof * h->dim * sizeof(double);
       if (h->dim == 2)

@@ -29,7 +29,7 @@ struct mimi_hip_domain_s {
   int el_begin[3] = {0, 0, 0}, el_end[3] = {1, 1, 1}, el_total[3] = {1, 1, 1};
   mimi_hip::DeviceBuffer<double> tab1d;      // per direction B then D: [n_spans][p+1][nq]
   mimi_hip::DeviceBuffer<int32_t> first1d;   // per direction [n_spans]
-  size_t tab_off_B[3] = {0, 0, 0}, tab_off_D[3] = {0, 0, 0}, first_off[3] = {0, 0, 0};
+  size_t tab_off_B[3] = {0, 0, 0}, tab_off_D[3] = {0, 0, 0}, tab_off_W[3] = {0, 0, 0}, first_off[3] = {0, 0, 0};
   mimi_hip::DeviceBuffer<double> geo;        // [n_el][dim*dim+1][n_q]: dxi/dX (d,J) then w*det
   mimi_hip::DeviceBuffer<int64_t> node_ids;  // lexicographic -> global, empty = identity
   bool structured_csr = false;               // CSR positions computable arithmetically

@@ -355,6 +355,54 @@ MH_DEV void tangent_of(const mimi_hip_material& m, const PointResult<DIM>& w, do
         }
 }
 
+// Row I of the tangent only: Arow[(J*DIM + j)*DIM + L] = dP_IJ / dF_jL  (same closed forms)
+template<int DIM, int I>
+MH_DEV void tangent_row_of(const mimi_hip_material& m, const PointResult<DIM>& w, double* Arow) {
+  const double J = w.detF;
+  const double* Fi = w.Finv;
+  if (m.kind == MIMI_HIP_MAT_NEOHOOKEAN) {
+    const double c1 = m.lambda * J * (J - 1.) - m.mu;
+    const double c2 = m.lambda * (2. * J - 1.) * J;
+#pragma unroll
+    for (int Jx = 0; Jx < DIM; ++Jx)
+#pragma unroll
+      for (int j = 0; j < DIM; ++j)
+#pragma unroll
+        for (int L = 0; L < DIM; ++L) {
+          double v = (I == j && Jx == L) ? m.mu : 0.0;
+          v += -c1 * MH_M(Fi, L, I) * MH_M(Fi, Jx, j);
+          v += c2 * MH_M(Fi, L, j) * MH_M(Fi, Jx, I);
+          Arow[(Jx * DIM + j) * DIM + L] = v;
+        }
+    return;
+  }
+  double beta = 1.0, gamma = 0.0;
+  if (w.plastic) {
+    const double q = w.q, G = m.G;
+    beta = 1.0 - 3.0 * G * w.delta / q;
+    gamma = 3.0 * G * (1.5 / q) * (1.0 / ((3.0 * G + w.hprime) * q) - w.delta / (q * q));
+  }
+  const double G2 = 2.0 * m.G;
+#pragma unroll
+  for (int Jx = 0; Jx < DIM; ++Jx)
+#pragma unroll
+    for (int j = 0; j < DIM; ++j)
+#pragma unroll
+      for (int L = 0; L < DIM; ++L) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+          v += MH_M(w.sigma, I, k) * J * (MH_M(Fi, L, j) * MH_M(Fi, Jx, k) - MH_M(Fi, Jx, j) * MH_M(Fi, L, k));
+          double C = (I == k && j == L ? m.K : 0.0);
+          C += beta * G2 * (0.5 * ((I == j && k == L ? 1.0 : 0.0) + (I == L && k == j ? 1.0 : 0.0))
+                            - (I == k && j == L ? 1.0 / (double)DIM : 0.0));
+          C -= G2 * gamma * MH_M(w.s_trial, I, k) * MH_M(w.s_trial, j, L);
+          v += J * C * MH_M(Fi, Jx, k);
+        }
+        Arow[(Jx * DIM + j) * DIM + L] = v;
+      }
+}
+
 // One call per quadrature point.  pt indexes the SoA state; F is (i,J) column-major.
 template<int DIM>
 MH_DEV int evaluate_pk1(const MaterialDev& md, double dt, const StateView& st, int64_t pt, const double* F,
