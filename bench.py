@@ -32,6 +32,8 @@ WORKLOADS = {
     "northstar": ((128, 128, 16), 2, "neohookean"),
     "cfg3": ((128, 128, 16), 3, "j2"),
     "cfg5": ((256, 256, 32), 2, "neohookean"),
+    # orientation experiments (same block, short axis first)
+    "northstar_zfirst": ((16, 128, 128), 2, "neohookean"),
 }
 
 # algorithmic bytes / flops per element integration

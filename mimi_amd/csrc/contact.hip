@@ -1,22 +1,570 @@
-// C ABI of the contact integrator (integrators::MortarContact) -- implementation pending.
+// C ABI + kernels of the contact integrator: integrators::MortarContact
+// (reference: src/mimi/integrators/mortar_contact.{hpp,cpp}, MortarContactWorkData in
+// integrators/integrator_utils.{hpp,cpp}, NearestDistanceBase::Results in
+// coefficients/nearest_distance.hpp:54-194).
+//
+// The reference's closest-point query is splinepy's proximity search (an absent, un-pinned
+// third-party library, nearest_distance.hpp:268-279); here the rigid body is analytic
+// (sphere / half space).  Everything downstream of the query follows the reference:
+//   pass 1  ElementGapAndArea + ComputePressure   mortar_contact.cpp:148-261
+//           nodal area A_i += w |J| N_i, gap G_i += w |J| g N_i, p_i = eps G_i / A_i
+//   pass 2  ElementResidual                        mortar_contact.hpp:99-134
+//           R(a,i) += -(w |J| p_q) N_a n_i   for faces with any non-zero nodal pressure
+//   tangent with the pressure frozen               mortar_contact.cpp:263-295 (FD in the reference;
+//           analytic here, or the reference's FD rule in MIMI_HIP_TANGENT_REFERENCE_FD mode)
+// Instead of per-thread copies + a mutex (mortar_contact.cpp:235-260,338-341,400-408) the nodal
+// sums and the scatter use fp64 atomics: the contact surface is (dim-1)-dimensional, a few
+// thousand faces, so this is not a bandwidth problem.
+#include <hip/hip_runtime.h>
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#include <algorithm>
+#include <memory>
+#include <vector>
+
 #include "common.hpp"
+#include "materials.hpp"
+
+namespace mimi_hip {
+
+struct ContactArgs {
+  int dim, n_faces, n_dof, n_q;
+  const int32_t* dofs;       // [n_faces][n_dof] global node ids
+  const int32_t* local;      // [n_faces][n_dof] index into the nodal arrays
+  const double* N;           // [n_faces][n_q][n_dof]
+  const double* dN;          // [n_faces][n_q][dim-1][n_dof]
+  const double* weight;      // [n_faces][n_q]
+  const double* x_ref;       // [n_nodes][dim]
+  const int64_t* rowptr;
+  const int32_t* pair_pos;   // [n_faces][n_dof][n_dof]
+  int body_kind;
+  double body[8];
+  double penalty;
+  const double* u;
+  double* r;
+  double* A;
+  double grad_factor;
+  double* area;              // [n_marked]
+  double* gap;
+  double* pressure;
+  double* scalars;           // [0] area, [1] pressure integral, [2..4] force, [5] gap norm^2
+  int mode;
+};
+
+constexpr int kMaxFaceDof = 16;
+
+// analytic stand-in for NearestDistance + ComputeNormal<true> + NormalGap
+// (nearest_distance.hpp:139-193): true gap and |x_rigid - x_query|
+template<int DIM>
+MH_DEV void nearest_body(const ContactArgs& p, const double* xq, double& true_g, double& distance) {
+  if (p.body_kind == MIMI_HIP_BODY_SPHERE) {
+    double d[DIM], nrm = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+      d[i] = xq[i] - p.body[i];
+      nrm += d[i] * d[i];
+    }
+    nrm = sqrt(nrm);
+    const double R = p.body[3];
+    double g = 0, dist = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+      const double n = d[i] / nrm;
+      const double pmq = (p.body[i] + R * n) - xq[i];
+      g -= n * pmq;
+      dist += pmq * pmq;
+    }
+    true_g = g;
+    distance = sqrt(dist);
+  } else {
+    double s = 0, dist = 0, g = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) s += (xq[i] - p.body[i]) * p.body[3 + i];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+      const double pmq = -s * p.body[3 + i];
+      g -= p.body[3 + i] * pmq;
+      dist += pmq * pmq;
+    }
+    true_g = g;
+    distance = sqrt(dist);
+  }
+}
+
+// J = x_e^T dN_dxi (integrator_utils.cpp:101-105); returns |J| (DenseMatrix::Weight) and the
+// NON-normalised normal m (ComputeUnitNormal before the division, integrator_utils.hpp:216-251)
+template<int DIM>
+MH_DEV double surface_normal(int n_dof, const double* x_e /*[DIM][n_dof]*/, const double* dN /*[DIM-1][n_dof]*/,
+                             double* m, double* t /*[DIM-1][DIM]*/) {
+#pragma unroll
+  for (int k = 0; k < DIM - 1; ++k)
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+      double s = 0;
+      for (int a = 0; a < n_dof; ++a) s += x_e[i * n_dof + a] * dN[k * n_dof + a];
+      t[k * DIM + i] = s;
+    }
+  if constexpr (DIM == 2) {
+    m[0] = t[1];
+    m[1] = -t[0];
+    return sqrt(m[0] * m[0] + m[1] * m[1]);
+  } else {
+    m[0] = t[1] * t[5] - t[2] * t[4];
+    m[1] = t[2] * t[3] - t[0] * t[5];
+    m[2] = t[0] * t[4] - t[1] * t[3];
+    return sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+  }
+}
+
+template<int DIM>
+MH_DEV void gather_x(const ContactArgs& p, int f, double* x_e) {
+  // integrator_utils.cpp:80-89: x_e = u[v_dofs] + X_ref
+  for (int a = 0; a < p.n_dof; ++a) {
+    const int64_t node = p.dofs[(int64_t)f * p.n_dof + a];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) x_e[i * p.n_dof + a] = p.u[node * DIM + i] + p.x_ref[node * DIM + i];
+  }
+}
+
+// pass 1: one thread per (face, quadrature point)
+template<int DIM>
+__global__ void contact_gap_area_kernel(ContactArgs p, int gap_norm_only) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)p.n_faces * p.n_q) return;
+  const int f = idx / p.n_q;
+  const int64_t pt = idx;
+  double x_e[DIM * kMaxFaceDof];
+  gather_x<DIM>(p, f, x_e);
+  const double* N = p.N + pt * p.n_dof;
+  double xq[DIM];
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) {
+    double s = 0;
+    for (int a = 0; a < p.n_dof; ++a) s += x_e[i * p.n_dof + a] * N[a];
+    xq[i] = s;
+  }
+  double true_g, distance;
+  nearest_body<DIM>(p, xq, true_g, distance);
+  if (gap_norm_only) {
+    // GapNorm (mortar_contact.cpp:423-467)
+    if (true_g < 0.0) unsafeAtomicAdd(&p.scalars[5], true_g * true_g);
+    return;
+  }
+  double g = true_g < 0. ? true_g : 0.;
+  double m[DIM], t[(DIM - 1) * DIM];
+  const double detJ = surface_normal<DIM>(p.n_dof, x_e, p.dN + pt * p.n_dof * (DIM - 1), m, t);
+  const double fac = p.weight[pt] * detJ;
+  unsafeAtomicAdd(&p.scalars[0], fac);
+  const double ratio = fabs(true_g) / distance;
+  if (acos(ratio < 1. ? ratio : 1.) > 1.e-5) g = 0.0;  // angle tolerance, mortar_contact.cpp:172-181
+  const double fac_g = fac * g;
+  for (int a = 0; a < p.n_dof; ++a) {
+    const int l = p.local[(int64_t)f * p.n_dof + a];
+    unsafeAtomicAdd(&p.area[l], fac * N[a]);
+    if (fac_g != 0.0) unsafeAtomicAdd(&p.gap[l], fac_g * N[a]);
+  }
+}
+
+__global__ void contact_pressure_kernel(int n, const double* area, const double* gap, double penalty, double* pressure) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pressure[i] = gap[i] / area[i] * penalty;  // mortar_contact.cpp:253-257
+}
+
+// element residual at given x_e (used by the FD mode too)
+template<int DIM>
+MH_DEV void face_residual(const ContactArgs& p, int f, const double* x_e, const double* p_e, double* R_e,
+                          double* force, double* pint) {
+  for (int k = 0; k < p.n_dof * DIM; ++k) R_e[k] = 0.0;
+  for (int q = 0; q < p.n_q; ++q) {
+    const int64_t pt = (int64_t)f * p.n_q + q;
+    const double* N = p.N + pt * p.n_dof;
+    double pq = 0;
+    for (int a = 0; a < p.n_dof; ++a) pq += N[a] * p_e[a];
+    double m[DIM], t[(DIM - 1) * DIM];
+    const double detJ = surface_normal<DIM>(p.n_dof, x_e, p.dN + pt * p.n_dof * (DIM - 1), m, t);
+    const double fac = p.weight[pt] * detJ * pq;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+      const double aw = (m[i] / detJ) * (-fac);
+      for (int a = 0; a < p.n_dof; ++a) R_e[i * p.n_dof + a] += aw * N[a];
+      if (force) force[i] += fac * (m[i] / detJ);
+    }
+    if (pint) *pint += fac;
+  }
+}
+
+// pass 2: one thread per face (faces are few; the work per face is small)
+template<int DIM>
+__global__ void contact_residual_kernel(ContactArgs p, int with_grad) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= p.n_faces) return;
+  double p_e[kMaxFaceDof];
+  bool any = false;
+  for (int a = 0; a < p.n_dof; ++a) {
+    p_e[a] = p.pressure[p.local[(int64_t)f * p.n_dof + a]];
+    any = any || (p_e[a] != 0.0);
+  }
+  if (!any) return;  // IsPressureZero (integrator_utils.cpp:112-119)
+  double x_e[DIM * kMaxFaceDof], R_e[DIM * kMaxFaceDof];
+  gather_x<DIM>(p, f, x_e);
+  double force[DIM] = {0}, pint = 0;
+  face_residual<DIM>(p, f, x_e, p_e, R_e, force, &pint);
+  for (int a = 0; a < p.n_dof; ++a) {
+    const int64_t node = p.dofs[(int64_t)f * p.n_dof + a];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) unsafeAtomicAdd(&p.r[node * DIM + i], R_e[i * p.n_dof + a]);
+  }
+  unsafeAtomicAdd(&p.scalars[1], pint);
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) unsafeAtomicAdd(&p.scalars[2 + i], force[i]);
+  if (!with_grad) return;
+  const int32_t* pp = p.pair_pos + (int64_t)f * p.n_dof * p.n_dof;
+  if (p.mode == MIMI_HIP_TANGENT_REFERENCE_FD) {
+    // mortar_contact.cpp:263-295: forward FD on the current POSITION, pressure frozen
+    double fwd[DIM * kMaxFaceDof];
+    for (int c = 0; c < p.n_dof * DIM; ++c) {
+      const double orig = x_e[c];
+      const double step = (orig != 0.0) ? fabs(orig) * 1.0e-8 : 1.0e-10;
+      const double step_inv = 1. / step;
+      x_e[c] = orig + step;
+      face_residual<DIM>(p, f, x_e, p_e, fwd, nullptr, nullptr);
+      x_e[c] = orig;
+      const int b = c % p.n_dof, j = c / p.n_dof;
+      for (int a = 0; a < p.n_dof; ++a) {
+        const int64_t rowA = (int64_t)p.dofs[(int64_t)f * p.n_dof + a] * DIM;
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) {
+          const double k_entry = (fwd[i * p.n_dof + a] - R_e[i * p.n_dof + a]) * step_inv;
+          unsafeAtomicAdd(p.A + p.rowptr[rowA + i] + pp[a * p.n_dof + b] + j, k_entry * p.grad_factor);
+        }
+      }
+    }
+    return;
+  }
+  // analytic: R(a,i) = -w p N_a m_i ;  d m / d x_bj with p frozen
+  for (int q = 0; q < p.n_q; ++q) {
+    const int64_t pt = (int64_t)f * p.n_q + q;
+    const double* N = p.N + pt * p.n_dof;
+    const double* dN = p.dN + pt * p.n_dof * (DIM - 1);
+    double pq = 0;
+    for (int a = 0; a < p.n_dof; ++a) pq += N[a] * p_e[a];
+    const double wp = p.weight[pt] * pq;
+    double m[DIM], t[(DIM - 1) * DIM];
+    surface_normal<DIM>(p.n_dof, x_e, dN, m, t);
+    for (int b = 0; b < p.n_dof; ++b)
+#pragma unroll
+      for (int j = 0; j < DIM; ++j) {
+        double dm[DIM];
+        if constexpr (DIM == 2) {
+          dm[0] = (j == 1) ? dN[b] : 0.0;
+          dm[1] = (j == 0) ? -dN[b] : 0.0;
+        } else {
+          double e[3] = {0, 0, 0};
+          e[j] = 1.0;
+          const double* t1 = t;
+          const double* t2 = t + 3;
+          const double d1 = dN[b], d2 = dN[p.n_dof + b];
+          dm[0] = d1 * (e[1] * t2[2] - e[2] * t2[1]) + d2 * (t1[1] * e[2] - t1[2] * e[1]);
+          dm[1] = d1 * (e[2] * t2[0] - e[0] * t2[2]) + d2 * (t1[2] * e[0] - t1[0] * e[2]);
+          dm[2] = d1 * (e[0] * t2[1] - e[1] * t2[0]) + d2 * (t1[0] * e[1] - t1[1] * e[0]);
+        }
+        for (int a = 0; a < p.n_dof; ++a) {
+          const int64_t rowA = (int64_t)p.dofs[(int64_t)f * p.n_dof + a] * DIM;
+#pragma unroll
+          for (int i = 0; i < DIM; ++i)
+            unsafeAtomicAdd(p.A + p.rowptr[rowA + i] + pp[a * p.n_dof + b] + j, -wp * N[a] * dm[i] * p.grad_factor);
+        }
+      }
+  }
+}
+
+__global__ void contact_pair_pos_kernel(int n_faces, int n_dof, int dim, const int32_t* dofs, const int64_t* rowptr,
+                                        const int32_t* col, int32_t* pair_pos, int* status) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n_faces * n_dof * n_dof) return;
+  const int b = idx % n_dof, a = (idx / n_dof) % n_dof;
+  const int64_t f = idx / ((int64_t)n_dof * n_dof);
+  const int64_t row = (int64_t)dofs[f * n_dof + a] * dim;
+  const int32_t target = dofs[f * n_dof + b] * dim;
+  int64_t lo = rowptr[row], hi = rowptr[row + 1];
+  const int64_t base = lo;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (col[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= rowptr[row + 1] || col[lo] != target) {
+    atomicOr(status, 4);
+    pair_pos[idx] = 0;
+    return;
+  }
+  pair_pos[idx] = (int32_t)(lo - base);
+}
+
+}  // namespace mimi_hip
 
 using namespace mimi_hip;
 
-static int not_yet() {
-  set_last_error("mimi_hip contact integrator: not implemented yet");
-  return 1;
+struct mimi_hip_contact_s {
+  int device = 0, dim = 0, n_faces = 0, n_dof = 0, n_q = 0, n_marked = 0;
+  int64_t n_nodes = 0, n_vdofs = 0, nnz = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  int mode = MIMI_HIP_TANGENT_ANALYTIC;
+  int body_kind = 0;
+  double body[8] = {0};
+  double penalty = 1e4;
+  DeviceBuffer<int32_t> dofs, local, pair_pos;
+  DeviceBuffer<double> N, dN, weight, x_ref, area, gap, pressure, scalars;
+  DeviceBuffer<int64_t> rowptr_own;
+  const int64_t* rowptr = nullptr;
+  DeviceBuffer<double> stage_u, stage_r, stage_A;
+  DeviceBuffer<int> status;
+  double last[6] = {0};
+  ~mimi_hip_contact_s() {
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+  }
+};
+
+template<typename F>
+static int guarded_c(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return 1;
+  }
+}
+
+static ContactArgs contact_args(mimi_hip_contact_s* h, const double* u, double* r, double* A, double gf) {
+  ContactArgs a{};
+  a.dim = h->dim;
+  a.n_faces = h->n_faces;
+  a.n_dof = h->n_dof;
+  a.n_q = h->n_q;
+  a.dofs = h->dofs.ptr;
+  a.local = h->local.ptr;
+  a.N = h->N.ptr;
+  a.dN = h->dN.ptr;
+  a.weight = h->weight.ptr;
+  a.x_ref = h->x_ref.ptr;
+  a.rowptr = h->rowptr;
+  a.pair_pos = h->pair_pos.ptr;
+  a.body_kind = h->body_kind;
+  for (int i = 0; i < 8; ++i) a.body[i] = h->body[i];
+  a.penalty = h->penalty;
+  a.u = u;
+  a.r = r;
+  a.A = A;
+  a.grad_factor = gf;
+  a.area = h->area.ptr;
+  a.gap = h->gap.ptr;
+  a.pressure = h->pressure.ptr;
+  a.scalars = h->scalars.ptr;
+  a.mode = h->mode;
+  return a;
+}
+
+static void run_contact(mimi_hip_contact_s* h, const double* u, double* r, double* A, double gf, bool with_grad) {
+  MH_HIP(hipSetDevice(h->device));
+  if (!u || !r || (with_grad && !A)) fail("null vector argument");
+  Mirror<double> mu = Mirror<double>::in(u, h->n_vdofs, h->stage_u, h->stream);
+  Mirror<double> mr = Mirror<double>::inout(r, h->n_vdofs, h->stage_r, h->stream);
+  Mirror<double> mA;
+  if (with_grad) mA = Mirror<double>::inout(A, h->nnz, h->stage_A, h->stream);
+  ContactArgs a = contact_args(h, mu.dev, mr.dev, mA.dev, gf);
+  // InitializeGapAreaPressure + last_* reset (mortar_contact.cpp:135-146,302-306)
+  MH_HIP(hipMemsetAsync(h->area.ptr, 0, h->n_marked * sizeof(double), h->stream));
+  MH_HIP(hipMemsetAsync(h->gap.ptr, 0, h->n_marked * sizeof(double), h->stream));
+  MH_HIP(hipMemsetAsync(h->scalars.ptr, 0, 6 * sizeof(double), h->stream));
+  const int threads = 128;
+  const int64_t npts = (int64_t)h->n_faces * h->n_q;
+  const unsigned b1 = (unsigned)((npts + threads - 1) / threads);
+  const unsigned b2 = (unsigned)((h->n_marked + threads - 1) / threads);
+  const unsigned b3 = (unsigned)((h->n_faces + 63) / 64);
+  if (h->dim == 2) {
+    hipLaunchKernelGGL(contact_gap_area_kernel<2>, dim3(b1), dim3(threads), 0, h->stream, a, 0);
+    hipLaunchKernelGGL(contact_pressure_kernel, dim3(b2), dim3(threads), 0, h->stream, h->n_marked, h->area.ptr, h->gap.ptr, h->penalty, h->pressure.ptr);
+    hipLaunchKernelGGL(contact_residual_kernel<2>, dim3(b3), dim3(64), 0, h->stream, a, with_grad ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL(contact_gap_area_kernel<3>, dim3(b1), dim3(threads), 0, h->stream, a, 0);
+    hipLaunchKernelGGL(contact_pressure_kernel, dim3(b2), dim3(threads), 0, h->stream, h->n_marked, h->area.ptr, h->gap.ptr, h->penalty, h->pressure.ptr);
+    hipLaunchKernelGGL(contact_residual_kernel<3>, dim3(b3), dim3(64), 0, h->stream, a, with_grad ? 1 : 0);
+  }
+  MH_HIP(hipGetLastError());
+  mr.finish(h->stream);
+  if (with_grad) mA.finish(h->stream);
+  if (mu.host || mr.host || (with_grad && mA.host)) MH_HIP(hipStreamSynchronize(h->stream));
 }
 
 extern "C" {
-int mimi_hip_contact_create(const mimi_hip_contact_tables*, int, mimi_hip_contact_t*) { return not_yet(); }
-int mimi_hip_contact_destroy(mimi_hip_contact_t) { return not_yet(); }
-int mimi_hip_contact_set_tangent_mode(mimi_hip_contact_t, int) { return not_yet(); }
-int mimi_hip_contact_set_stream(mimi_hip_contact_t, void*) { return not_yet(); }
-int mimi_hip_contact_synchronize(mimi_hip_contact_t) { return not_yet(); }
-int mimi_hip_contact_add_residual(mimi_hip_contact_t, const double*, double*) { return not_yet(); }
-int mimi_hip_contact_add_residual_and_grad(mimi_hip_contact_t, const double*, double, double*, double*) { return not_yet(); }
-int mimi_hip_contact_gap_norm(mimi_hip_contact_t, const double*, double*) { return not_yet(); }
-int mimi_hip_contact_last_history(mimi_hip_contact_t, double*) { return not_yet(); }
-int mimi_hip_contact_get_pressure(mimi_hip_contact_t, double*, int64_t, int64_t*) { return not_yet(); }
+
+int mimi_hip_contact_create(const mimi_hip_contact_tables* t, int device, mimi_hip_contact_t* out) {
+  return guarded_c([&] {
+    if (!t || !out) fail("null argument");
+    if (t->dim != 2 && t->dim != 3) fail("Unsupported Dim: %d", t->dim);
+    if (t->n_dof < 1 || t->n_dof > kMaxFaceDof) fail("face n_dof %d out of range [1,%d]", t->n_dof, kMaxFaceDof);
+    if (t->n_faces < 1) fail("no marked boundary faces");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+      fail("libmimi_hip: no HIP device visible -- this library has no CPU fallback");
+    auto h = std::make_unique<mimi_hip_contact_s>();
+    h->device = device;
+    MH_HIP(hipSetDevice(device));
+    MH_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    h->dim = t->dim;
+    h->n_faces = t->n_faces;
+    h->n_dof = t->n_dof;
+    h->n_q = t->n_quad;
+    h->n_nodes = t->n_nodes;
+    h->n_vdofs = t->n_nodes * t->dim;
+    h->body_kind = t->body_kind;
+    for (int i = 0; i < 8; ++i) h->body[i] = t->body[i];
+    h->penalty = t->penalty;
+    const size_t nfd = (size_t)t->n_faces * t->n_dof;
+    // host copy of the connectivity for the dense local numbering of marked dofs
+    // (mortar_contact.cpp:41-76: sorted unique marked dofs -> 0..n_marked-1)
+    std::vector<int32_t> dofs(nfd);
+    if (is_device_pointer(t->dofs))
+      MH_HIP(hipMemcpy(dofs.data(), t->dofs, nfd * sizeof(int32_t), hipMemcpyDeviceToHost));
+    else
+      std::copy(t->dofs, t->dofs + nfd, dofs.begin());
+    std::vector<int32_t> marked(dofs);
+    std::sort(marked.begin(), marked.end());
+    marked.erase(std::unique(marked.begin(), marked.end()), marked.end());
+    h->n_marked = (int)marked.size();
+    std::vector<int32_t> local(nfd);
+    for (size_t k = 0; k < nfd; ++k)
+      local[k] = (int32_t)(std::lower_bound(marked.begin(), marked.end(), dofs[k]) - marked.begin());
+    h->dofs.assign(dofs.data(), nfd, h->stream);
+    h->local.assign(local.data(), nfd, h->stream);
+    const size_t npts = (size_t)t->n_faces * t->n_quad;
+    h->N.assign(t->N, npts * t->n_dof, h->stream);
+    h->dN.assign(t->dN_dxi, npts * t->n_dof * (t->dim - 1), h->stream);
+    h->weight.assign(t->weight, npts, h->stream);
+    h->x_ref.assign(t->x_ref, (size_t)t->n_nodes * t->dim, h->stream);
+    h->area.resize(h->n_marked);
+    h->gap.resize(h->n_marked);
+    h->pressure.resize(h->n_marked);
+    h->scalars.resize(6);
+    MH_HIP(hipMemsetAsync(h->pressure.ptr, 0, h->n_marked * sizeof(double), h->stream));
+    h->status.resize(1);
+    MH_HIP(hipMemsetAsync(h->status.ptr, 0, sizeof(int), h->stream));
+    if (!t->csr_rowptr || !t->csr_col) fail("csr_rowptr / csr_col must be given");
+    if (is_device_pointer(t->csr_rowptr)) {
+      h->rowptr = t->csr_rowptr;
+    } else {
+      h->rowptr_own.assign(t->csr_rowptr, h->n_vdofs + 1, h->stream);
+      h->rowptr = h->rowptr_own.ptr;
+    }
+    MH_HIP(hipMemcpy(&h->nnz, h->rowptr + h->n_vdofs, sizeof(int64_t), hipMemcpyDeviceToHost));
+    DeviceBuffer<int32_t> col_tmp;
+    const int32_t* col_dev = t->csr_col;
+    if (!is_device_pointer(t->csr_col)) {
+      col_tmp.assign(t->csr_col, h->nnz, h->stream);
+      col_dev = col_tmp.ptr;
+    }
+    const int64_t total = (int64_t)nfd * t->n_dof;
+    h->pair_pos.resize(total);
+    hipLaunchKernelGGL(contact_pair_pos_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, t->n_faces,
+                       t->n_dof, t->dim, h->dofs.ptr, h->rowptr, col_dev, h->pair_pos.ptr, h->status.ptr);
+    MH_HIP(hipGetLastError());
+    int st = 0;
+    MH_HIP(hipMemcpyAsync(&st, h->status.ptr, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    MH_HIP(hipStreamSynchronize(h->stream));
+    if (st) fail("CSR pattern does not contain a boundary element's dof block");
+    *out = h.release();
+  });
 }
+
+int mimi_hip_contact_destroy(mimi_hip_contact_t h) {
+  return guarded_c([&] {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+  });
+}
+
+int mimi_hip_contact_set_tangent_mode(mimi_hip_contact_t h, int mode) {
+  return guarded_c([&] {
+    if (!h) fail("null handle");
+    if (mode != MIMI_HIP_TANGENT_ANALYTIC && mode != MIMI_HIP_TANGENT_REFERENCE_FD) fail("bad tangent mode %d", mode);
+    h->mode = mode;
+  });
+}
+
+int mimi_hip_contact_set_stream(mimi_hip_contact_t h, void* stream) {
+  return guarded_c([&] {
+    if (!h) fail("null handle");
+    h->stream = stream ? reinterpret_cast<hipStream_t>(stream) : h->own_stream;
+  });
+}
+
+int mimi_hip_contact_synchronize(mimi_hip_contact_t h) {
+  return guarded_c([&] {
+    if (!h) fail("null handle");
+    MH_HIP(hipSetDevice(h->device));
+    MH_HIP(hipStreamSynchronize(h->stream));
+  });
+}
+
+int mimi_hip_contact_add_residual(mimi_hip_contact_t h, const double* u, double* r) {
+  return guarded_c([&] {
+    if (!h) fail("null handle");
+    run_contact(h, u, r, nullptr, 0.0, false);
+  });
+}
+
+int mimi_hip_contact_add_residual_and_grad(mimi_hip_contact_t h, const double* u, double grad_factor, double* r,
+                                           double* A_values) {
+  return guarded_c([&] {
+    if (!h) fail("null handle");
+    run_contact(h, u, r, A_values, grad_factor, true);
+  });
+}
+
+int mimi_hip_contact_gap_norm(mimi_hip_contact_t h, const double* u, double* out) {
+  return guarded_c([&] {
+    if (!h || !out) fail("null argument");
+    MH_HIP(hipSetDevice(h->device));
+    Mirror<double> mu = Mirror<double>::in(u, h->n_vdofs, h->stage_u, h->stream);
+    ContactArgs a = contact_args(h, mu.dev, nullptr, nullptr, 0.0);
+    MH_HIP(hipMemsetAsync(h->scalars.ptr + 5, 0, sizeof(double), h->stream));
+    const int threads = 128;
+    const int64_t npts = (int64_t)h->n_faces * h->n_q;
+    const unsigned b1 = (unsigned)((npts + threads - 1) / threads);
+    if (h->dim == 2)
+      hipLaunchKernelGGL(contact_gap_area_kernel<2>, dim3(b1), dim3(threads), 0, h->stream, a, 1);
+    else
+      hipLaunchKernelGGL(contact_gap_area_kernel<3>, dim3(b1), dim3(threads), 0, h->stream, a, 1);
+    MH_HIP(hipGetLastError());
+    double g2 = 0;
+    MH_HIP(hipMemcpyAsync(&g2, h->scalars.ptr + 5, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MH_HIP(hipStreamSynchronize(h->stream));
+    *out = std::sqrt(g2);
+  });
+}
+
+int mimi_hip_contact_last_history(mimi_hip_contact_t h, double* out5) {
+  return guarded_c([&] {
+    if (!h || !out5) fail("null argument");
+    MH_HIP(hipSetDevice(h->device));
+    MH_HIP(hipMemcpyAsync(out5, h->scalars.ptr, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MH_HIP(hipStreamSynchronize(h->stream));
+  });
+}
+
+int mimi_hip_contact_get_pressure(mimi_hip_contact_t h, double* out, int64_t capacity, int64_t* n) {
+  return guarded_c([&] {
+    if (!h || !n) fail("null argument");
+    *n = h->n_marked;
+    if (!out) return;
+    if (capacity < h->n_marked) fail("pressure buffer too small");
+    MH_HIP(hipSetDevice(h->device));
+    MH_HIP(hipMemcpyAsync(out, h->pressure.ptr, h->n_marked * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    MH_HIP(hipStreamSynchronize(h->stream));
+  });
+}
+
+}  // extern "C"

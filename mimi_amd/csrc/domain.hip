@@ -521,6 +521,21 @@ int mimi_hip_domain_reset_state(mimi_hip_domain_t h) {
   });
 }
 
+// diagnostic (MH_PROFILE builds): per-stage cycle sums of the tensor kernel; not part of the ABI header
+int mimi_hip_debug_profile(mimi_hip_domain_t h, unsigned long long* out12, int reset) {
+  return guarded([&] {
+    if (!h) fail("null handle");
+    MH_HIP(hipSetDevice(h->device));
+    if (!h->prof_dev) {
+      MH_HIP(hipMalloc(reinterpret_cast<void**>(&h->prof_dev), 12 * sizeof(unsigned long long)));
+      MH_HIP(hipMemset(h->prof_dev, 0, 12 * sizeof(unsigned long long)));
+    }
+    MH_HIP(hipDeviceSynchronize());
+    if (out12) MH_HIP(hipMemcpy(out12, h->prof_dev, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) MH_HIP(hipMemset(h->prof_dev, 0, 12 * sizeof(unsigned long long)));
+  });
+}
+
 int64_t mimi_hip_domain_info(mimi_hip_domain_t h, int what) {
   if (!h) return -1;
   switch (what) {

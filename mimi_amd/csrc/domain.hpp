@@ -40,6 +40,7 @@ struct mimi_hip_domain_s {
   // status word raised by kernels (ScalarSolve failures, bad pattern)
   int* status_dev = nullptr;
   int* status_host = nullptr;  // pinned
+  unsigned long long* prof_dev = nullptr;  // MH_PROFILE builds only
 
   // staging for host-resident u / r / A
   mimi_hip::DeviceBuffer<double> stage_u, stage_r, stage_A;

@@ -51,6 +51,7 @@ struct TensorArgs {
   MaterialDev mat;
   StateView state;
   int* status;
+  unsigned long long* prof;  // diagnostic build only (MH_PROFILE): per-stage cycle sums
 };
 
 // wave-private LDS carve, in doubles
@@ -65,8 +66,24 @@ struct TensorLds {
   static constexpr int off_zb = off_ah + 27 * NQ3;       // [2 groups][NQ q0][NC]; also stage-R scratch
   static constexpr int zb_r = 3 * NQ3 + 3 * NB * NQ * NQ + 3 * NB2 * NQ;
   static constexpr int zb_size = 2 * NQ * NC > zb_r ? 2 * NQ * NC : zb_r;
-  static constexpr int total = off_zb + zb_size + (zb_size & 1);
+  static constexpr int off_cb = off_zb + zb_size + (zb_size & 1);   // [3 j][NB a0][n_carry] carry along the walk axis
+  static constexpr int n_carry = (NB - 1) * NB * (NB - 1) * NB * NB;
+  static constexpr int total = off_cb + 3 * NB * n_carry;
 };
+
+#ifdef MH_PROFILE
+#define MH_STAMP(k)                                                         \
+  do {                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+    unsigned long long t_;                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+    prof_acc[k] += t_ - prof_last;                                          \
+    prof_last = t_;                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                      \
+  } while (0)
+#else
+#define MH_STAMP(k)
+#endif
 
 template<int P>
 MH_DEV const double* tab_ptr(const double* tab, int dir, int isD) {
@@ -93,6 +110,15 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
   int64_t* rs = reinterpret_cast<int64_t*>(lds + L::off_rs);
   double* AH = lds + L::off_ah;
   double* ZB = lds + L::off_zb;
+  double* CB = lds + L::off_cb;
+  // entries shared with the next element of the column are carried in LDS instead of being
+  // written and re-read through memory (only when the walk axis is the third local direction)
+  const bool use_carry = p.seq_axis == 2;
+#ifdef MH_PROFILE
+  unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last)::"memory");
+#endif
 
   const int n_seq = p.seq_axis == 0 ? p.box_n[0] : (p.seq_axis == 1 ? p.box_n[1] : p.box_n[2]);
   auto element_of = [&](int es, int* el) -> int64_t {
@@ -150,6 +176,7 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
   }
 
   for (int es = 0; es < n_seq; ++es) {
+    MH_STAMP(0);
     // ---- stage 0: registers -> LDS, then issue the loads of the NEXT element -----------------
 #pragma unroll
     for (int rd = 0; rd < DROUNDS; ++rd) {
@@ -217,6 +244,7 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
     }
     __builtin_amdgcn_wave_barrier();
 
+    MH_STAMP(1);
     // ---- stage A: constitutive update, lane = quadrature point ----------------------------
     double Phat[QROUNDS][3];
 #pragma unroll
@@ -309,6 +337,7 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
       }
     }
 
+    MH_STAMP(2);
     // ---- stage R: residual row I by sum factorisation (scratch aliases ZB) ------------------
     {
       double* PH = ZB;                   // [3 m][NQ3]  (q = q0 + NQ q1 + NQ^2 q2)
@@ -366,6 +395,7 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
       __builtin_amdgcn_wave_barrier();
     }
 
+    MH_STAMP(3);
     if constexpr (GRAD == 1) {
       // ---- issue the loads of this element's CSR entries now (3 contiguous values per node
       // pair: j = 0..2); they are consumed after the contractions.  The entries touched by
@@ -379,11 +409,12 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
         const bool act = t < NB * NC;
         const int tt = act ? t : 0;
         const int c = tt / NB;
-        const int a1 = (c / NB2) % NB, a2 = c / (NB2 * NB);
+        const int b2 = (c / NB) % NB, a1 = (c / NB2) % NB, a2 = c / (NB2 * NB);
+        const bool carried = use_carry && a2 >= 1 && b2 >= 1 && es + 1 < n_seq;
 #pragma unroll
         for (int a0 = 0; a0 < NB; ++a0) {
           const int a = a0 + NB * (a1 + NB * a2);
-          dstp[rd][a0] = act ? p.A + rs[a] + ppv[rd][a0] : nullptr;
+          dstp[rd][a0] = (act && !carried) ? p.A + rs[a] + ppv[rd][a0] : nullptr;
         }
       }
 #ifndef MH_ABL_NOSCATTER
@@ -394,6 +425,7 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
 #pragma unroll
           for (int jj = 0; jj < 3; ++jj) old[rd][a0][jj] = dstp[rd][a0] ? dstp[rd][a0][jj] : 0.0;
 #endif
+      MH_STAMP(4);
 #pragma unroll 1
       for (int j = 0; j < 3; ++j) {
         const double* AHj = AH + j * 9 * NQ3;
@@ -510,6 +542,7 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
               }
           }
           __builtin_amdgcn_wave_barrier();
+          MH_STAMP(5);
           // ---- S3 partial: lane = (b0, c):  K[a0] += T0a[a0] (B0[b0] Z_h0 + D0[b0] Z_h1) ----------
 #ifdef MH_ABL_NOS3
           for (int rd = 0; rd < 0; ++rd) {
@@ -529,7 +562,40 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
             }
           }
           __builtin_amdgcn_wave_barrier();
+          MH_STAMP(6);
         }
+        if (use_carry) {
+          // incoming: the previous element's (a2+1, b2+1) entries are this element's (a2, b2)
+          double* CBj = CB + j * NB * L::n_carry;
+#pragma unroll
+          for (int rd = 0; rd < S3R; ++rd) {
+            const int t = rd * 64 + lane;
+            const int tt = t < NB * NC ? t : 0;
+            const int b0 = tt % NB, c = tt / NB;
+            const int b1 = c % NB, b2 = (c / NB) % NB, a1 = (c / NB2) % NB, a2 = c / (NB2 * NB);
+            if (t < NB * NC && es > 0 && a2 <= NB - 2 && b2 <= NB - 2) {
+              const int u = (((a2 * NB + a1) * (NB - 1) + b2) * NB + b1) * NB + b0;
+#pragma unroll
+              for (int a0 = 0; a0 < NB; ++a0) Kt[rd][a0] += CBj[a0 * L::n_carry + u];
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          // outgoing
+#pragma unroll
+          for (int rd = 0; rd < S3R; ++rd) {
+            const int t = rd * 64 + lane;
+            const int tt = t < NB * NC ? t : 0;
+            const int b0 = tt % NB, c = tt / NB;
+            const int b1 = c % NB, b2 = (c / NB) % NB, a1 = (c / NB2) % NB, a2 = c / (NB2 * NB);
+            if (t < NB * NC && a2 >= 1 && b2 >= 1 && es + 1 < n_seq) {
+              const int u = ((((a2 - 1) * NB + a1) * (NB - 1) + (b2 - 1)) * NB + b1) * NB + b0;
+#pragma unroll
+              for (int a0 = 0; a0 < NB; ++a0) CBj[a0 * L::n_carry + u] = Kt[rd][a0];
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        MH_STAMP(7);
         // keep the block in registers without dynamic indexing (the j loop stays rolled)
 #pragma unroll
         for (int rd = 0; rd < S3R; ++rd)
@@ -538,6 +604,7 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj) Kv[jj][rd][a0] = (jj == j) ? Kt[rd][a0] : Kv[jj][rd][a0];
       }
+      MH_STAMP(8);
       // ---- CSR read-modify-write: adds and stores
 #ifndef MH_ABL_NOSCATTER
 #pragma unroll
@@ -559,7 +626,12 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
       }
 #endif
     }
+    MH_STAMP(9);
   }
+#ifdef MH_PROFILE
+  if (lane == 0 && p.prof)
+    for (int k = 0; k < 12; ++k) atomicAdd(&p.prof[k], prof_acc[k]);
+#endif
 }
 
 template<int P, int GRAD>
@@ -655,7 +727,7 @@ inline TensorArgs tensor_args(mimi_hip_domain_s* h, const double* u, double* r, 
   // walk along the shortest axis (most units), colour over the other two
   int seq = 0;
   for (int d = 1; d < 3; ++d)
-    if (a.box_n[d] < a.box_n[seq]) seq = d;
+    if (a.box_n[d] <= a.box_n[seq]) seq = d;
   a.seq_axis = seq;
   a.u_axis = seq == 0 ? 1 : 0;
   a.v_axis = seq == 2 ? 1 : 2;
@@ -671,6 +743,7 @@ inline TensorArgs tensor_args(mimi_hip_domain_s* h, const double* u, double* r, 
   a.mat = h->mat;
   a.state = StateView{h->eqps.ptr, h->temperature.ptr, h->plastic_strain.ptr, h->n_pts};
   a.status = h->status_dev;
+  a.prof = h->prof_dev;
   return a;
 }
 

@@ -199,3 +199,124 @@ class NonlinearSolid(NonlinearBase):
     add_domain_residual = AddDomainResidual
     add_domain_residual_and_grad = AddDomainResidualAndGrad
     domain_post_time_advance = DomainPostTimeAdvance
+
+
+class RigidSphere:
+    """Analytic rigid body standing in for NearestDistanceToSplines
+    (coefficients/nearest_distance.hpp:215-288; splinepy's proximity query is not available)."""
+    kind = 0
+
+    def __init__(self, center, radius, coefficient=1.0e4):
+        self.center, self.radius = [float(c) for c in center], float(radius)
+        self.coefficient = float(coefficient)   # NearestDistanceBase::coefficient_ (nearest_distance.hpp:18)
+
+    def params(self, dim):
+        return self.center + [0.0] * (3 - dim) + [self.radius]
+
+
+class RigidPlane:
+    kind = 1
+
+    def __init__(self, point, normal, coefficient=1.0e4):
+        n = np.asarray(normal, dtype=np.float64)
+        self.point, self.normal = [float(c) for c in point], list(n / np.linalg.norm(n))
+        self.coefficient = float(coefficient)
+
+    def params(self, dim):
+        return self.point + [0.0] * (3 - dim) + self.normal + [0.0] * (3 - dim)
+
+
+class MortarContact(NonlinearBase):
+    """integrators::MortarContact (integrators/mortar_contact.hpp:23-172) against an analytic
+    rigid body, on one face of a B-spline patch."""
+
+    def __init__(self, nearest_distance_coeff, name, pattern, patch, axis, side, device=0, quadrature_order=-1):
+        super().__init__(name)
+        self.nearest_distance_coeff_ = nearest_distance_coeff
+        self.pattern_, self.patch_ = pattern, patch
+        self.axis_, self.side_ = axis, side
+        self.device_, self.quadrature_order_ = device, quadrature_order
+        self._h = None
+        self.last_area_ = 0.0
+        self.last_pressure_ = 0.0
+        self.last_force_ = np.zeros(patch.dim)
+
+    def Prepare(self):
+        from . import splines
+        L = _capi.lib()
+        p = self.patch_
+        dofs, N, dN, weight = splines.face_tables(p, self.axis_, self.side_, self.quadrature_order_)
+        t = _capi.ContactTables()
+        t.dim = p.dim
+        t.n_faces, t.n_dof = dofs.shape
+        t.n_quad = weight.shape[1]
+        t.n_nodes = p.n_nodes
+        self._keep = [dofs, N, dN, weight, p.control_points]
+        t.dofs, t.N, t.dN_dxi, t.weight = dofs.ctypes.data, N.ctypes.data, dN.ctypes.data, weight.ctypes.data
+        t.x_ref = p.control_points.ctypes.data
+        body = self.nearest_distance_coeff_
+        t.body_kind = body.kind
+        for i, v in enumerate(body.params(p.dim)):
+            t.body[i] = v
+        t.penalty = body.coefficient
+        t.csr_rowptr = ptr(self.pattern_.rowptr).value
+        t.csr_col = ptr(self.pattern_.col).value
+        h = C.c_void_p()
+        check(L.mimi_hip_contact_create(C.byref(t), self.device_, C.byref(h)))
+        self._h = h
+        self.n_marked_boundaries_ = int(t.n_faces)
+        return self
+
+    def _handle(self):
+        if self._h is None:
+            raise RuntimeError("Prepare() has not been called")
+        return self._h
+
+    def SetTangentMode(self, mode):
+        check(_capi.lib().mimi_hip_contact_set_tangent_mode(self._handle(), mode))
+
+    def SetStream(self, stream):
+        check(_capi.lib().mimi_hip_contact_set_stream(self._handle(), C.c_void_p(stream) if stream else None))
+
+    def _history(self):
+        out = np.zeros(5)
+        check(_capi.lib().mimi_hip_contact_last_history(self._handle(), ptr(out)))
+        self.last_area_, self.last_pressure_ = out[0], out[1]
+        self.last_force_ = out[2:2 + self.patch_.dim].copy()
+
+    # mortar_contact.cpp:297-351
+    def AddBoundaryResidual(self, current_u, residual):
+        check(_capi.lib().mimi_hip_contact_add_residual(self._handle(), ptr(current_u), ptr(residual)))
+
+    # mortar_contact.cpp:353-421
+    def AddBoundaryResidualAndGrad(self, current_u, grad_factor, residual, grad_values):
+        check(_capi.lib().mimi_hip_contact_add_residual_and_grad(self._handle(), ptr(current_u), float(grad_factor),
+                                                                 ptr(residual), ptr(grad_values)))
+
+    # mortar_contact.cpp:423-467
+    def GapNorm(self, test_u, nthreads=-1):
+        out = C.c_double(0.0)
+        check(_capi.lib().mimi_hip_contact_gap_norm(self._handle(), ptr(test_u), C.byref(out)))
+        return out.value
+
+    # mortar_contact.cpp:469-488: record last_area_, last_force_, last_pressure_
+    def BoundaryPostTimeAdvance(self, converged_u):
+        self._history()
+
+    def AveragePressure(self):
+        n = C.c_int64(0)
+        check(_capi.lib().mimi_hip_contact_get_pressure(self._handle(), None, 0, C.byref(n)))
+        out = np.zeros(n.value)
+        check(_capi.lib().mimi_hip_contact_get_pressure(self._handle(), ptr(out), out.size, C.byref(n)))
+        return out
+
+    def AddBoundaryGrad(self, current_u, grad):
+        raise RuntimeError("Currently not implemented, use AddDomainResidualAndGrad")  # mortar_contact.hpp:142-149
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _capi.lib().mimi_hip_contact_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -70,3 +70,99 @@ class BSplinePatch:
             end[d] = self.n_spans[d]
         begin[axis], end[axis] = b, e
         return begin, end
+
+
+# ---- boundary (face) tables for the contact integrator ---------------------------------
+def _gauss_01(n):
+    x, w = np.polynomial.legendre.leggauss(n)
+    return 0.5 * (x + 1.0), 0.5 * w
+
+
+def _basis_and_derivative(knots, p, span, xi):
+    """All p+1 non-zero B-splines of degree p on knot span `span` and their derivatives,
+    by the Cox-de Boor recursion written as a triangular table."""
+    N = np.zeros((p + 1, p + 1))
+    N[0, 0] = 1.0
+    for d in range(1, p + 1):
+        for j in range(d + 1):
+            i = span - d + j
+            v = 0.0
+            if j >= 1 and knots[i + d] > knots[i]:
+                v += (xi - knots[i]) / (knots[i + d] - knots[i]) * N[d - 1, j - 1]
+            if j <= d - 1 and knots[i + d + 1] > knots[i + 1]:
+                v += (knots[i + d + 1] - xi) / (knots[i + d + 1] - knots[i + 1]) * N[d - 1, j]
+            N[d, j] = v
+    dN = np.zeros(p + 1)
+    for j in range(p + 1):
+        i = span - p + j
+        if j >= 1 and knots[i + p] > knots[i]:
+            dN[j] += p / (knots[i + p] - knots[i]) * N[p - 1, j - 1]
+        if j <= p - 1 and knots[i + p + 1] > knots[i + 1]:
+            dN[j] -= p / (knots[i + p + 1] - knots[i + 1]) * N[p - 1, j]
+    return N[p], dN
+
+
+def _tables_1d(knots, p, nq):
+    x, w = _gauss_01(nq)
+    spans = [s for s in range(p, len(knots) - p - 1) if knots[s + 1] > knots[s]]
+    B = np.zeros((len(spans), p + 1, nq))
+    D = np.zeros_like(B)
+    for ie, s in enumerate(spans):
+        h = knots[s + 1] - knots[s]
+        for iq in range(nq):
+            B[ie, :, iq], dn = _basis_and_derivative(knots, p, s, knots[s] + x[iq] * h)
+            D[ie, :, iq] = dn * h
+    return np.array(spans), B, D, w
+
+
+def face_tables(patch, axis, side, quadrature_order=-1):
+    """Boundary-element tables of the patch face {xi_axis = side}: what the reference's
+    MortarContact reads from PrecomputedData for its marked boundary elements
+    (QuadData::N, dN_dxi, integration_weight; src/mimi/utils/precomputed.cpp:100-143,295-311).
+    The face parametrisation is oriented so that the surface normal of
+    ComputeUnitNormal (integrators/integrator_utils.hpp:216-251) points out of the body.
+    Returns dofs[f,a] (int32), N[f,q,a], dN_dxi[f,q,dim-1,a], weight[f,q]."""
+    dim = patch.dim
+    pmax = max(patch.degrees)
+    order = 2 * pmax + 3 if quadrature_order < 0 else quadrature_order
+    nq = order // 2 + 1
+    if dim == 3:
+        cyc = [(axis + 1) % 3, (axis + 2) % 3]
+        tang = cyc if side == 1 else cyc[::-1]
+        flip = False
+    else:
+        tang = [1 - axis]
+        # 2-D normal of tangent t is (t_y, -t_x): outward needs the tangent reversed on these faces
+        flip = (side == 1) if axis == 1 else (side == 0)
+    tabs = [_tables_1d(patch.knots[t], patch.degrees[t], nq) for t in tang]
+    strides = [int(np.prod(patch.n_ctrl[:d])) for d in range(dim)]
+    fixed = (0 if side == 0 else patch.n_ctrl[axis] - 1) * strides[axis]
+    if dim == 2:
+        spans, B, D, w = tabs[0]
+        t = tang[0]
+        p = patch.degrees[t]
+        dofs = fixed + (spans[:, None] - p + np.arange(p + 1)[None, :]) * strides[t]
+        N = np.transpose(B, (0, 2, 1))
+        dN = np.transpose(D, (0, 2, 1))[:, :, None, :]
+        wq = w.copy()
+        if flip:
+            N, dN, wq = N[:, ::-1, :], -dN[:, ::-1, :, :], wq[::-1]
+        weight = np.broadcast_to(wq, (len(spans), nq)).copy()
+    else:
+        (s0, B0, D0, w0), (s1, B1, D1, w1) = tabs
+        t0, t1 = tang
+        p0, p1 = patch.degrees[t0], patch.degrees[t1]
+        f0, f1 = np.meshgrid(np.arange(len(s0)), np.arange(len(s1)), indexing="ij")
+        f0, f1 = f0.T.ravel(), f1.T.ravel()          # t0 fastest
+        a0 = np.tile(np.arange(p0 + 1), p1 + 1)
+        a1 = np.repeat(np.arange(p1 + 1), p0 + 1)
+        dofs = (fixed + (s0[f0][:, None] - p0 + a0[None, :]) * strides[t0]
+                + (s1[f1][:, None] - p1 + a1[None, :]) * strides[t1])
+        nf = len(f0)
+        N = np.einsum("fax,fby->fyxba", B0[f0], B1[f1]).reshape(nf, nq * nq, -1)
+        d0 = np.einsum("fax,fby->fyxba", D0[f0], B1[f1]).reshape(nf, nq * nq, -1)
+        d1 = np.einsum("fax,fby->fyxba", B0[f0], D1[f1]).reshape(nf, nq * nq, -1)
+        dN = np.stack([d0, d1], axis=2)
+        weight = np.broadcast_to(np.einsum("y,x->yx", w1, w0).ravel(), (nf, nq * nq)).copy()
+    return (np.ascontiguousarray(dofs, dtype=np.int32), np.ascontiguousarray(N), np.ascontiguousarray(dN),
+            np.ascontiguousarray(weight))

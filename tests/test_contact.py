@@ -1,0 +1,110 @@
+"""Contact integrator: oracle self-checks (CPU) and HIP-vs-oracle parity (GPU).
+
+PARITY UNPINNED for contact: no reference test exercises MortarContact and its closest-point
+query (splinepy) is absent; the oracle follows the reference's arithmetic downstream of an
+analytic rigid body (see oracle/contact_path.c)."""
+import numpy as np
+import pytest
+
+from _cases import synthetic_u
+
+
+def sphere_over_top(P, axis):
+    """rigid sphere R = 0.25 Lx centred 0.9 R above the centre of the top face."""
+    L = P.ctrl.max(axis=0)
+    R = 0.25 * L[0]
+    c = 0.5 * L
+    c[axis] = L[axis] + 0.9 * R
+    return dict(kind="sphere", center=list(c), radius=float(R))
+
+
+CASES = [((6, 3), 2, 1), ((4, 4, 2), 2, 2), ((3, 3, 2), 3, 2), ((4, 3), 3, 1)]
+
+
+@pytest.mark.parametrize("n_el,p,axis", CASES)
+def test_oracle_contact_selfconsistency(n_el, p, axis):
+    from oracle import iga, ref_path as rp
+    P = iga.Patch.block(n_el, p)
+    rowptr, col = P.sparsity()
+    Cn = rp.ContactOracle(P, axis, 1, sphere_over_top(P, axis), penalty=1e4, rowptr=rowptr, col=col)
+    u = synthetic_u(P, scale=0.01)
+    r = np.zeros(P.n_vdofs)
+    Cn.add_boundary_residual(u, r)
+    # area of the (slightly deformed) top face ~ product of the tangential lengths
+    L = P.ctrl.max(axis=0)
+    area0 = np.prod([L[d] for d in range(P.dim) if d != axis])
+    assert abs(Cn.last_area - area0) < 0.05 * area0
+    # penetrating nodes get negative pressure, the contact force pushes the body down (-axis)
+    assert Cn.pressure.min() < 0 and Cn.pressure.max() <= 0
+    assert Cn.last_force[axis] < 0        # fac * n with fac < 0 and n outward (+axis)
+    top = P.boundary_nodes(axis, 1)
+    assert r.reshape(-1, P.dim)[top, axis].sum() > 0   # residual = -traction work: pushes against +axis
+    assert Cn.gap_norm(u) > 0
+    # frozen-pressure tangent: reference FD vs exact
+    A_fd = np.zeros(rowptr[-1])
+    A_ex = np.zeros(rowptr[-1])
+    Cn.add_boundary_residual_and_grad(u, 1.0, np.zeros_like(r), A_fd, rp.TANGENT_FD)
+    Cn.add_boundary_residual_and_grad(u, 1.0, np.zeros_like(r), A_ex, rp.TANGENT_EXACT)
+    assert np.abs(A_ex).max() > 0
+    assert np.abs(A_fd - A_ex).max() < 1e-4 * np.abs(A_ex).max()   # FD round-off (steps |x|*1e-8)
+
+
+def test_oracle_contact_plane_no_contact_is_zero():
+    from oracle import iga, ref_path as rp
+    P = iga.Patch.block((3, 3, 2), 2)
+    body = dict(kind="plane", point=[0, 0, 5.0], normal=[0, 0, -1.0])   # far above, facing down
+    Cn = rp.ContactOracle(P, 2, 1, body)
+    r = np.zeros(P.n_vdofs)
+    Cn.add_boundary_residual(np.zeros(P.n_vdofs), r)
+    assert np.all(r == 0) and np.all(Cn.pressure == 0) and Cn.gap_norm(np.zeros(P.n_vdofs)) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_el,p,axis", CASES)
+@pytest.mark.parametrize("bodykind", ["sphere", "plane"])
+def test_contact_parity_gpu(n_el, p, axis, bodykind):
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, MortarContact, RigidPlane, RigidSphere
+    from oracle import iga, ref_path as rp
+    P = iga.Patch.block(n_el, p)
+    rowptr, col = P.sparsity()
+    if bodykind == "sphere":
+        body = sphere_over_top(P, axis)
+        pbody = RigidSphere(body["center"], body["radius"], 1e4)
+    else:
+        L = P.ctrl.max(axis=0)
+        point = [0.0] * P.dim
+        point[axis] = L[axis] - 0.03
+        normal = [0.0] * P.dim
+        normal[axis] = -1.0
+        body = dict(kind="plane", point=point, normal=normal)
+        pbody = RigidPlane(point, normal, 1e4)
+    Cn = rp.ContactOracle(P, axis, 1, body, penalty=1e4, rowptr=rowptr, col=col)
+    patch = mimi_amd.BSplinePatch.block(n_el, p)
+    pattern = CSRPattern(rowptr.astype(np.int64), col.astype(np.int32), rowptr[-1])
+    G = MortarContact(pbody, "contact", pattern, patch, axis, 1).Prepare()
+    u = synthetic_u(P, scale=0.01)
+    r0 = np.random.default_rng(5).standard_normal(P.n_vdofs)
+    A0 = np.random.default_rng(6).standard_normal(rowptr[-1])
+
+    def rel(a, b):
+        return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+    r_o, r_g = r0.copy(), r0.copy()
+    Cn.add_boundary_residual(u, r_o)
+    G.AddBoundaryResidual(u, r_g)
+    assert np.abs(r_o - r0).max() > 0
+    assert rel(r_g - r0, r_o - r0) < 1e-12
+    assert np.allclose(G.AveragePressure(), Cn.pressure, rtol=1e-12, atol=1e-12)
+    G.BoundaryPostTimeAdvance(u)
+    assert np.isclose(G.last_area_, Cn.last_area, rtol=1e-13)
+    assert np.allclose(G.last_force_, Cn.last_force, rtol=1e-11, atol=1e-12)
+    assert np.isclose(G.last_pressure_, Cn.last_pressure, rtol=1e-11)
+    assert np.isclose(G.GapNorm(u), Cn.gap_norm(u), rtol=1e-12)
+    for mode, tol in ((rp.TANGENT_EXACT, 1e-11), (rp.TANGENT_FD, 1e-4)):
+        G.SetTangentMode(0 if mode == rp.TANGENT_EXACT else 1)
+        r_o, r_g, A_o, A_g = r0.copy(), r0.copy(), A0.copy(), A0.copy()
+        Cn.add_boundary_residual_and_grad(u, 0.6, r_o, A_o, mode)
+        G.AddBoundaryResidualAndGrad(u, 0.6, r_g, A_g)
+        assert rel(r_g - r0, r_o - r0) < 1e-12
+        assert rel(A_g - A0, A_o - A0) < tol
