@@ -8,5 +8,8 @@ from .materials import (CompressibleOgdenNeoHookean, J2, Material, HardeningBase
                         JohnsonCookConstantTemperatureHardening)
 from .splines import BSplinePatch
 from . import integrators
+from .integrators import RigidSphere, RigidPlane
+from .solid import NonlinearSolid, Solid, BoundaryConditions, RuntimeCommunication
 
-__all__ = ["CompressibleOgdenNeoHookean", "J2", "Material", "BSplinePatch", "integrators"]
+__all__ = ["CompressibleOgdenNeoHookean", "J2", "Material", "BSplinePatch", "integrators", "NonlinearSolid",
+           "Solid", "BoundaryConditions", "RuntimeCommunication", "RigidSphere", "RigidPlane"]

@@ -405,6 +405,35 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
       MH_HIP(hipStreamSynchronize(h->stream));
     }
     setup_csr(h.get(), p->csr_rowptr, p->csr_col, true);
+    // lexicographic numbering + the closed-form pattern => CSR positions are arithmetic
+    h->structured_csr = false;
+    if (!p->node_ids && dim == 3 && !(getenv("MIMI_HIP_NO_STRUCTURED") && getenv("MIMI_HIP_NO_STRUCTURED")[0] == '1')) {
+      SparsityDev S{};
+      S.dim = dim;
+      DeviceBuffer<int64_t> prefix[3];
+      for (int d = 0; d < 3; ++d) {
+        S.n[d] = h->n_ctrl[d];
+        S.p[d] = h->degree[d];
+        std::vector<int64_t> pre(S.n[d] + 1, 0);
+        prefix[d].assign(pre.data(), pre.size(), h->stream);  // unused by the check kernel
+        S.prefix[d] = prefix[d].ptr;
+      }
+      DeviceBuffer<int32_t> col_tmp;
+      const int32_t* col_dev = p->csr_col;
+      if (!is_device_pointer(p->csr_col)) {
+        col_tmp.assign(p->csr_col, h->nnz, h->stream);
+        col_dev = col_tmp.ptr;
+      }
+      MH_HIP(hipMemsetAsync(h->status_dev, 0, sizeof(int), h->stream));
+      const int64_t n_rows = h->n_vdofs;
+      hipLaunchKernelGGL(structured_col_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, h->stream, S, n_rows,
+                         h->rowptr, const_cast<int32_t*>(col_dev), 1, h->status_dev);
+      MH_HIP(hipGetLastError());
+      MH_HIP(hipMemcpyAsync(h->status_host, h->status_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      MH_HIP(hipStreamSynchronize(h->stream));
+      h->structured_csr = (*h->status_host == 0);
+      MH_HIP(hipMemsetAsync(h->status_dev, 0, sizeof(int), h->stream));
+    }
     init_state(h.get());
     MH_HIP(hipStreamSynchronize(h->stream));
     *out = h.release();
@@ -545,6 +574,7 @@ int64_t mimi_hip_domain_info(mimi_hip_domain_t h, int what) {
   case 3: return h->nnz;
   case 4: return h->n_vdofs;
   case 5: return h->path;
+  case 6: return h->structured_csr ? 1 : 0;
   default: return -1;
   }
 }

@@ -1,0 +1,429 @@
+"""Host-side callers of the hot path with the reference's Python surface, so that the solver
+calls of the reference's tests / examples run against the HIP integrators:
+
+    nl = mimi_amd.NonlinearSolid(); nl.read_mesh(...); nl.elevate_degrees(2); nl.subdivide(1)
+    nl.set_material(mat); nl.boundary_condition = bc; nl.runtime_communication = rc
+    nl.setup(1); nl.configure_newton("nonlinear_solid", 1e-12, 1e-8, 10, False)
+    nl.time_step_size = 0.05; u = nl.solution_view("displacement", "x"); nl.step_time2()
+
+These layers are CALLERS of the path (out of scope for acceleration); they are
+restated in plain numpy / scipy only as far as the path's tests need them:
+  PySolid / PyNonlinearSolid::Setup        src/mimi/py/py_solid.cpp:9-68, py_nonlinear_solid.cpp:15-387
+  operators::NonlinearSolid                src/mimi/operators/nonlinear_solid.cpp:124-292
+  forms::Nonlinear::AddMult[Grad]          src/mimi/forms/nonlinear.hpp:53-116
+  solvers::LineSearchNewton::Mult          src/mimi/solvers/newton.cpp:10-218
+  solvers::GeneralizedAlpha2               src/mimi/solvers/ode.cpp:5-79
+The linear solves (UMFPack / CG in the reference) use scipy's sparse LU.  The element
+integration itself always goes through libmimi_hip (no CPU fallback).
+
+Differences a user must know: dofs are numbered lexicographically (the reference exposes MFEM's
+NURBS numbering); meshes must be single-patch boxes with unit weights (affine geometry), which
+covers every mesh the reference's solver tests use.
+"""
+import re
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from . import splines
+from .integrators import CSRPattern, MortarContact, NonlinearSolid as NonlinearSolidIntegrator
+from .splines import BSplinePatch
+
+
+# ---- utils/runtime_communication.hpp:48-198 (the keys that reach the path) -----------------
+class RuntimeCommunication:
+    def __init__(self):
+        self.reals, self.ints = {}, {}
+
+    def set_real(self, key, value):
+        self.reals[key] = float(value)
+
+    def set_int(self, key, value):
+        self.ints[key] = int(value)
+
+    def get_real(self, key, default):
+        return self.reals.get(key, default)
+
+    def get_int(self, key, default):
+        return self.ints.get(key, default)
+
+
+# ---- utils/boundary_conditions.hpp: BCMarker / BoundaryConditions ----------------------------
+class BoundaryMarker:
+    def __init__(self):
+        self.dirichlet_, self.body_force_, self.contact_ = [], {}, {}
+
+    def dirichlet(self, bid, dim):
+        self.dirichlet_.append((int(bid), int(dim)))
+        return self
+
+    def body_force(self, dim, value):
+        self.body_force_[int(dim)] = float(value)
+        return self
+
+    def contact(self, bid, nearest_distance_coeff):
+        self.contact_[int(bid)] = nearest_distance_coeff
+        return self
+
+
+class BoundaryConditions:
+    def __init__(self):
+        self.initial = BoundaryMarker()
+        self.current = BoundaryMarker()
+
+
+# ---- mesh: MFEM NURBS mesh v1.0, single box patch ---------------------------------------------
+def _read_mfem_nurbs_box(fname):
+    text = open(fname).read()
+    if not text.lstrip().startswith("MFEM NURBS mesh v1.0"):
+        raise RuntimeError("only 'MFEM NURBS mesh v1.0' files are supported")
+    text = re.sub(r"#.*", "", text)
+    tok = text.split()
+
+    def section(name):
+        return tok.index(name) + 1
+
+    dim = int(tok[section("dimension")])
+    i = section("elements")
+    if int(tok[i]) != 1:
+        raise RuntimeError("only single-patch meshes are supported")
+    i = section("boundary")
+    nb = int(tok[i])
+    i += 1
+    nv_b = 2 if dim == 2 else 4
+    bdr = []
+    for _ in range(nb):
+        attr = int(tok[i])
+        verts = [int(v) for v in tok[i + 2:i + 2 + nv_b]]
+        bdr.append((attr, verts))
+        i += 2 + nv_b
+    i = section("knotvectors")
+    nk = int(tok[i])
+    i += 1
+    knots = []
+    for _ in range(nk):
+        p, n = int(tok[i]), int(tok[i + 1])
+        kv = np.array([float(x) for x in tok[i + 2:i + 2 + n + p + 1]])
+        knots.append((p, kv))
+        i += 2 + n + p + 1
+    nvert = int(tok[section("vertices")])
+    if "weights" in tok:
+        i = section("weights")
+        w = np.array([float(x) for x in tok[i:i + nvert]])
+        if not np.allclose(w, 1.0):
+            raise RuntimeError("rational (weighted) patches are not supported by this reader")
+    i = tok.index("Ordering:") + 2
+    coords = np.array([float(x) for x in tok[i:i + nvert * dim]]).reshape(nvert, dim)
+    if any(p != 1 for p, _ in knots) or nvert != 2 ** dim:
+        raise RuntimeError("this reader expects the degree-1 single-element description the reference's solver tests use")
+    lo, hi = coords.min(axis=0), coords.max(axis=0)
+    corners = np.array(np.meshgrid(*[[lo[d], hi[d]] for d in range(dim)], indexing="ij")).reshape(dim, -1).T
+    if not all(np.any(np.all(np.isclose(c, coords), axis=1)) for c in corners):
+        raise RuntimeError("only axis-aligned box geometries are supported")
+    # boundary attribute -> (axis, side) from the vertices of the boundary element
+    faces = {}
+    for attr, verts in bdr:
+        x = coords[verts]
+        for d in range(dim):
+            if np.allclose(x[:, d], lo[d]):
+                faces[attr] = (d, 0)
+            elif np.allclose(x[:, d], hi[d]):
+                faces[attr] = (d, 1)
+    return dim, lo, hi, faces
+
+
+def _open_knots(n_el, p):
+    return np.concatenate([np.zeros(p), np.arange(n_el + 1) / n_el, np.ones(p)])
+
+
+class Solid:
+    """PySolid (src/mimi/py/py_solid.cpp:9-68): mesh handling."""
+
+    def __init__(self):
+        self._dim = None
+        self.runtime_communication = None
+        self.boundary_condition = None
+        self.time_step_size = 0.0
+        self.current_time = 0.0
+
+    def read_mesh(self, fname):
+        self._dim, self._lo, self._hi, self._faces = _read_mfem_nurbs_box(fname)
+        self._degrees = [1] * self._dim
+        self._n_el = [1] * self._dim
+
+    def elevate_degrees(self, degrees, max_degrees=50):
+        self._degrees = [min(p + int(degrees), max_degrees) for p in self._degrees]   # py_solid.cpp:148-168
+
+    def subdivide(self, n_subdivision):
+        for _ in range(int(n_subdivision)):                                           # py_solid.cpp:170-183
+            self._n_el = [2 * m for m in self._n_el]
+
+    def mesh_dim(self):
+        return self._dim
+
+    def mesh_degrees(self):
+        return list(self._degrees)
+
+    def n_elements(self):
+        return int(np.prod(self._n_el))
+
+    def n_vertices(self):
+        return int(np.prod([m + 1 for m in self._n_el]))
+
+    def n_boundary_elements(self):
+        return int(2 * sum(np.prod([m for k, m in enumerate(self._n_el) if k != d]) for d in range(self._dim)))
+
+    def patch(self):
+        knots = [_open_knots(m, p) for m, p in zip(self._n_el, self._degrees)]
+        grev = []
+        for d, (k, p) in enumerate(zip(knots, self._degrees)):
+            n = len(k) - p - 1
+            g = np.array([k[i + 1:i + p + 1].sum() / p for i in range(n)])
+            grev.append(self._lo[d] + (self._hi[d] - self._lo[d]) * g)
+        dim = self._dim
+        pts = np.zeros([len(g) for g in grev][::-1] + [dim])
+        for d in range(dim):
+            shape = [1] * dim
+            shape[dim - 1 - d] = -1
+            pts[..., d] = grev[d].reshape(shape)
+        return BSplinePatch(self._degrees, knots, pts.reshape(-1, dim))
+
+
+def _element_tables(patch, quadrature_order=-1):
+    """N[e,q,a] and w*det[e,q] for the mass matrix / body force (affine geometry)."""
+    dim = patch.dim
+    pmax = max(patch.degrees)
+    order = 2 * pmax + 3 if quadrature_order < 0 else quadrature_order
+    nq = order // 2 + 1
+    tabs = [splines._tables_1d(patch.knots[d], patch.degrees[d], nq) for d in range(dim)]
+    m = [len(t[0]) for t in tabs]
+    e = np.arange(int(np.prod(m)))
+    em = []
+    for s in m:
+        em.append(e % s)
+        e = e // s
+    if dim == 2:
+        N = np.einsum("eax,eby->eyxba", tabs[0][1][em[0]], tabs[1][1][em[1]])
+        w = np.einsum("y,x->yx", tabs[1][3], tabs[0][3]).ravel()
+    else:
+        N = np.einsum("eax,eby,ecz->ezyxcba", tabs[0][1][em[0]], tabs[1][1][em[1]], tabs[2][1][em[2]])
+        w = np.einsum("z,y,x->zyx", tabs[2][3], tabs[1][3], tabs[0][3]).ravel()
+    ne = len(em[0])
+    N = N.reshape(ne, w.size, -1)
+    # affine box: det = prod(span length * physical length)
+    det = np.ones(ne)
+    ext = patch.control_points.max(axis=0) - patch.control_points.min(axis=0)
+    for d in range(dim):
+        k, p = patch.knots[d], patch.degrees[d]
+        spans = tabs[d][0]
+        det *= (k[spans + 1] - k[spans])[em[d]] * ext[d]
+    # connectivity
+    conn = np.zeros((ne, N.shape[2]), dtype=np.int64)
+    a = np.arange(N.shape[2])
+    stride = 1
+    for d in range(dim):
+        ad = (a // int(np.prod([pp + 1 for pp in patch.degrees[:d]]))) % (patch.degrees[d] + 1)
+        conn += ((tabs[d][0][em[d]] - patch.degrees[d])[:, None] + ad[None, :]) * stride
+        stride *= patch.n_ctrl[d]
+    return N, w[None, :] * det[:, None], conn
+
+
+class NonlinearSolid(Solid):
+    """PyNonlinearSolid (src/mimi/py/py_nonlinear_solid.cpp:15-387) on top of the HIP integrators."""
+
+    def __init__(self, device=0):
+        super().__init__()
+        self.material = None
+        self.device = device
+        self._newton = dict(rel_tol=1e-8, abs_tol=1e-12, max_iter=None, iterative_mode=False)
+        self.tangent_mode = 0
+        self.newton_history = []
+
+    def set_material(self, material):
+        self.material = material
+
+    # -- Setup (py_nonlinear_solid.cpp:15-387) -------------------------------------------------
+    def setup(self, nthreads=-1):
+        dim = self._dim
+        self.patch_ = patch = self.patch()
+        n = patch.n_vdofs
+        self.pattern_ = CSRPattern.of_bspline_patch(patch, device=self.device)
+        rowptr, col = self.pattern_.rowptr, self.pattern_.col
+        self.x = np.zeros(n)        # displacement (py_nonlinear_solid.cpp:119)
+        self.x_dot = np.zeros(n)
+        rc = self.runtime_communication or RuntimeCommunication()
+        bc = self.boundary_condition or BoundaryConditions()
+        # Dirichlet dofs (FindBoundaryDofIds, py_solid.cpp:185-235): bid -> attribute bid+1
+        dofs = []
+        for bid, comp in bc.initial.dirichlet_:
+            axis, side = self._faces[bid + 1]
+            dofs.append(patch.boundary_nodes(axis, side) * dim + comp)
+        self.dirichlet_ = np.unique(np.concatenate(dofs)) if dofs else np.zeros(0, dtype=np.int64)
+        # mass (VectorMassIntegrator(rho), FormSystemMatrix(zero_dofs); :155-173) and rhs (:221-283)
+        N, wd, conn = _element_tables(patch)
+        Me = self.material.density * np.einsum("eq,eqa,eqb->eab", wd, N, N)
+        keys = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr)) * n + col
+        mass = np.zeros(len(col))
+        for c in range(dim):
+            r = conn * dim + c
+            pos = np.searchsorted(keys, (r[:, :, None] * n + r[:, None, :]).ravel())
+            np.add.at(mass, pos, Me.ravel())
+        self.mass_ = mass
+        _eliminate_row_col(rowptr, col, self.mass_, self.dirichlet_)
+        rhs = np.zeros(n)
+        fe = np.einsum("eq,eqa->ea", wd, N)
+        for comp, value in bc.initial.body_force_.items():
+            np.add.at(rhs, (conn * dim + comp).ravel(), (fe * value).ravel())
+        rhs[self.dirichlet_] = 0.0
+        self.rhs_ = rhs
+        # integrators (py_nonlinear_solid.cpp:197-218, 286-326)
+        q_order = rc.get_int("nonlinear_solid_quadrature_order", -1)
+        self.domain_ = NonlinearSolidIntegrator("nonlinear_solid", self.material, self.pattern_, patch=patch,
+                                                device=self.device, quadrature_order=q_order).Prepare()
+        self.domain_.SetTangentMode(self.tangent_mode)
+        self.contacts_ = []
+        for bid, body in bc.current.contact_.items():
+            axis, side = self._faces[bid + 1]
+            self.contacts_.append(MortarContact(body, "contact", self.pattern_, patch, axis, side, device=self.device,
+                                                quadrature_order=rc.get_int("contact_quadrature_order", -1)).Prepare())
+        if self._newton["max_iter"] is None:
+            self._newton["max_iter"] = 10 * dim                                       # :346-361
+        rho_inf = min(max(rc.get_real("ode_coefficient", 0.25), 0.0), 1.0)            # :367-370
+        am = (2.0 - rho_inf) / (1.0 + rho_inf)
+        af = 1.0 / (1.0 + rho_inf)
+        beta = 0.25 * (1.0 + am - af) ** 2
+        gamma = 0.5 + am - af
+        self._fac = (0.5 - beta / am, af, af * (1.0 - gamma / am), beta * af / am, gamma * af / am, am)  # ode.cpp:5-14
+        self._nstate = 0
+        self._jac = np.zeros_like(self.mass_)
+
+    def configure_newton(self, name, rel_tol, abs_tol, max_iter, iterative_mode):   # py_solid.cpp:334-346
+        self._newton = dict(rel_tol=rel_tol, abs_tol=abs_tol, max_iter=int(max_iter), iterative_mode=bool(iterative_mode))
+
+    def solution_view(self, fe_space, component):
+        return {"x": self.x, "x_dot": self.x_dot}[component]
+
+    # -- operators::NonlinearSolid ----------------------------------------------------------------
+    def _csr(self, vals):
+        n = len(self.x)
+        return sp.csr_matrix((vals, self.pattern_.col, self.pattern_.rowptr), shape=(n, n))
+
+    def _push(self, integ):
+        integ.dt_, integ.first_effective_dt_, integ.second_effective_dt_ = self.time_step_size, self._fac0, self._fac1
+
+    def _add_mult(self, xt, y):                       # forms/nonlinear.hpp:53-81
+        self._push(self.domain_)
+        self.domain_.AddDomainResidual(xt, y)
+        for c in self.contacts_:
+            c.AddBoundaryResidual(xt, y)
+        y[self.dirichlet_] = 0.0
+
+    def _mult(self, a):                               # operators/nonlinear_solid.cpp:172-205
+        xt = self._xa + self._fac0 * a
+        y = self._csr(self.mass_) @ a
+        self._add_mult(xt, y)
+        y -= self.rhs_
+        y[self.dirichlet_] = 0.0
+        return y
+
+    def _residual_and_grad(self, a):                  # operators/nonlinear_solid.cpp:240-283
+        xt = self._xa + self._fac0 * a
+        y = self._csr(self.mass_) @ a
+        self._jac[:] = self.mass_
+        self._push(self.domain_)
+        self.domain_.AddDomainResidualAndGrad(xt, self._fac0, y, self._jac)
+        for c in self.contacts_:
+            c.AddBoundaryResidualAndGrad(xt, self._fac0, y, self._jac)
+        y[self.dirichlet_] = 0.0
+        _eliminate_row_col(self.pattern_.rowptr, self.pattern_.col, self._jac, self.dirichlet_)
+        y -= self.rhs_
+        y[self.dirichlet_] = 0.0
+        return y, self._jac
+
+    def _newton_solve(self, x0):                      # solvers/newton.cpp:10-218
+        o = self._newton
+        x = x0.copy() if o["iterative_mode"] else np.zeros_like(x0)
+        improved, i_improved = [True] * 5, 0
+        best_res, best_x = np.finfo(float).max, x.copy()
+        r, J = self._residual_and_grad(x)
+        norm0 = norm = np.linalg.norm(r)
+        goal = max(o["rel_tol"] * norm, o["abs_tol"])
+        it, converged = 0, False
+        while True:
+            if norm <= goal:
+                converged = True
+                break
+            if it >= o["max_iter"]:
+                if it != 0:
+                    x = best_x.copy()
+                break
+            if not any(improved):
+                x = best_x.copy()
+                break
+            c = spla.splu(self._csr(J).tocsc()).solve(r)
+            q1 = norm
+            q3 = np.linalg.norm(self._mult(x - c))
+            q2 = np.linalg.norm(self._mult(x - 0.5 * c))
+            den = q1 - 2.0 * q2 + q3
+            eps = (3.0 * q1 - 4.0 * q2 + q3) / (4.0 * den) if den != 0 else np.inf
+            scale = eps if (den > 0 and 0 < eps < 1) else (1.0 if q3 < q1 else 0.05)
+            if abs(scale) < 1e-12:
+                break
+            x = x - scale * c
+            if it == o["max_iter"] - 1:
+                r = self._mult(x)
+            else:
+                r, J = self._residual_and_grad(x)
+            norm = np.linalg.norm(r)
+            if norm < best_res:
+                best_x, best_res = x.copy(), norm
+                improved[i_improved % 5] = True
+            else:
+                improved[i_improved % 5] = False
+            i_improved += 1
+            it += 1
+        self.newton_history.append(dict(converged=converged, iterations=it, norm=norm, norm0=norm0))
+        return x
+
+    # -- GeneralizedAlpha2::StepTime2 (solvers/ode.cpp:16-79) -------------------------------------
+    def step_time2(self):
+        dt = self.time_step_size
+        f0, f1, f2, f3, f4, f5 = self._fac
+        x, v = self.x, self.x_dot
+        self._fac0, self._fac1 = f3 * dt * dt, f4 * dt
+        if self._nstate == 0:
+            z = np.zeros_like(x)                       # operators/nonlinear_solid.cpp:124-156
+            self._add_mult(x, z)
+            z = -z + self.rhs_
+            self._a = spla.splu(self._csr(self.mass_).tocsc()).solve(z)
+            self._aa = np.zeros_like(x)
+            self._nstate = 1
+        a = self._a
+        self._xa = x + (v + f0 * dt * a) * (f1 * dt)
+        va = v + f2 * dt * a
+        self._aa = self._newton_solve(self._aa)
+        aa = self._aa
+        xa = self._xa + self._fac0 * aa
+        va = va + self._fac1 * aa
+        prev = 1.0 - 1.0 / f1
+        x[:] = x * prev + xa / f1
+        v[:] = v * prev + va / f1
+        self._a = a * prev + aa / f5
+        # PostTimeAdvance (operators/nonlinear_solid.cpp:285-292)
+        self._push(self.domain_)
+        self.domain_.DomainPostTimeAdvance(x)
+        for c in self.contacts_:
+            c.BoundaryPostTimeAdvance(x)
+        self.current_time += dt
+
+
+def _eliminate_row_col(rowptr, col, vals, dofs):
+    """SparseMatrix::EliminateRowCol(rc, DIAG_ONE) for each rc (forms/nonlinear.hpp:112-115)."""
+    n = len(rowptr) - 1
+    mask = np.zeros(n, dtype=bool)
+    mask[dofs] = True
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    kill = mask[rows] | mask[col]
+    vals[kill] = 0.0
+    vals[kill & (rows == col) & mask[rows]] = 1.0

@@ -1,0 +1,152 @@
+"""The reference's own solver test (tests/test_nonlinear_solid.py:55-98 in j042/mimi), run
+against the HIP integrators through the mimi_amd facade: 10 implicit generalized-alpha steps of
+the 2-D p=3 2x2-element beam, displacement compared with the reference's golden files after
+every step with the reference's criterion (np.allclose defaults) -- and a tighter 1e-8.
+
+Dof order: the golden files are in MFEM's NURBS numbering, the facade numbers lexicographically;
+the permutation is `oracle.harness.GOLDEN_NODE_ORDER_5x5`."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MESH = os.path.join(HERE, "golden", "meshes", "balken.mesh")
+
+
+def balken(subd, order):
+    import mimi_amd as mimi
+    nl = mimi.NonlinearSolid()
+    nl.read_mesh(MESH)
+    if order > 0:
+        nl.elevate_degrees(order)
+    if subd > 0:
+        nl.subdivide(subd)
+    return nl
+
+
+def balken_plasticity(subd, order, mat):
+    import mimi_amd as mimi
+    nl = balken(subd, order)
+    mat.density = 1
+    mat.viscosity = -1
+    mat.melting_temperature = 1500
+    mat.initial_temperature = 20
+    mat.specific_heat = 450
+    mat.heat_fraction = 0.9
+    mat.set_young_poisson(2100, 0.3)
+    mat.hardening = mimi.JohnsonCookTemperatureAndRateDependentHardening()
+    mat.hardening.A = 70
+    mat.hardening.B = 140
+    mat.hardening.n = 0.2835
+    mat.hardening.m = 1.3558
+    mat.hardening.eps0_dot = 0.004
+    mat.hardening.reference_temperature = 20
+    nl.set_material(mat)
+    rc = mimi.RuntimeCommunication()
+    rc.set_real("ode_coefficient", 0.5)
+    nl.runtime_communication = rc
+    bc = mimi.BoundaryConditions()
+    bc.initial.dirichlet(2, 0).dirichlet(2, 1)
+    bc.initial.body_force(1, -3)
+    nl.boundary_condition = bc
+    return nl
+
+
+def test_mesh_counts_cpu():
+    """reference tests/test_mesh_refinement.py: counts after read / subdivide / elevate."""
+    import mimi_amd as mimi
+    s = mimi.Solid()
+    s.read_mesh(MESH)
+    assert (s.mesh_dim(), s.n_elements(), s.n_vertices(), s.mesh_degrees()) == (2, 1, 4, [1, 1])
+    s.elevate_degrees(2)
+    s.subdivide(1)
+    assert (s.n_elements(), s.n_vertices(), s.mesh_degrees(), s.n_boundary_elements()) == (4, 9, [3, 3], 8)
+    p = s.patch()
+    assert p.n_ctrl == [5, 5] and np.allclose(p.control_points.max(axis=0), [5.0, 1.0])
+    c = mimi.Solid()
+    c.read_mesh(os.path.join(HERE, "golden", "meshes", "cube-nurbs.mesh"))
+    c.subdivide(2)
+    assert (c.mesh_dim(), c.n_elements(), c.n_vertices()) == (3, 64, 125)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tangent_mode", [0, 1], ids=["analytic", "referenceFD"])
+def test_nonlinear_solid_neohook(golden_dir, tangent_mode):
+    import mimi_amd as mimi
+    from oracle import harness as hz
+    nl = balken(1, 2)
+    mat = mimi.CompressibleOgdenNeoHookean()
+    mat.density = 1
+    mat.viscosity = -1
+    mat.set_young_poisson(2100, 0.3)
+    nl.set_material(mat)
+    rc = mimi.RuntimeCommunication()
+    rc.set_real("ode_coefficient", 0.5)
+    nl.runtime_communication = rc
+    bc = mimi.BoundaryConditions()
+    bc.initial.dirichlet(2, 0).dirichlet(2, 1)
+    bc.initial.body_force(1, -5)
+    nl.boundary_condition = bc
+    nl.tangent_mode = tangent_mode
+    nl.setup(1)
+    nl.configure_newton("nonlinear_solid", 1e-12, 1e-8, 10, False)
+    nl.time_step_size = 0.05
+    u = nl.solution_view("displacement", "x").ravel()
+    for i in range(10):
+        nl.step_time2()
+        ref = hz.golden_to_lexicographic(np.genfromtxt(os.path.join(golden_dir, "ref", "neohook_h1_p2", f"x_{i}.txt")))
+        assert np.allclose(u, ref)
+        assert np.abs(u - ref).max() < 1e-8, (i, np.abs(u - ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tangent_mode", [0, 1], ids=["analytic", "referenceFD"])
+def test_nonlinear_solid_j2(golden_dir, tangent_mode):
+    import mimi_amd as mimi
+    from oracle import harness as hz
+    nl = balken_plasticity(1, 2, mimi.J2())
+    nl.tangent_mode = tangent_mode
+    nl.setup(1)
+    nl.configure_newton("nonlinear_solid", 1e-12, 1e-8, 10, False)
+    nl.time_step_size = 0.5
+    u = nl.solution_view("displacement", "x").ravel()
+    for i in range(10):
+        nl.step_time2()
+        ref = hz.golden_to_lexicographic(np.genfromtxt(os.path.join(golden_dir, "ref", "j2_h1_p2", f"x_{i}.txt")))
+        assert np.allclose(u, ref)
+        assert np.abs(u - ref).max() < 1e-8, (i, np.abs(u - ref).max())
+    assert nl.domain_.State("accumulated_plastic_strain").max() > 0.05
+
+
+@pytest.mark.gpu
+def test_3d_cantilever_runs_through_tensor_kernels():
+    """cfg1-like plumbing: 3-D p=2 block from cube-nurbs.mesh, one implicit step converges and
+    agrees with the same step taken with the reference-FD tangent."""
+    import mimi_amd as mimi
+    sols = []
+    for mode in (0, 1):
+        nl = mimi.NonlinearSolid()
+        nl.read_mesh(os.path.join(HERE, "golden", "meshes", "cube-nurbs.mesh"))
+        nl.elevate_degrees(1)
+        nl.subdivide(1)
+        mat = mimi.CompressibleOgdenNeoHookean()
+        mat.density = 1
+        mat.set_young_poisson(2100, 0.3)
+        nl.set_material(mat)
+        bc = mimi.BoundaryConditions()
+        bid = [a - 1 for a, f in nl._faces.items() if f == (0, 0)][0]
+        bc.initial.dirichlet(bid, 0).dirichlet(bid, 1).dirichlet(bid, 2)
+        bc.initial.body_force(2, -20)
+        nl.boundary_condition = bc
+        nl.tangent_mode = mode
+        nl.setup(1)
+        assert nl.domain_.path_ == 1
+        nl.configure_newton("nonlinear_solid", 1e-12, 1e-9, 20, False)
+        nl.time_step_size = 0.05
+        for _ in range(2):
+            nl.step_time2()
+        assert nl.newton_history[-1]["converged"]
+        sols.append(nl.solution_view("displacement", "x").copy())
+    assert np.abs(sols[0]).max() > 1e-4
+    assert np.allclose(sols[0], sols[1], rtol=1e-6, atol=1e-9)
