@@ -8,6 +8,8 @@
 #include "kernels_general.hpp"
 #include "kernels_setup.hpp"
 #include "kernels_tensor.hpp"
+#include "kernels_tensor_mfma.hpp"
+#include "kernels_tensor_2phase.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -347,6 +349,9 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
       h->first_off[d] = first.size();
       first.insert(first.end(), t1[d].first.begin(), t1[d].first.end());
     }
+    h->first_is_identity = true;
+    for (int d = 0; d < dim; ++d)
+      for (int k = 0; k < (int)t1[d].first.size(); ++k) h->first_is_identity = h->first_is_identity && (t1[d].first[k] == k);
     h->tab1d.assign(tab.data(), tab.size(), h->stream);
     h->first1d.assign(first.data(), first.size(), h->stream);
     DeviceBuffer<double> ctrl;

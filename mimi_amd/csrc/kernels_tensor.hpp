@@ -43,6 +43,9 @@ struct TensorArgs {
   const double* geo;            // [n_el][10][NQ^3]
   const int32_t* dofs;          // [n_el][NB^3]
   const int32_t* pair_pos;      // [n_el][NB^3][NB^3]
+  int structured;               // CSR positions computable arithmetically (lexicographic patch)
+  int n_ctrl[3];                // control points per direction
+  const int32_t* first[3];      // [n_spans] first basis index of a span
   const int64_t* rowptr;
   const double* u;
   double* r;
@@ -52,6 +55,8 @@ struct TensorArgs {
   StateView state;
   int* status;
   unsigned long long* prof;  // diagnostic build only (MH_PROFILE): per-stage cycle sums
+  double* scratch_k;         // two-phase path: [n_el][3][27*81] element row pieces
+  double* scratch_r;         // two-phase path: [n_el][3][27] element residual pieces
 };
 
 // wave-private LDS carve, in doubles
@@ -734,6 +739,11 @@ inline TensorArgs tensor_args(mimi_hip_domain_s* h, const double* u, double* r, 
   a.geo = h->geo.ptr;
   a.dofs = h->dofs.ptr;
   a.pair_pos = h->pair_pos.ptr;
+  a.structured = h->structured_csr ? 1 : 0;
+  for (int d = 0; d < 3; ++d) {
+    a.n_ctrl[d] = h->n_ctrl[d];
+    a.first[d] = h->first1d.ptr + h->first_off[d];
+  }
   a.rowptr = h->rowptr;
   a.u = u;
   a.r = r;
@@ -767,9 +777,22 @@ inline void launch_tensor_p(mimi_hip_domain_s* h, int grad, TensorArgs a) {
     }
 }
 
+inline void launch_tensor_mfma(mimi_hip_domain_s* h, int grad, TensorArgs a);  // kernels_tensor_mfma.hpp
+inline bool two_phase_supported(const mimi_hip_domain_s* h);                     // kernels_tensor_2phase.hpp
+inline void launch_tensor_two_phase(mimi_hip_domain_s* h, TensorArgs a);
+
 inline void launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, double* r, double* A, double gf) {
   TensorArgs a = tensor_args(h, u, r, A, gf);
-  launch_tensor_p<2>(h, grad, a);
+  // MIMI_HIP_TENSOR_VARIANT: "2phase" (default when supported), "mfma", "valu"
+  static const char* variant = getenv("MIMI_HIP_TENSOR_VARIANT");
+  const bool want_valu = variant && variant[0] == 'v';
+  const bool want_mfma = variant && variant[0] == 'm';
+  if (grad && !want_valu && !want_mfma && two_phase_supported(h))
+    launch_tensor_two_phase(h, a);
+  else if (grad && want_mfma)
+    launch_tensor_mfma(h, grad, a);
+  else
+    launch_tensor_p<2>(h, grad, a);
 }
 
 inline void launch_tensor_post(mimi_hip_domain_s* h, const double* u) {

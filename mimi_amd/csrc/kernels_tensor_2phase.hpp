@@ -1,0 +1,456 @@
+// Two-phase tangent assembly for structured p = 2 patches (the benchmarked path).
+//
+// Why two phases: with colour-partitioned read-modify-write inside the integration kernel the
+// wave is bound by its CU's outstanding-request capacity -- every (element, i) touches 243 CSR row
+// segments of 72 B, i.e. partial cache lines, both ways (profiles/r01_*: 58 % of a wave's time in
+// the flush, or the same time in issuing the prefetch).  So the integration kernel now only
+// STORES: its 27 row pieces per (element, i) go, coalesced, to a dense scratch, and a second
+// kernel that owns CSR rows gathers them and does ONE coalesced read-modify-write per row.
+//
+//   phase 1  tensor_p1_kernel: stage 0 / A / R and the MFMA contraction stage of
+//            kernels_tensor_mfma.hpp; no loads of A or r, no colouring (one launch), no
+//            atomics.  Entries shared with the next element of the walked column are carried in
+//            the wave's LDS tile, so each (node pair, element column) is stored exactly once,
+//            by the highest element of the column that contains both nodes.
+//   phase 2  tensor_p2_kernel: one wave per CSR node row block (3 rows); a lane owns row entries
+//            and sums the <= 9 stored pieces (one per element column), in a fixed order, then
+//            A[row] += grad_factor * sum, r += sum of element residual pieces.
+// Results are bitwise reproducible; nothing is atomic.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kernels_tensor_mfma.hpp"
+
+namespace mimi_hip {
+
+template<int I>
+MH_DEV void tensor_p1_body(const TensorArgs& p, double* lds, int eu, int ev, int& status) {
+  using L = MfmaLds;
+  constexpr int P = 2, NB = 3, NQ = 4, NB2 = 9, ND = 27, NQ3 = 64, NROW = 81;
+  constexpr int TROUNDS = 2;  // 72 table values
+  const int lane = threadIdx.x & 63;
+  double* ue = lds + L::off_ue;
+  double* tab = lds + L::off_tab;
+  double* RS = lds + L::off_r;
+  double* KS = lds + L::off_ks;
+  const bool use_carry = p.seq_axis == 2;
+#ifdef MH_PROFILE
+  unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last)::"memory");
+#endif
+
+  const int n_seq = p.seq_axis == 0 ? p.box_n[0] : (p.seq_axis == 1 ? p.box_n[1] : p.box_n[2]);
+  auto element_of = [&](int es, int* el) -> int64_t {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) el[d] = (d == p.seq_axis) ? es : (d == p.u_axis ? eu : ev);
+    return el[0] + (int64_t)p.box_n[0] * (el[1] + (int64_t)p.box_n[1] * el[2]);
+  };
+  auto table_src = [&](const int* el, int t) -> const double* {
+    const int dir = t / (2 * NB * NQ);
+    const int rem = t % (2 * NB * NQ);
+    const int isD = rem / (NB * NQ);
+    const int k = rem % (NB * NQ);
+    const int span = (dir == 0 ? p.box_begin[0] + el[0] : dir == 1 ? p.box_begin[1] + el[1] : p.box_begin[2] + el[2]);
+    return (isD ? (dir == 0 ? p.tabD[0] : dir == 1 ? p.tabD[1] : p.tabD[2])
+                : (dir == 0 ? p.tabB[0] : dir == 1 ? p.tabB[1] : p.tabB[2])) + (int64_t)span * NB * NQ + k;
+  };
+
+  // lane constants of the matrix stages
+  const int mrow = lane & 15, mk = lane >> 4;
+  const bool mrow_ok = mrow < NB2;
+  const int mra = mrow_ok ? mrow / NB : 0, mrb = mrow_ok ? mrow % NB : 0;
+  const int idx1 = 4 * ((lane & 3) + 4 * (lane >> 4) + 16 * ((lane >> 2) & 3));
+  const int idx2 = 4 * ((lane >> 4) + 4 * (lane & 3) + 16 * ((lane >> 2) & 3));
+
+  for (int k = lane; k < ND * NROW; k += 64) KS[k] = 0.0;
+
+  // ---- pipeline prologue ------------------------------------------------------------------------
+  int el_c[3], el_n[3];
+  int64_t e_cur = element_of(0, el_c);
+  int32_t node_c = lane < ND ? p.dofs[e_cur * ND + lane] : 0, node_n = 0;
+  double ue_r[3];
+  double tab_r[TROUNDS];
+  double geo_r[10];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ue_r[c] = p.u[(int64_t)node_c * 3 + c];
+#pragma unroll
+  for (int rd = 0; rd < TROUNDS; ++rd) {
+    const int t = rd * 64 + lane;
+    tab_r[rd] = *table_src(el_c, t < 6 * NB * NQ ? t : 0);
+  }
+  {
+    const double* g = p.geo + e_cur * 10 * NQ3 + lane;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) geo_r[k] = g[(int64_t)k * NQ3];
+  }
+  if (n_seq > 1) {
+    const int64_t e1 = element_of(1, el_n);
+    node_n = lane < ND ? p.dofs[e1 * ND + lane] : 0;
+  }
+
+  for (int es = 0; es < n_seq; ++es) {
+    MH_STAMP(0);
+    // ---- stage 0: registers -> LDS, then issue the loads of the NEXT element -------------------
+    if (lane < ND) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ue[c * ND + lane] = ue_r[c];
+    }
+#pragma unroll
+    for (int rd = 0; rd < TROUNDS; ++rd) {
+      const int t = rd * 64 + lane;
+      if (t < 6 * NB * NQ) tab[t] = tab_r[rd];
+    }
+    double Ji[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ji[k] = geo_r[k];
+    const double wd = geo_r[9];
+    const int64_t e = e_cur;
+    int el_w[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) el_w[d] = el_c[d];
+    if (es + 1 < n_seq) {
+      e_cur = element_of(es + 1, el_c);
+      node_c = node_n;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ue_r[c] = p.u[(int64_t)node_c * 3 + c];
+    #pragma unroll
+      for (int rd = 0; rd < TROUNDS; ++rd) {
+        const int t = rd * 64 + lane;
+        tab_r[rd] = *table_src(el_c, t < 6 * NB * NQ ? t : 0);
+      }
+      const double* g = p.geo + e_cur * 10 * NQ3 + lane;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) geo_r[k] = g[(int64_t)k * NQ3];
+      if (es + 2 < n_seq) {
+        const int64_t e2 = element_of(es + 2, el_n);
+        node_n = lane < ND ? p.dofs[e2 * ND + lane] : 0;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    constexpr int NK = ND * NROW;   // 2187 slots
+    const bool last = es + 1 >= n_seq;
+
+    MH_STAMP(1);
+    // ---- stage A: constitutive update, lane = quadrature point q = q0 + 4 q1 + 16 q2 -------------
+    double Ahat[27];  // [(m*3 + j)*3 + n] for row I
+    double Phat[3];
+    {
+      const int q0 = lane & 3, q1 = (lane >> 2) & 3, q2 = lane >> 4;
+      double b0[NB], d0[NB], b1[NB], d1[NB], b2[NB], d2[NB];
+#pragma unroll
+      for (int a = 0; a < NB; ++a) {
+        b0[a] = tab_ptr<P>(tab, 0, 0)[a * NQ + q0];
+        d0[a] = tab_ptr<P>(tab, 0, 1)[a * NQ + q0];
+        b1[a] = tab_ptr<P>(tab, 1, 0)[a * NQ + q1];
+        d1[a] = tab_ptr<P>(tab, 1, 1)[a * NQ + q1];
+        b2[a] = tab_ptr<P>(tab, 2, 0)[a * NQ + q2];
+        d2[a] = tab_ptr<P>(tab, 2, 1)[a * NQ + q2];
+      }
+      double H[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) H[k] = 0.0;
+#pragma unroll
+      for (int a2 = 0; a2 < NB; ++a2)
+#pragma unroll
+        for (int a1 = 0; a1 < NB; ++a1) {
+          const double tbb = b1[a1] * b2[a2], tdb = d1[a1] * b2[a2], tbd = b1[a1] * d2[a2];
+#pragma unroll
+          for (int a0 = 0; a0 < NB; ++a0) {
+            const int a = a0 + NB * (a1 + NB * a2);
+            const double dn0 = d0[a0] * tbb, dn1 = b0[a0] * tdb, dn2 = b0[a0] * tbd;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              const double uu = ue[i * ND + a];
+              H[i * 3 + 0] += uu * dn0;
+              H[i * 3 + 1] += uu * dn1;
+              H[i * 3 + 2] += uu * dn2;
+            }
+          }
+        }
+      double F[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int J = 0; J < 3; ++J) {
+          double sf = (i == J) ? 1.0 : 0.0;
+#pragma unroll
+          for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * Ji[m * 3 + J];
+          F[i + J * 3] = sf;
+        }
+      PointResult<3> w;
+      status |= evaluate_pk1<3>(p.mat, p.dt, p.state, e * NQ3 + lane, F, w);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        double sp = 0.0;
+#pragma unroll
+        for (int J = 0; J < 3; ++J) sp += w.P[I + J * 3] * Ji[m * 3 + J];
+        Phat[m] = wd * sp;
+      }
+      double A[27];
+      tangent_row_of<3, I>(p.mat.m, w, A);
+      double T[27];
+#pragma unroll
+      for (int J = 0; J < 3; ++J)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) {
+            double st = 0.0;
+#pragma unroll
+            for (int Lx = 0; Lx < 3; ++Lx) st += A[(J * 3 + j) * 3 + Lx] * Ji[n * 3 + Lx];
+            T[(J * 3 + j) * 3 + n] = st;
+          }
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) {
+            double sa = 0.0;
+#pragma unroll
+            for (int J = 0; J < 3; ++J) sa += Ji[m * 3 + J] * T[(J * 3 + j) * 3 + n];
+            Ahat[(m * 3 + j) * 3 + n] = wd * sa;
+          }
+    }
+
+    MH_STAMP(2);
+    // ---- stage R: residual row I by sum factorisation ---------------------------------------------
+    {
+      double* PH = RS;                   // [3 m][64]
+      double* V = PH + 3 * NQ3;          // [3 m][3 a2][16]
+      double* W = V + 3 * NB * NQ * NQ;  // [3 m][9 a1a2][4]
+#pragma unroll
+      for (int m = 0; m < 3; ++m) PH[m * NQ3 + lane] = Phat[m];
+      __builtin_amdgcn_wave_barrier();
+      if (lane < NB * NQ * NQ) {
+        const int q01 = lane % (NQ * NQ), a2 = lane / (NQ * NQ);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const double* T2 = tab_ptr<P>(tab, 2, m == 2 ? 1 : 0) + a2 * NQ;
+          double sv = 0.0;
+#pragma unroll
+          for (int q2 = 0; q2 < NQ; ++q2) sv += T2[q2] * PH[m * NQ3 + q01 + NQ * NQ * q2];
+          V[(m * NB + a2) * NQ * NQ + q01] = sv;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < NB2 * NQ) {
+        const int q0 = lane % NQ, a12 = lane / NQ, a1 = a12 % NB, a2 = a12 / NB;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const double* T1 = tab_ptr<P>(tab, 1, m == 1 ? 1 : 0) + a1 * NQ;
+          double sw = 0.0;
+#pragma unroll
+          for (int q1 = 0; q1 < NQ; ++q1) sw += T1[q1] * V[(m * NB + a2) * NQ * NQ + q0 + NQ * q1];
+          W[(m * NB2 + a12) * NQ + q0] = sw;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < ND) {
+        const int a0 = lane % NB, a12 = lane / NB;
+        double sr = 0.0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const double* T0 = tab_ptr<P>(tab, 0, m == 0 ? 1 : 0) + a0 * NQ;
+#pragma unroll
+          for (int q0 = 0; q0 < NQ; ++q0) sr += T0[q0] * W[(m * NB2 + a12) * NQ + q0];
+        }
+        p.scratch_r[(e * 3 + I) * ND + lane] = sr;
+      }
+    }
+
+    MH_STAMP(3);
+    // ---- stage C on the matrix pipe ----------------------------------------------------------------
+    // A operands: pair tables of the three directions, lane = (row = pair index, k = quadrature index)
+    double aS[3][4];  // [dir][variant]: 0 B.B, 1 D(a).B(b), 2 B(a).D(b), 3 D.D
+#pragma unroll
+    for (int dir = 0; dir < 3; ++dir) {
+      const double Ba = tab_ptr<P>(tab, dir, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, dir, 1)[mra * NQ + mk];
+      const double Bb = tab_ptr<P>(tab, dir, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, dir, 1)[mrb * NQ + mk];
+      aS[dir][0] = mrow_ok ? Ba * Bb : 0.0;
+      aS[dir][1] = mrow_ok ? Da * Bb : 0.0;
+      aS[dir][2] = mrow_ok ? Ba * Db : 0.0;
+      aS[dir][3] = mrow_ok ? Da * Db : 0.0;
+    }
+    const mh_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      mh_d4 Z[4][3];  // [g][r]: rows a1b1 = (lane>>4) + 4 r2, cols (q0, a2b2 & 3), a2b2 = (a2b2 & 3) + 4 r
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Z[g][r] = zero4;
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          const int v2 = (m == 2 ? 1 : 0) + (n == 2 ? 2 : 0);
+          const int v1 = (m == 1 ? 1 : 0) + (n == 1 ? 2 : 0);
+          const int g = (m == 0 ? 1 : 0) + (n == 0 ? 2 : 0);
+          const mh_d4 X = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[2][v2], Ahat[(m * 3 + j) * 3 + n], zero4, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const double xt = bperm_f64(idx1, X[r]);
+            Z[g][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[1][v1], xt, Z[g][r], 0, 0, 0);
+          }
+        }
+      // S3 per (r, r2) tile, then add the tile into KS
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int r2 = 0; r2 < 3; ++r2) {
+          mh_d4 K = zero4;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const double zt = bperm_f64(idx2, Z[g][r][r2]);
+            K = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[0][g], zt, K, 0, 0, 0);
+          }
+          const int ab2 = (lane & 3) + 4 * r, a1b1 = ((lane >> 2) & 3) + 4 * r2;
+          if (ab2 < NB2 && a1b1 < NB2) {
+            const int a2 = ab2 / NB, b2 = ab2 % NB, a1 = a1b1 / NB, b1 = a1b1 % NB;
+#pragma unroll
+            for (int r3 = 0; r3 < 3; ++r3) {
+              const int a0b0 = (lane >> 4) + 4 * r3;
+              if (a0b0 < NB2) {
+                const int a0 = a0b0 / NB, b0 = a0b0 % NB;
+                const int idx = (a0 + NB * (a1 + NB * a2)) * NROW + (b2 * NB + b1) * 9 + b0 * 3 + j;
+                KS[idx] += K[r3];
+              }
+            }
+          }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    MH_STAMP(5);
+    // ---- flush: entries shared with the next element of the column stay in KS (moved to their
+    // (a2-1, b2-1) slots); all others go to this (element, I)'s dense scratch piece, coalesced.
+    {
+      double* S = p.scratch_k + (e * 3 + I) * (int64_t)NK;
+#pragma unroll 5
+      for (int c = 0; c < (NK + 63) / 64; ++c) {
+        const int k = c * 64 + lane;
+        if (k < NK) {
+          const int a = k / NROW, within = k % NROW;
+          const int a2 = a / NB2, b2 = within / (NB * 9);
+          const double v = KS[k];
+          KS[k] = 0.0;
+          if (use_carry && !last && a2 >= 1 && b2 >= 1) {
+            KS[k - (NB2 * NROW + NB * 9)] = v;   // always a slot of an earlier round
+          } else {
+            S[k] = v;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    MH_STAMP(9);
+  }
+#ifdef MH_PROFILE
+  if (lane == 0 && p.prof)
+    for (int k = 0; k < 12; ++k) atomicAdd(&p.prof[k], prof_acc[k]);
+#endif
+}
+
+
+__global__ __launch_bounds__(64, 2) void tensor_p1_kernel(TensorArgs p) {
+  extern __shared__ __align__(16) double smem_p1[];
+  const int comp = blockIdx.x % 3, unit = blockIdx.x / 3;
+  const int eu = unit % p.n_units_u, ev = unit / p.n_units_u;
+  int status = 0;
+  if (comp == 0) tensor_p1_body<0>(p, smem_p1, eu, ev, status);
+  else if (comp == 1) tensor_p1_body<1>(p, smem_p1, eu, ev, status);
+  else tensor_p1_body<2>(p, smem_p1, eu, ev, status);
+  if (status) atomicOr(p.status, status);
+}
+
+// phase 2: gather.  Requires: lexicographic numbering, structured CSR, first[e] == e (no repeated
+// interior knots), walk axis == 2.
+__global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_nodes) {
+  constexpr int P = 2, NB = 3, ND = 27, NROW = 81, NK = ND * NROW;
+  const int64_t A = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (A >= n_nodes) return;
+  const int n0 = p.n_ctrl[0], n1 = p.n_ctrl[1], n2 = p.n_ctrl[2];
+  const int A0 = A % n0, A1 = (A / n0) % n1, A2 = A / ((int64_t)n0 * n1);
+  // elements of THIS shard containing node A: e_d in [A_d - P, A_d] clipped to the box
+  const int bx0 = p.box_begin[0], bx1 = p.box_begin[1], bx2 = p.box_begin[2];
+  const int ex_lo = max(A0 - P, bx0), ex_hi = min(A0, bx0 + p.box_n[0] - 1);
+  const int ey_lo = max(A1 - P, bx1), ey_hi = min(A1, bx1 + p.box_n[1] - 1);
+  const int ez_lo = max(A2 - P, bx2), ez_hi = min(A2, bx2 + p.box_n[2] - 1);
+  if (ex_lo > ex_hi || ey_lo > ey_hi || ez_lo > ez_hi) return;
+  const int last_ez = bx2 + p.box_n[2] - 1;
+  const int lo0 = max(A0 - P, 0), lo1 = max(A1 - P, 0), lo2 = max(A2 - P, 0);
+  const int w0 = min(A0 + P, n0 - 1) - lo0 + 1, w1 = min(A1 + P, n1 - 1) - lo1 + 1, w2 = min(A2 + P, n2 - 1) - lo2 + 1;
+  const int L = 3 * w0 * w1 * w2;
+  auto elem = [&](int ex, int ey, int ez) -> int64_t {
+    return (ex - bx0) + (int64_t)p.box_n[0] * ((ey - bx1) + (int64_t)p.box_n[1] * (ez - bx2));
+  };
+  for (int I = 0; I < 3; ++I) {
+    double* row = p.A + p.rowptr[A * 3 + I];
+    for (int t = lane; t < L; t += 64) {
+      const int j = t % 3;
+      int nb = t / 3;
+      const int B0 = lo0 + nb % w0;
+      nb /= w0;
+      const int B1 = lo1 + nb % w1;
+      const int B2 = lo2 + nb / w1;
+      // the storing element of pair (A, B) in a column: the highest one containing both nodes
+      const int ez = min(min(A2, B2), last_ez);
+      double s = 0.0;
+      if (ez >= max(max(A2, B2) - P, bx2)) {
+        const int a2 = A2 - ez, b2 = B2 - ez;
+        const int cx_lo = max(max(A0, B0) - P, bx0), cx_hi = min(min(A0, B0), bx0 + p.box_n[0] - 1);
+        const int cy_lo = max(max(A1, B1) - P, bx1), cy_hi = min(min(A1, B1), bx1 + p.box_n[1] - 1);
+        for (int ey = cy_lo; ey <= cy_hi; ++ey)
+          for (int ex = cx_lo; ex <= cx_hi; ++ex) {
+            const int a = (A0 - ex) + NB * ((A1 - ey) + NB * a2);
+            const int slot = a * NROW + (b2 * NB + (B1 - ey)) * 9 + (B0 - ex) * 3 + j;
+            s += p.scratch_k[(elem(ex, ey, ez) * 3 + I) * (int64_t)NK + slot];
+          }
+      }
+      row[t] += p.grad_factor * s;
+    }
+    // residual row: sum of the element residual pieces
+    if (lane == 0) {
+      double s = 0.0;
+      for (int ez = ez_lo; ez <= ez_hi; ++ez)
+        for (int ey = ey_lo; ey <= ey_hi; ++ey)
+          for (int ex = ex_lo; ex <= ex_hi; ++ex) {
+            const int a = (A0 - ex) + NB * ((A1 - ey) + NB * (A2 - ez));
+            s += p.scratch_r[(elem(ex, ey, ez) * 3 + I) * ND + a];
+          }
+      p.r[A * 3 + I] += s;
+    }
+  }
+}
+
+inline bool two_phase_supported(const mimi_hip_domain_s* h) {
+  if (!h->structured_csr || h->node_ids.ptr || !h->first_is_identity) return false;
+  // walk axis (shortest, ties -> last) must be the third direction
+  int seq = 0;
+  for (int d = 1; d < 3; ++d)
+    if (h->el_end[d] - h->el_begin[d] <= h->el_end[seq] - h->el_begin[seq]) seq = d;
+  return seq == 2;
+}
+
+inline void launch_tensor_two_phase(mimi_hip_domain_s* h, TensorArgs a) {
+  constexpr int NK = 27 * 81;
+  h->scratch_k.resize((size_t)h->n_el * 3 * NK);
+  h->scratch_r.resize((size_t)h->n_el * 3 * 27);
+  a.scratch_k = h->scratch_k.ptr;
+  a.scratch_r = h->scratch_r.ptr;
+  a.n_units_u = a.box_n[a.u_axis];
+  a.n_units_v = a.box_n[a.v_axis];
+  const size_t lds = MfmaLds::total * sizeof(double);
+  hipLaunchKernelGGL(tensor_p1_kernel, dim3(a.n_units_u * a.n_units_v * 3), dim3(64), lds, h->stream, a);
+  MH_HIP(hipGetLastError());
+  const int64_t n_nodes = h->n_nodes;
+  hipLaunchKernelGGL(tensor_p2_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, h->stream, a, n_nodes);
+  MH_HIP(hipGetLastError());
+}
+
+}  // namespace mimi_hip

@@ -1,4 +1,4 @@
-import sys, ctypes as C, numpy as np
+import sys, os, ctypes as C, numpy as np
 sys.path.insert(0, '/root/repo')
 import torch, mimi_amd
 from mimi_amd.integrators import CSRPattern, NonlinearSolid
@@ -19,7 +19,7 @@ L.mimi_hip_debug_profile(G._h, out, 1)
 G.AddDomainResidualAndGrad(u, 1.0, r, A); G.Synchronize()
 L.mimi_hip_debug_profile(G._h, out, 1)
 v = np.array(list(out), dtype=np.float64)
-names = ['loop-top/prev-scatter-tail', 'stage0 LDS fill+prefetch', 'stageA material', 'stageR residual', 'issue old loads', 'S12', 'S3', 'carry', 'Kv select', 'scatter stores', '', '']
+names = ['loop top', 'stage0', 'stageA', 'stageR', '-', 'MFMA stage C', '-', '-', '-', 'flush RMW', '', ''] if os.environ.get('MFMA_NAMES') else ['loop-top/prev-scatter-tail', 'stage0 LDS fill+prefetch', 'stageA material', 'stageR residual', 'issue old loads', 'S12', 'S3', 'carry', 'Kv select', 'scatter stores', '', '']
 n_items = patch.n_elements * 3
 print('shader cycles per (element,i):')
 for k in range(10):
