@@ -65,6 +65,12 @@ MH_DEV void tensor_p1_body(const TensorArgs& p, double* lds, int eu, int ev, int
   const int idx2 = 4 * ((lane >> 4) + 4 * (lane & 3) + 16 * ((lane >> 2) & 3));
 
   for (int k = lane; k < ND * NROW; k += 64) KS[k] = 0.0;
+  // bit c: slot k = 64 c + lane has a2 >= 1 and b2 >= 1 (shared with the next element of the column)
+  unsigned long long carry_mask = 0;
+  for (int c = 0; c < (ND * NROW + 63) / 64; ++c) {
+    const int k = c * 64 + lane;
+    if (k < ND * NROW && (k / NROW) / NB2 >= 1 && (k % NROW) / (NB * 9) >= 1) carry_mask |= 1ull << c;
+  }
 
   // ---- pipeline prologue ------------------------------------------------------------------------
   int el_c[3], el_n[3];
@@ -110,24 +116,6 @@ MH_DEV void tensor_p1_body(const TensorArgs& p, double* lds, int eu, int ev, int
     int el_w[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) el_w[d] = el_c[d];
-    if (es + 1 < n_seq) {
-      e_cur = element_of(es + 1, el_c);
-      node_c = node_n;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) ue_r[c] = p.u[(int64_t)node_c * 3 + c];
-    #pragma unroll
-      for (int rd = 0; rd < TROUNDS; ++rd) {
-        const int t = rd * 64 + lane;
-        tab_r[rd] = *table_src(el_c, t < 6 * NB * NQ ? t : 0);
-      }
-      const double* g = p.geo + e_cur * 10 * NQ3 + lane;
-#pragma unroll
-      for (int k = 0; k < 10; ++k) geo_r[k] = g[(int64_t)k * NQ3];
-      if (es + 2 < n_seq) {
-        const int64_t e2 = element_of(es + 2, el_n);
-        node_n = lane < ND ? p.dofs[e2 * ND + lane] : 0;
-      }
-    }
     __builtin_amdgcn_wave_barrier();
 
     constexpr int NK = ND * NROW;   // 2187 slots
@@ -263,6 +251,26 @@ MH_DEV void tensor_p1_body(const TensorArgs& p, double* lds, int eu, int ev, int
     }
 
     MH_STAMP(3);
+    // ---- loads of the NEXT element, in flight during the matrix stage ------------------------------
+    if (es + 1 < n_seq) {
+      e_cur = element_of(es + 1, el_c);
+      node_c = node_n;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) ue_r[c] = p.u[(int64_t)node_c * 3 + c];
+    #pragma unroll
+      for (int rd = 0; rd < TROUNDS; ++rd) {
+        const int t = rd * 64 + lane;
+        tab_r[rd] = *table_src(el_c, t < 6 * NB * NQ ? t : 0);
+      }
+      const double* g = p.geo + e_cur * 10 * NQ3 + lane;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) geo_r[k] = g[(int64_t)k * NQ3];
+      if (es + 2 < n_seq) {
+        const int64_t e2 = element_of(es + 2, el_n);
+        node_n = lane < ND ? p.dofs[e2 * ND + lane] : 0;
+      }
+    }
+    MH_STAMP(4);
     // ---- stage C on the matrix pipe ----------------------------------------------------------------
     // A operands: pair tables of the three directions, lane = (row = pair index, k = quadrature index)
     double aS[3][4];  // [dir][variant]: 0 B.B, 1 D(a).B(b), 2 B(a).D(b), 3 D.D
@@ -275,79 +283,131 @@ MH_DEV void tensor_p1_body(const TensorArgs& p, double* lds, int eu, int ev, int
       aS[dir][2] = mrow_ok ? Ba * Db : 0.0;
       aS[dir][3] = mrow_ok ? Da * Db : 0.0;
     }
+    // Contraction chain (no LDS, no lane shuffles):
+    //   S1 (matrix pipe)  D1[q1][q0 | a2b2] = sum_q2 Ahat(q0 q1; q2) TT2[q2][a2b2]
+    //        the constitutive stage's lane = q layout is also the A-operand layout (row = q0 + 4 q1,
+    //        k = q2); the result has q1 on the 4 accumulator registers, q0 on lane bits 5:4.
+    //   S2 (vector pipe)  E_g[a1b1][q0 | a2b2] += sum_q1 T1^m[a1][q1] T1^n[b1][q1] D1[q1]
+    //        a linear combination of the 4 accumulator registers with wave-uniform coefficients,
+    //        grouped by the direction-0 variant g = (m == 0) + 2 (n == 0).
+    //   S3 (matrix pipe)  K[a1b1][a0b0 | a2b2] = sum_g sum_q0 TT0^g[a0b0][q0] E_g[a1b1][q0 | a2b2]
+    //        E is already a B operand (k = q0 on lane bits 5:4, col = a2b2).
+    // pair-table variant of direction d for (m, n): v_d = (m == d) + 2 (n == d)
     const mh_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+    // wave-uniform direction-1 tables in scalar registers
+    double uB1[NB][NQ], uD1[NB][NQ];
 #pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+      for (int q1 = 0; q1 < NQ; ++q1) {
+        const unsigned long long vb = __double_as_longlong(tab_ptr<P>(tab, 1, 0)[a * NQ + q1]);
+        const unsigned long long vd = __double_as_longlong(tab_ptr<P>(tab, 1, 1)[a * NQ + q1]);
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)vb), bhi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
+        const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)vd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(vd >> 32));
+        uB1[a][q1] = __longlong_as_double(((unsigned long long)bhi << 32) | blo);
+        uD1[a][q1] = __longlong_as_double(((unsigned long long)dhi << 32) | dlo);
+      }
+    MH_STAMP(5);
+#pragma unroll 1
     for (int j = 0; j < 3; ++j) {
-      mh_d4 Z[4][3];  // [g][r]: rows a1b1 = (lane>>4) + 4 r2, cols (q0, a2b2 & 3), a2b2 = (a2b2 & 3) + 4 r
+      double E[4][NB2];  // [g][a1b1], lane = (q0 on bits 5:4, a2b2 on bits 3:0)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int r = 0; r < 3; ++r) Z[g][r] = zero4;
+        for (int k = 0; k < NB2; ++k) E[g][k] = 0.0;
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
           const int v2 = (m == 2 ? 1 : 0) + (n == 2 ? 2 : 0);
-          const int v1 = (m == 1 ? 1 : 0) + (n == 1 ? 2 : 0);
           const int g = (m == 0 ? 1 : 0) + (n == 0 ? 2 : 0);
-          const mh_d4 X = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[2][v2], Ahat[(m * 3 + j) * 3 + n], zero4, 0, 0, 0);
+          // static selection of the j-th entry (the j loop stays rolled)
+          const double ah = j == 0 ? Ahat[(m * 3 + 0) * 3 + n] : j == 1 ? Ahat[(m * 3 + 1) * 3 + n] : Ahat[(m * 3 + 2) * 3 + n];
+          const mh_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ah, aS[2][v2], zero4, 0, 0, 0);
 #pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            const double xt = bperm_f64(idx1, X[r]);
-            Z[g][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[1][v1], xt, Z[g][r], 0, 0, 0);
-          }
-        }
-      // S3 per (r, r2) tile, then add the tile into KS
+          for (int b1 = 0; b1 < NB; ++b1) {
+            double U[NQ];
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
+            for (int q1 = 0; q1 < NQ; ++q1) U[q1] = (n == 1 ? uD1[b1][q1] : uB1[b1][q1]) * D1[q1];
 #pragma unroll
-        for (int r2 = 0; r2 < 3; ++r2) {
-          mh_d4 K = zero4;
+            for (int a1 = 0; a1 < NB; ++a1) {
+              double acc = E[g][a1 * NB + b1];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const double zt = bperm_f64(idx2, Z[g][r][r2]);
-            K = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[0][g], zt, K, 0, 0, 0);
-          }
-          const int ab2 = (lane & 3) + 4 * r, a1b1 = ((lane >> 2) & 3) + 4 * r2;
-          if (ab2 < NB2 && a1b1 < NB2) {
-            const int a2 = ab2 / NB, b2 = ab2 % NB, a1 = a1b1 / NB, b1 = a1b1 % NB;
-#pragma unroll
-            for (int r3 = 0; r3 < 3; ++r3) {
-              const int a0b0 = (lane >> 4) + 4 * r3;
-              if (a0b0 < NB2) {
-                const int a0 = a0b0 / NB, b0 = a0b0 % NB;
-                const int idx = (a0 + NB * (a1 + NB * a2)) * NROW + (b2 * NB + b1) * 9 + b0 * 3 + j;
-                KS[idx] += K[r3];
-              }
+              for (int q1 = 0; q1 < NQ; ++q1) acc += (m == 1 ? uD1[a1][q1] : uB1[a1][q1]) * U[q1];
+              E[g][a1 * NB + b1] = acc;
             }
           }
         }
+      MH_STAMP(6);
+      // S3, then accumulation into KS: all reads first, then all writes (the slots of one block are
+      // distinct; written this way the LDS accesses are not serialised by may-alias ordering)
+      mh_d4 K[NB2];
+#pragma unroll
+      for (int a1b1 = 0; a1b1 < NB2; ++a1b1) {
+        K[a1b1] = zero4;  // rows a0b0 = (lane>>4) + 4 r, cols a2b2
+#pragma unroll
+        for (int g = 0; g < 4; ++g) K[a1b1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[0][g], E[g][a1b1], K[a1b1], 0, 0, 0);
+      }
+      MH_STAMP(7);
+      const int ab2 = lane & 15;
+      const bool col_ok = ab2 < NB2;
+      const int a2 = col_ok ? ab2 / NB : 0, b2 = col_ok ? ab2 % NB : 0;
+      double prev[NB2][3];
+#pragma unroll
+      for (int a1b1 = 0; a1b1 < NB2; ++a1b1)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int a0b0 = (lane >> 4) + 4 * r;
+          const bool ok = col_ok && a0b0 < NB2;
+          const int a0 = ok ? a0b0 / NB : 0, b0 = ok ? a0b0 % NB : 0;
+          const int idx = (a0 + NB * (a1b1 / NB + NB * a2)) * NROW + (b2 * NB + a1b1 % NB) * 9 + b0 * 3 + j;
+          prev[a1b1][r] = ok ? KS[idx] : 0.0;
+        }
+#pragma unroll
+      for (int a1b1 = 0; a1b1 < NB2; ++a1b1)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int a0b0 = (lane >> 4) + 4 * r;
+          const bool ok = col_ok && a0b0 < NB2;
+          const int a0 = ok ? a0b0 / NB : 0, b0 = ok ? a0b0 % NB : 0;
+          const int idx = (a0 + NB * (a1b1 / NB + NB * a2)) * NROW + (b2 * NB + a1b1 % NB) * 9 + b0 * 3 + j;
+          if (ok) KS[idx] = prev[a1b1][r] + K[a1b1][r];
+        }
+      MH_STAMP(8);
     }
     __builtin_amdgcn_wave_barrier();
 
-    MH_STAMP(5);
+    MH_STAMP(10);
     // ---- flush: entries shared with the next element of the column stay in KS (moved to their
     // (a2-1, b2-1) slots); all others go to this (element, I)'s dense scratch piece, coalesced.
+    // Reads, LDS writes and global stores in separate passes (no may-alias serialisation).
     {
       double* S = p.scratch_k + (e * 3 + I) * (int64_t)NK;
-#pragma unroll 5
-      for (int c = 0; c < (NK + 63) / 64; ++c) {
+      constexpr int NR = (NK + 63) / 64;  // 35
+      double v[NR];
+#pragma unroll
+      for (int c = 0; c < NR; ++c) {
         const int k = c * 64 + lane;
+        v[c] = k < NK ? KS[k] : 0.0;
+      }
+      const bool do_carry = use_carry && !last;
+#pragma unroll
+      for (int c = 0; c < NR; ++c) {
+        const int k = c * 64 + lane;
+        if (k < NK) KS[k] = 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < NR; ++c) {
+        const int k = c * 64 + lane;
+        const bool cr = do_carry && ((carry_mask >> c) & 1);
         if (k < NK) {
-          const int a = k / NROW, within = k % NROW;
-          const int a2 = a / NB2, b2 = within / (NB * 9);
-          const double v = KS[k];
-          KS[k] = 0.0;
-          if (use_carry && !last && a2 >= 1 && b2 >= 1) {
-            KS[k - (NB2 * NROW + NB * 9)] = v;   // always a slot of an earlier round
-          } else {
-            S[k] = v;
-          }
+          if (cr) KS[k - (NB2 * NROW + NB * 9)] = v[c];
+          else S[k] = v[c];
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
-    MH_STAMP(9);
+    MH_STAMP(11);
   }
 #ifdef MH_PROFILE
   if (lane == 0 && p.prof)
@@ -356,7 +416,7 @@ MH_DEV void tensor_p1_body(const TensorArgs& p, double* lds, int eu, int ev, int
 }
 
 
-__global__ __launch_bounds__(64, 2) void tensor_p1_kernel(TensorArgs p) {
+__global__ __launch_bounds__(64) void tensor_p1_kernel(TensorArgs p) {
   extern __shared__ __align__(16) double smem_p1[];
   const int comp = blockIdx.x % 3, unit = blockIdx.x / 3;
   const int eu = unit % p.n_units_u, ev = unit / p.n_units_u;
