@@ -10,6 +10,7 @@
 #include "kernels_tensor.hpp"
 #include "kernels_tensor_mfma.hpp"
 #include "kernels_tensor_2phase.hpp"
+#include "kernels_tensor_wgs.hpp"
 
 #include <algorithm>
 #include <cmath>

@@ -1,0 +1,580 @@
+// Phase 1 of the two-phase tangent assembly as a ROLE-SPECIALISED workgroup (p = 2, 3-D).
+//
+// Why: the single-wave phase-1 kernel (kernels_tensor_2phase.hpp) needs the whole register file
+// of a SIMD (constitutive stage + contraction tiles + prefetch live together) and 31 KB of LDS,
+// so one wave runs alone per SIMD and every LDS / matrix-pipe / memory latency is exposed
+// (profiles/r01_*: ~46 k cycles per (element, i) for ~20 k cycles of issued work).  Here the work
+// of one element column is split over four waves of one workgroup so that each wave fits in half
+// a register file and two workgroups (8 waves) share a CU:
+//
+//   wave 0  "X"   quadrature-point stage: gathers u, evaluates F and the material ONCE per point
+//                 (the single-wave kernel repeats this for every row i), then per row i the
+//                 residual piece (sum factorisation) and the pulled-back tangent row
+//                 Ahat_i[m][j][n] -> LDS (lane = quadrature point, private slots).
+//   wave 1+i "Y_i" contraction of row i:  S1 (matrix pipe, q2) -> S2 (vector pipe, q1, wave-uniform
+//                 coefficients) -> S3 (matrix pipe, q0), with the tile TRANSPOSED with respect to
+//                 the single-wave kernel: rows = (a2,b2) pair index, so that the entries shared with
+//                 the next element of the column, (a2,b2) -> (a2-1,b2-1) = pair index - 4, are the
+//                 NEXT ACCUMULATOR REGISTER OF THE SAME LANE.  The carry along the column therefore
+//                 lives in registers (27 doubles per lane) instead of a 17.5 KB LDS tile with
+//                 read-modify-write; LDS is only used to transpose the finished entries for
+//                 coalesced stores (write once, read once).
+//
+// The four waves run in lock step, three steps per element (X: row k; Y_i: column component j),
+// Y_i lagging X by i + 1 steps, so Ahat needs a single LDS buffer:
+//     step = [Y: read its operands from LDS] barrier [X: compute + write; Y: compute] barrier
+// Every wave executes exactly 6 (n_seq + 1) barriers.  Scratch layout, phase 2 and the bitwise
+// reproducibility of the result are those of kernels_tensor_2phase.hpp.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kernels_tensor_2phase.hpp"
+
+namespace mimi_hip {
+
+struct WgsLds {
+  static constexpr int NB = 3, NQ = 4, NB2 = 9, ND = 27, NQ3 = 64, NROW = 81;
+  static constexpr int off_ue = 0;                       // [3][27] (+1 pad)           X private
+  static constexpr int off_tab = off_ue + 3 * ND + 1;    // [2 parity][3 dir][2][3][4]  X -> Y
+  static constexpr int off_r = off_tab + 2 * 6 * NB * NQ;  // stage-R scratch            X private
+  static constexpr int r_size = 3 * NQ3 + 3 * NB * NQ * NQ + 3 * NB2 * NQ;
+  static constexpr int off_ah = off_r + r_size;          // [3 i][27 (m,j,n)][64]        X -> Y_i
+  static constexpr int n_final = 9 * NROW + 18 * ND;     // 1215 entries stored by a non-last element
+  static constexpr int n_carry = 18 * 2 * ND;            // 972 more by the last element of a column
+  static constexpr int st_size = n_final + 1;
+  static constexpr int off_st = off_ah + 3 * ND * NQ3;   // [3 i][1216] store transposition     Y_i private
+  static constexpr int total = off_st + 3 * st_size;
+};
+
+#define WGS_PIN(x) asm volatile("" : "+v"(x))
+
+MH_DEV void wgs_barrier() {
+  // LDS hand-off only: outstanding global loads / stores need not drain here
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+MH_DEV double rot32_f64(int lane, double v) { return bperm_f64(((lane ^ 32) & 63) * 4, v); }
+
+// ------------------------------------------------------------------------------------------------
+// wave X
+// ------------------------------------------------------------------------------------------------
+template<int I>
+MH_DEV void wgs_x_row(const TensorArgs& p, double* lds, int lane, int64_t e, int par, const PointResult<3>& w,
+                      const double* Ji, double wd) {
+  using L = WgsLds;
+  constexpr int P = 2, NB = 3, NQ = 4, NB2 = 9, ND = 27, NQ3 = 64;
+  const double* tab = lds + L::off_tab + par * 6 * NB * NQ;
+  double* AH = lds + L::off_ah + I * ND * NQ3;
+  double* RS = lds + L::off_r;
+  double Phat[3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    double sp = 0.0;
+#pragma unroll
+    for (int J = 0; J < 3; ++J) sp += w.P[I + J * 3] * Ji[m * 3 + J];
+    Phat[m] = wd * sp;
+  }
+  {
+    double A[27];
+    tangent_row_of<3, I>(p.mat.m, w, A);
+    double T[27];
+#pragma unroll
+    for (int J = 0; J < 3; ++J)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          double st = 0.0;
+#pragma unroll
+          for (int Lx = 0; Lx < 3; ++Lx) st += A[(J * 3 + j) * 3 + Lx] * Ji[n * 3 + Lx];
+          T[(J * 3 + j) * 3 + n] = st;
+        }
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          double sa = 0.0;
+#pragma unroll
+          for (int J = 0; J < 3; ++J) sa += Ji[m * 3 + J] * T[(J * 3 + j) * 3 + n];
+          AH[((m * 3 + j) * 3 + n) * NQ3 + lane] = wd * sa;
+        }
+  }
+  // residual row I by sum factorisation (as kernels_tensor_2phase.hpp)
+  double* PH = RS;                   // [3 m][64]
+  double* V = PH + 3 * NQ3;          // [3 m][3 a2][16]
+  double* W = V + 3 * NB * NQ * NQ;  // [3 m][9 a1a2][4]
+#pragma unroll
+  for (int m = 0; m < 3; ++m) PH[m * NQ3 + lane] = Phat[m];
+  __builtin_amdgcn_wave_barrier();
+  if (lane < NB * NQ * NQ) {
+    const int q01 = lane % (NQ * NQ), a2 = lane / (NQ * NQ);
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const double* T2 = tab_ptr<P>(tab, 2, m == 2 ? 1 : 0) + a2 * NQ;
+      double sv = 0.0;
+#pragma unroll
+      for (int q2 = 0; q2 < NQ; ++q2) sv += T2[q2] * PH[m * NQ3 + q01 + NQ * NQ * q2];
+      V[(m * NB + a2) * NQ * NQ + q01] = sv;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < NB2 * NQ) {
+    const int q0 = lane % NQ, a12 = lane / NQ, a1 = a12 % NB, a2 = a12 / NB;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const double* T1 = tab_ptr<P>(tab, 1, m == 1 ? 1 : 0) + a1 * NQ;
+      double sw = 0.0;
+#pragma unroll
+      for (int q1 = 0; q1 < NQ; ++q1) sw += T1[q1] * V[(m * NB + a2) * NQ * NQ + q0 + NQ * q1];
+      W[(m * NB2 + a12) * NQ + q0] = sw;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < ND) {
+    const int a0 = lane % NB, a12 = lane / NB;
+    double sr = 0.0;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const double* T0 = tab_ptr<P>(tab, 0, m == 0 ? 1 : 0) + a0 * NQ;
+#pragma unroll
+      for (int q0 = 0; q0 < NQ; ++q0) sr += T0[q0] * W[(m * NB2 + a12) * NQ + q0];
+    }
+    p.scratch_r[(e * 3 + I) * ND + lane] = sr;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& status) {
+  using L = WgsLds;
+  constexpr int P = 2, NB = 3, NQ = 4, ND = 27, NQ3 = 64;
+  constexpr int TROUNDS = 2;  // 72 table values
+  const int lane = threadIdx.x & 63;
+  double* ue = lds + L::off_ue;
+  const int n_seq = p.box_n[2];
+  auto element_of = [&](int es, int* el) -> int64_t {
+    el[0] = eu;
+    el[1] = ev;
+    el[2] = es;
+    return el[0] + (int64_t)p.box_n[0] * (el[1] + (int64_t)p.box_n[1] * el[2]);
+  };
+  auto table_src = [&](const int* el, int t) -> const double* {
+    const int dir = t / (2 * NB * NQ);
+    const int rem = t % (2 * NB * NQ);
+    const int isD = rem / (NB * NQ);
+    const int k = rem % (NB * NQ);
+    const int span = (dir == 0 ? p.box_begin[0] + el[0] : dir == 1 ? p.box_begin[1] + el[1] : p.box_begin[2] + el[2]);
+    return (isD ? (dir == 0 ? p.tabD[0] : dir == 1 ? p.tabD[1] : p.tabD[2])
+                : (dir == 0 ? p.tabB[0] : dir == 1 ? p.tabB[1] : p.tabB[2])) + (int64_t)span * NB * NQ + k;
+  };
+
+  // prologue: element 0 into registers, connectivity of element 1
+  int el_c[3], el_n[3];
+  int64_t e_cur = element_of(0, el_c);
+  int32_t node_c = lane < ND ? p.dofs[e_cur * ND + lane] : 0, node_n = 0;
+  double ue_r[3], tab_r[TROUNDS], geo_r[10];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ue_r[c] = p.u[(int64_t)node_c * 3 + c];
+#pragma unroll
+  for (int rd = 0; rd < TROUNDS; ++rd) {
+    const int t = rd * 64 + lane;
+    tab_r[rd] = *table_src(el_c, t < 6 * NB * NQ ? t : 0);
+  }
+  {
+    const double* g = p.geo + e_cur * 10 * NQ3 + lane;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) geo_r[k] = g[(int64_t)k * NQ3];
+  }
+  if (n_seq > 1) {
+    const int64_t e1 = element_of(1, el_n);
+    node_n = lane < ND ? p.dofs[e1 * ND + lane] : 0;
+  }
+
+  PointResult<3> w;
+  double Ji[9], wd = 0.0;
+  int64_t e = 0;
+  for (int it = 0; it <= n_seq; ++it) {
+    const bool valid = it < n_seq;
+    const int par = it & 1;
+    // ---- step 0: quadrature-point stage + row 0 ------------------------------------------------
+    wgs_barrier();
+    if (valid) {
+      double* tab = lds + L::off_tab + par * 6 * NB * NQ;
+      if (lane < ND) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ue[c * ND + lane] = ue_r[c];
+      }
+#pragma unroll
+      for (int rd = 0; rd < TROUNDS; ++rd) {
+        const int t = rd * 64 + lane;
+        if (t < 6 * NB * NQ) tab[t] = tab_r[rd];
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Ji[k] = geo_r[k];
+      wd = geo_r[9];
+      e = e_cur;
+      __builtin_amdgcn_wave_barrier();
+      // loads of the next element, in flight during the three steps of this one
+      if (it + 1 < n_seq) {
+        e_cur = element_of(it + 1, el_c);
+        node_c = node_n;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ue_r[c] = p.u[(int64_t)node_c * 3 + c];
+#pragma unroll
+        for (int rd = 0; rd < TROUNDS; ++rd) {
+          const int t = rd * 64 + lane;
+          tab_r[rd] = *table_src(el_c, t < 6 * NB * NQ ? t : 0);
+        }
+        const double* g = p.geo + e_cur * 10 * NQ3 + lane;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) geo_r[k] = g[(int64_t)k * NQ3];
+        if (it + 2 < n_seq) {
+          const int64_t e2 = element_of(it + 2, el_n);
+          node_n = lane < ND ? p.dofs[e2 * ND + lane] : 0;
+        }
+      }
+      // F at the quadrature point of this lane, q = q0 + 4 q1 + 16 q2
+      {
+        const int q0 = lane & 3, q1 = (lane >> 2) & 3, q2 = lane >> 4;
+        double b0[NB], d0[NB], b1[NB], d1[NB], b2[NB], d2[NB];
+#pragma unroll
+        for (int a = 0; a < NB; ++a) {
+          b0[a] = tab_ptr<P>(tab, 0, 0)[a * NQ + q0];
+          d0[a] = tab_ptr<P>(tab, 0, 1)[a * NQ + q0];
+          b1[a] = tab_ptr<P>(tab, 1, 0)[a * NQ + q1];
+          d1[a] = tab_ptr<P>(tab, 1, 1)[a * NQ + q1];
+          b2[a] = tab_ptr<P>(tab, 2, 0)[a * NQ + q2];
+          d2[a] = tab_ptr<P>(tab, 2, 1)[a * NQ + q2];
+        }
+        double H[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) H[k] = 0.0;
+#pragma unroll
+        for (int a2 = 0; a2 < NB; ++a2)
+#pragma unroll
+          for (int a1 = 0; a1 < NB; ++a1) {
+            const double tbb = b1[a1] * b2[a2], tdb = d1[a1] * b2[a2], tbd = b1[a1] * d2[a2];
+#pragma unroll
+            for (int a0 = 0; a0 < NB; ++a0) {
+              const int a = a0 + NB * (a1 + NB * a2);
+              const double dn0 = d0[a0] * tbb, dn1 = b0[a0] * tdb, dn2 = b0[a0] * tbd;
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                const double uu = ue[i * ND + a];
+                H[i * 3 + 0] += uu * dn0;
+                H[i * 3 + 1] += uu * dn1;
+                H[i * 3 + 2] += uu * dn2;
+              }
+            }
+          }
+        double F[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int J = 0; J < 3; ++J) {
+            double sf = (i == J) ? 1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * Ji[m * 3 + J];
+            F[i + J * 3] = sf;
+          }
+        status |= evaluate_pk1<3>(p.mat, p.dt, p.state, e * NQ3 + lane, F, w);
+      }
+      wgs_x_row<0>(p, lds, lane, e, par, w, Ji, wd);
+    }
+    wgs_barrier();
+    // ---- step 1: row 1 ---------------------------------------------------------------------------
+    wgs_barrier();
+    if (valid) wgs_x_row<1>(p, lds, lane, e, par, w, Ji, wd);
+    wgs_barrier();
+    // ---- step 2: row 2 ---------------------------------------------------------------------------
+    wgs_barrier();
+    if (valid) wgs_x_row<2>(p, lds, lane, e, par, w, Ji, wd);
+    wgs_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave Y_I
+// ------------------------------------------------------------------------------------------------
+template<int I>
+MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
+  using L = WgsLds;
+  constexpr int P = 2, NB = 3, NQ = 4, NB2 = 9, ND = 27, NQ3 = 64, NROW = 81, NK = ND * NROW;
+  const int lane = threadIdx.x & 63;
+  const double* AH = lds + L::off_ah + I * ND * NQ3;
+  double* ST = lds + L::off_st + I * L::st_size;
+  const int n_seq = p.box_n[2];
+
+  // matrix-operand lane constants: pair index on bits 3:0, contraction index on bits 5:4
+  const int mrow = lane & 15, mk = lane >> 4;
+  const bool mrow_ok = mrow < NB2;
+  const int mra = mrow_ok ? mrow / NB : 0, mrb = mrow_ok ? mrow % NB : 0;
+  // result tile of S3: row (a2,b2) pair = grp + 4 r, column (a0,b0) pair = lane & 15
+  const int grp = lane >> 4;
+  const bool col_ok = mrow_ok;
+  const int a0 = mra, b0 = mrb;
+  // store-transposition slots (the compact image of the scratch piece, see flush below):
+  //   a2 == 0 : s = (a0 + 3 a1) 81 + b2 27 + b1 9 + b0 3 + j
+  //   a2 >= 1, b2 == 0 : s = 729 + (a0 + 3 a1 + 9 (a2 - 1)) 27 + b1 9 + b0 3 + j
+  // register 0 holds rows 0..3 = (0,0) (0,1) (0,2) (1,0); register 1, group 2 holds row 6 = (2,0)
+  const int base0 = grp < 3 ? a0 * NROW + grp * ND + b0 * 3 : 9 * NROW + a0 * ND + b0 * 3;
+  const int stride0 = grp < 3 ? 3 * NROW : 3 * ND;
+  const int base1 = 9 * NROW + (a0 + 9) * ND + b0 * 3;   // stride 3 * ND
+  // carried rows, stored only by the last element of the column, from the packed carry register:
+  //   group 0: row 4 (1,1)  group 1: row 5 (1,2)  group 3: row 7 (2,1)  group 2: row 8 (2,2)
+  //   s' = (a - 9) 54 + (b2 - 1) 27 + b1 9 + b0 3 + j
+  const int basec = a0 * 54 + b0 * 3 + (grp == 0 ? 0 : grp == 1 ? ND : grp == 3 ? 9 * 54 : 9 * 54 + ND);
+
+  const mh_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  double C[3][NB2];  // packed carry [j][a1b1]
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < NB2; ++k) C[j][k] = 0.0;
+  double aS0[4], aS2[4];      // pair tables of directions 0 and 2 (variants B.B, D.B, B.D, D.D)
+  double uB1[NB][NQ], uD1[NB][NQ];  // wave-uniform direction-1 tables
+#pragma unroll
+  for (int v = 0; v < 4; ++v) aS0[v] = aS2[v] = 0.0;
+#pragma unroll
+  for (int a = 0; a < NB; ++a)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) uB1[a][q] = uD1[a][q] = 0.0;
+
+  {
+    double* AHw = lds + L::off_ah + I * ND * NQ3;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) AHw[c * NQ3 + lane] = 0.0;
+    if (lane < 6 * NB * NQ) {
+      lds[L::off_tab + lane] = 0.0;
+      lds[L::off_tab + 6 * NB * NQ + lane] = 0.0;
+    }
+    if (lane + 64 < 6 * NB * NQ) {
+      lds[L::off_tab + 64 + lane] = 0.0;
+      lds[L::off_tab + 6 * NB * NQ + 64 + lane] = 0.0;
+    }
+  }
+  for (int it = 0; it <= n_seq; ++it) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int j = (k - I - 1 + 3) % 3;             // compile-time after unrolling
+      const int es = (k >= I + 1) ? it : it - 1;     // element of this step
+      const bool valid = es >= 0 && es < n_seq;
+      double ah[9];
+      // ---- read window ---------------------------------------------------------------------------
+      // (steps before the first / after the last element of this wave run on zeros / stale operands:
+      // their results are never stored, and branch-free steps keep the carry in registers)
+      {
+        if (j == 0) {
+          const double* tab = lds + L::off_tab + (es & 1) * 6 * NB * NQ;
+          {
+            const double Ba = tab_ptr<P>(tab, 0, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 0, 1)[mra * NQ + mk];
+            const double Bb = tab_ptr<P>(tab, 0, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 0, 1)[mrb * NQ + mk];
+            aS0[0] = mrow_ok ? Ba * Bb : 0.0;
+            aS0[1] = mrow_ok ? Da * Bb : 0.0;
+            aS0[2] = mrow_ok ? Ba * Db : 0.0;
+            aS0[3] = mrow_ok ? Da * Db : 0.0;
+          }
+          {
+            const double Ba = tab_ptr<P>(tab, 2, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 2, 1)[mra * NQ + mk];
+            const double Bb = tab_ptr<P>(tab, 2, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 2, 1)[mrb * NQ + mk];
+            aS2[0] = mrow_ok ? Ba * Bb : 0.0;
+            aS2[1] = mrow_ok ? Da * Bb : 0.0;
+            aS2[2] = mrow_ok ? Ba * Db : 0.0;
+            aS2[3] = mrow_ok ? Da * Db : 0.0;
+          }
+#pragma unroll
+          for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int q1 = 0; q1 < NQ; ++q1) {
+              const unsigned long long vb = __double_as_longlong(tab_ptr<P>(tab, 1, 0)[a * NQ + q1]);
+              const unsigned long long vd = __double_as_longlong(tab_ptr<P>(tab, 1, 1)[a * NQ + q1]);
+              const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)vb), bhi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
+              const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)vd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(vd >> 32));
+              uB1[a][q1] = __longlong_as_double(((unsigned long long)bhi << 32) | blo);
+              uD1[a][q1] = __longlong_as_double(((unsigned long long)dhi << 32) | dlo);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) ah[m * 3 + n] = AH[((m * 3 + j) * 3 + n) * NQ3 + lane];
+      }
+      wgs_barrier();
+      // ---- compute window ------------------------------------------------------------------------
+      {
+        const bool last = es + 1 >= n_seq;
+        // S1 + S2 (see kernels_tensor_2phase.hpp): E_g[a1b1], lane = (q0 on bits 5:4, a2b2 on bits 3:0)
+        double E[4][NB2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int c = 0; c < NB2; ++c) E[g][c] = 0.0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) {
+            const int v2 = (m == 2 ? 1 : 0) + (n == 2 ? 2 : 0);
+            const int g = (m == 0 ? 1 : 0) + (n == 0 ? 2 : 0);
+            const mh_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[m * 3 + n], aS2[v2], zero4, 0, 0, 0);
+#pragma unroll
+            for (int b1 = 0; b1 < NB; ++b1) {
+              double U[NQ];
+#pragma unroll
+              for (int q1 = 0; q1 < NQ; ++q1) U[q1] = (n == 1 ? uD1[b1][q1] : uB1[b1][q1]) * D1[q1];
+#pragma unroll
+              for (int a1 = 0; a1 < NB; ++a1) {
+                double acc = E[g][a1 * NB + b1];
+#pragma unroll
+                for (int q1 = 0; q1 < NQ; ++q1) acc += (m == 1 ? uD1[a1][q1] : uB1[a1][q1]) * U[q1];
+                E[g][a1 * NB + b1] = acc;
+              }
+            }
+            // pin the program order of the contraction blocks (the selector otherwise interleaves
+            // all nine and spills): every E of this block is final before the next block starts
+#pragma unroll
+            for (int c = 0; c < NB2; ++c) WGS_PIN(E[g][c]);
+          }
+        // S3 transposed: rows (a2,b2) = grp + 4 r, columns (a0,b0); then carry in registers
+#pragma unroll
+        for (int a1b1 = 0; a1b1 < NB2; ++a1b1) {
+          mh_d4 Kt = zero4;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Kt = __builtin_amdgcn_mfma_f64_16x16x4f64(E[g][a1b1], aS0[g], Kt, 0, 0, 0);
+#ifdef WGS_EXP_NOCARRY
+          const double c = 0.0;
+#else
+          const double c = C[j][a1b1];
+#endif
+          const double c_rot = rot32_f64(lane, c);       // group 0 sees the row-4 carry parked in group 2
+          const double out0 = Kt[0] + (grp != 2 ? c : 0.0);
+          const double out1 = Kt[1] + (grp == 0 ? c_rot : 0.0);
+          const double out2 = Kt[2];
+          const int off = (a1b1 / NB) * 0 + (a1b1 % NB) * 9 + j;  // + a1 * stride (lane dependent)
+          const int a1 = a1b1 / NB;
+          if (col_ok) ST[base0 + a1 * stride0 + off] = out0;
+          if (col_ok && grp == 2) ST[base1 + a1 * (3 * ND) + off] = out1;
+          // rows 4, 5, 7 -> rows 0, 1, 3 of the next element; row 8 (group 0) -> row 4, parked in group 2
+          const double o2_rot = rot32_f64(lane, out2);
+#ifndef WGS_EXP_NOCARRY
+          C[j][a1b1] = grp == 2 ? o2_rot : out1;
+#else
+          if (o2_rot == 1.2345) ST[0] = o2_rot;
+#endif
+          WGS_PIN(C[j][a1b1]);
+        }
+#ifdef WGS_EXP_NOFLUSH
+        if (false) {
+#else
+        if (j == 2 && valid) {
+#endif
+          // ---- flush: compact slots -> this (element, I)'s dense scratch piece, coalesced -----------
+          __builtin_amdgcn_wave_barrier();
+          double* S = p.scratch_k + ((eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * es)) * 3 + I) * (int64_t)NK;
+          constexpr int NR = (L::n_final + 63) / 64;  // 19
+          double v[NR];
+#pragma unroll
+          for (int c = 0; c < NR; ++c) {
+            const int s = c * 64 + lane;
+            v[c] = s < L::n_final ? ST[s] : 0.0;
+          }
+#pragma unroll
+          for (int c = 0; c < NR; ++c) {
+            const int s = c * 64 + lane;
+            const int t = s - 9 * NROW;
+            const int kk = t < 0 ? s : 9 * NROW + (t / ND) * NROW + t % ND;
+            if (s < L::n_final) S[kk] = v[c];
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (last) {
+            // the carried rows of the last element have no successor: store them as well
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+              for (int a1b1 = 0; a1b1 < NB2; ++a1b1)
+                if (col_ok) ST[basec + (a1b1 / NB) * (3 * 54) + (a1b1 % NB) * 9 + jj] = C[jj][a1b1];
+            __builtin_amdgcn_wave_barrier();
+            constexpr int NRC = (L::n_carry + 63) / 64;  // 16
+#pragma unroll
+            for (int c = 0; c < NRC; ++c) {
+              const int s = c * 64 + lane;
+              if (s < L::n_carry) {
+                const int kk = (9 + s / 54) * NROW + ND + s % 54;
+                S[kk] = ST[s];
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+      wgs_barrier();
+    }
+  }
+}
+
+#ifdef WGS_EXP_SKIP_Y
+template<int I>
+MH_DEV void wgs_y_skip(const TensorArgs& p) {
+  for (int it = 0; it < 6 * (p.box_n[2] + 1); ++it) wgs_barrier();
+}
+#define wgs_y_loop wgs_y_skip
+#define WGS_Y_ARGS p
+#else
+#define WGS_Y_ARGS p, smem_wgs, eu, ev
+#endif
+
+__global__ __launch_bounds__(256, 2) void tensor_wgs_kernel(TensorArgs p) {
+  extern __shared__ __align__(16) double smem_wgs[];
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int unit = blockIdx.x;
+  const int eu = unit % p.box_n[0], ev = unit / p.box_n[0];
+#ifdef WGS_ONLY_X
+  if (true) {
+#elif defined(WGS_ONLY_Y)
+  if (false) {
+#else
+  if (role == 0) {
+#endif
+    int status = 0;
+#ifdef WGS_EXP_SKIP_X
+    for (int it = 0; it < 6 * (p.box_n[2] + 1); ++it) wgs_barrier();
+#else
+    wgs_x_loop(p, smem_wgs, eu, ev, status);
+#endif
+    if (status) atomicOr(p.status, status);
+#ifdef WGS_ONLY_Y
+  } else if (true) {
+#else
+  } else if (role == 1) {
+#endif
+    wgs_y_loop<0>(WGS_Y_ARGS);
+  } else if (role == 2) {
+    wgs_y_loop<1>(WGS_Y_ARGS);
+  } else {
+    wgs_y_loop<2>(WGS_Y_ARGS);
+  }
+}
+
+inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a) {
+  constexpr int NK = 27 * 81;
+  h->scratch_k.resize((size_t)h->n_el * 3 * NK);
+  h->scratch_r.resize((size_t)h->n_el * 3 * 27);
+  a.scratch_k = h->scratch_k.ptr;
+  a.scratch_r = h->scratch_r.ptr;
+  a.n_units_u = a.box_n[0];
+  a.n_units_v = a.box_n[1];
+  const size_t lds = WgsLds::total * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tensor_wgs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(tensor_wgs_kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
+  MH_HIP(hipGetLastError());
+  const int64_t n_nodes = h->n_nodes;
+  hipLaunchKernelGGL(tensor_p2_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, h->stream, a, n_nodes);
+  MH_HIP(hipGetLastError());
+}
+
+}  // namespace mimi_hip

@@ -6,7 +6,7 @@ for d in sys.argv[1:]:
         for r in rows:
             agg[r['Kernel_Name'][:70]][r['Counter_Name']].append(float(r['Counter_Value']))
         for k, v in agg.items():
-            if 'tensor_domain' not in k and 'general' not in k: continue
+            if not any(t in k for t in ('tensor_', 'general', 'contact')): continue
             n = len(next(iter(v.values())))
             print(k, 'dispatches', n, 'VGPR', rows[0].get('VGPR_Count'), 'LDS', rows[0].get('LDS_Block_Size'))
             for c, vals in sorted(v.items()):
