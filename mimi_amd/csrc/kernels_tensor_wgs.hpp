@@ -59,48 +59,143 @@ MH_DEV double rot32_f64(int lane, double v) { return bperm_f64(((lane ^ 32) & 63
 // ------------------------------------------------------------------------------------------------
 // wave X
 // ------------------------------------------------------------------------------------------------
-template<int I>
-MH_DEV void wgs_x_row(const TensorArgs& p, double* lds, int lane, int64_t e, int par, const PointResult<3>& w,
-                      const double* Ji, double wd) {
+// What wave X keeps per quadrature point between its three steps.  KIND is the material kind as a
+// compile-time constant: the fields the other material needs are then dead, and so is its code.
+template<int KIND>
+struct WgsPoint;
+
+// Neo-Hookean, closed form of the pulled-back tangent: with G = Jinv F^-1 (G[m][i] = sum_J Jinv[m][J] Finv[J][i])
+// and M = Jinv Jinv^T, from dP_iJ/dF_jL = mu d_ij d_JL - c1 Finv_Li Finv_Jj + c2 Finv_Lj Finv_Ji
+// (materials.hpp tangent_of):
+//   Ahat_i[m][j][n] = wd (mu d_ij M[m][n] - c1 G[n][i] G[m][j] + c2 G[n][j] G[m][i])
+template<>
+struct WgsPoint<MIMI_HIP_MAT_NEOHOOKEAN> {
+  double G[9], M[6], Phat[9];  // Phat[i*3 + m]
+  double mu_w, c1_w, c2_w;     // coefficients times wd
+};
+
+template<>
+struct WgsPoint<MIMI_HIP_MAT_J2> {
+  PointResult<3> w;
+  double Ji[9], wd;
+};
+
+template<int KIND>
+MH_DEV int wgs_x_point(const TensorArgs& p, int64_t pt, const double* F, const double* Ji, double wd, WgsPoint<KIND>& s) {
+  if constexpr (KIND == MIMI_HIP_MAT_NEOHOOKEAN) {
+    PointResult<3> w;
+    neo_hookean_stress<3>(p.mat.m, F, w);
+    const double J = w.detF;
+    s.mu_w = wd * p.mat.m.mu;
+    s.c1_w = wd * (p.mat.m.lambda * J * (J - 1.) - p.mat.m.mu);
+    s.c2_w = wd * (p.mat.m.lambda * (2. * J - 1.) * J);
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        double g = 0.0;
+#pragma unroll
+        for (int Jx = 0; Jx < 3; ++Jx) g += Ji[m * 3 + Jx] * w.Finv[Jx + i * 3];
+        s.G[m * 3 + i] = g;
+      }
+    {
+      int c = 0;
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int n = m; n < 3; ++n) {
+          double v = 0.0;
+#pragma unroll
+          for (int Jx = 0; Jx < 3; ++Jx) v += Ji[m * 3 + Jx] * Ji[n * 3 + Jx];
+          s.M[c++] = v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        double sp = 0.0;
+#pragma unroll
+        for (int Jx = 0; Jx < 3; ++Jx) sp += w.P[i + Jx * 3] * Ji[m * 3 + Jx];
+        s.Phat[i * 3 + m] = wd * sp;
+      }
+    return 0;
+  } else {
+    MaterialDev mat = p.mat;
+    mat.m.kind = KIND;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s.Ji[k] = Ji[k];
+    s.wd = wd;
+    return evaluate_pk1<3>(mat, p.dt, p.state, pt, F, s.w);
+  }
+}
+
+// row I of one element: Ahat_I -> LDS (lane = quadrature point), residual piece -> scratch_r
+template<int KIND, int I>
+MH_DEV void wgs_x_row(const TensorArgs& p, double* lds, int lane, int64_t e, int par, const WgsPoint<KIND>& s) {
   using L = WgsLds;
   constexpr int P = 2, NB = 3, NQ = 4, NB2 = 9, ND = 27, NQ3 = 64;
   const double* tab = lds + L::off_tab + par * 6 * NB * NQ;
   double* AH = lds + L::off_ah + I * ND * NQ3;
   double* RS = lds + L::off_r;
   double Phat[3];
+  if constexpr (KIND == MIMI_HIP_MAT_NEOHOOKEAN) {
 #pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    double sp = 0.0;
+    for (int m = 0; m < 3; ++m) Phat[m] = s.Phat[I * 3 + m];
 #pragma unroll
-    for (int J = 0; J < 3; ++J) sp += w.P[I + J * 3] * Ji[m * 3 + J];
-    Phat[m] = wd * sp;
-  }
-  {
+    for (int m = 0; m < 3; ++m) {
+      const double c2gm = s.c2_w * s.G[m * 3 + I];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const double c1gm = s.c1_w * s.G[m * 3 + j];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          double v = c2gm * s.G[n * 3 + j] - c1gm * s.G[n * 3 + I];
+          if (I == j) {
+            const int lo = m < n ? m : n, hi = m < n ? n : m;
+            v += s.mu_w * s.M[lo * 3 - lo * (lo - 1) / 2 + (hi - lo)];
+          }
+          AH[((m * 3 + j) * 3 + n) * NQ3 + lane] = v;
+        }
+      }
+    }
+  } else {
+    const double* Ji = s.Ji;
+    const double wd = s.wd;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      double sp = 0.0;
+#pragma unroll
+      for (int J = 0; J < 3; ++J) sp += s.w.P[I + J * 3] * Ji[m * 3 + J];
+      Phat[m] = wd * sp;
+    }
+    mimi_hip_material mm = p.mat.m;
+    mm.kind = KIND;
     double A[27];
-    tangent_row_of<3, I>(p.mat.m, w, A);
-    double T[27];
+    tangent_row_of<3, I>(mm, s.w, A);
+    // one column component j at a time: T[J][n] = sum_L A[J][j][L] Jinv[n][L], then Ahat[m][j][n]
 #pragma unroll
-    for (int J = 0; J < 3; ++J)
+    for (int j = 0; j < 3; ++j) {
+      double T[9];
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
+      for (int J = 0; J < 3; ++J)
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
           double st = 0.0;
 #pragma unroll
           for (int Lx = 0; Lx < 3; ++Lx) st += A[(J * 3 + j) * 3 + Lx] * Ji[n * 3 + Lx];
-          T[(J * 3 + j) * 3 + n] = st;
+          T[J * 3 + n] = st;
         }
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
+      for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
           double sa = 0.0;
 #pragma unroll
-          for (int J = 0; J < 3; ++J) sa += Ji[m * 3 + J] * T[(J * 3 + j) * 3 + n];
+          for (int J = 0; J < 3; ++J) sa += Ji[m * 3 + J] * T[J * 3 + n];
           AH[((m * 3 + j) * 3 + n) * NQ3 + lane] = wd * sa;
         }
+    }
   }
   // residual row I by sum factorisation (as kernels_tensor_2phase.hpp)
   double* PH = RS;                   // [3 m][64]
@@ -147,6 +242,7 @@ MH_DEV void wgs_x_row(const TensorArgs& p, double* lds, int lane, int64_t e, int
   __builtin_amdgcn_wave_barrier();
 }
 
+template<int KIND>
 MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& status) {
   using L = WgsLds;
   constexpr int P = 2, NB = 3, NQ = 4, ND = 27, NQ3 = 64;
@@ -154,52 +250,50 @@ MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& st
   const int lane = threadIdx.x & 63;
   double* ue = lds + L::off_ue;
   const int n_seq = p.box_n[2];
-  auto element_of = [&](int es, int* el) -> int64_t {
-    el[0] = eu;
-    el[1] = ev;
-    el[2] = es;
-    return el[0] + (int64_t)p.box_n[0] * (el[1] + (int64_t)p.box_n[1] * el[2]);
-  };
-  auto table_src = [&](const int* el, int t) -> const double* {
+  auto element_at = [&](int es) -> int64_t { return eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * es); };
+  auto table_src = [&](int es, int t) -> const double* {
     const int dir = t / (2 * NB * NQ);
     const int rem = t % (2 * NB * NQ);
     const int isD = rem / (NB * NQ);
     const int k = rem % (NB * NQ);
-    const int span = (dir == 0 ? p.box_begin[0] + el[0] : dir == 1 ? p.box_begin[1] + el[1] : p.box_begin[2] + el[2]);
+    const int span = (dir == 0 ? p.box_begin[0] + eu : dir == 1 ? p.box_begin[1] + ev : p.box_begin[2] + es);
     return (isD ? (dir == 0 ? p.tabD[0] : dir == 1 ? p.tabD[1] : p.tabD[2])
                 : (dir == 0 ? p.tabB[0] : dir == 1 ? p.tabB[1] : p.tabB[2])) + (int64_t)span * NB * NQ + k;
   };
-
-  // prologue: element 0 into registers, connectivity of element 1
-  int el_c[3], el_n[3];
-  int64_t e_cur = element_of(0, el_c);
-  int32_t node_c = lane < ND ? p.dofs[e_cur * ND + lane] : 0, node_n = 0;
+  // The operands of an element are requested at the END of the previous element's last step (they are
+  // in flight across the two barriers, not across the row computations, which need the registers);
+  // the connectivity one element earlier still.
+  int32_t node_n = lane < ND ? p.dofs[element_at(0) * ND + lane] : 0;
   double ue_r[3], tab_r[TROUNDS], geo_r[10];
+  auto request = [&](int es) {
+    const int64_t e_n = element_at(es);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) ue_r[c] = p.u[(int64_t)node_c * 3 + c];
+    for (int c = 0; c < 3; ++c) ue_r[c] = p.u[(int64_t)node_n * 3 + c];
 #pragma unroll
-  for (int rd = 0; rd < TROUNDS; ++rd) {
-    const int t = rd * 64 + lane;
-    tab_r[rd] = *table_src(el_c, t < 6 * NB * NQ ? t : 0);
-  }
-  {
-    const double* g = p.geo + e_cur * 10 * NQ3 + lane;
+    for (int rd = 0; rd < TROUNDS; ++rd) {
+      const int t = rd * 64 + lane;
+      tab_r[rd] = *table_src(es, t < 6 * NB * NQ ? t : 0);
+    }
+    const double* g = p.geo + e_n * 10 * NQ3 + lane;
 #pragma unroll
     for (int k = 0; k < 10; ++k) geo_r[k] = g[(int64_t)k * NQ3];
-  }
-  if (n_seq > 1) {
-    const int64_t e1 = element_of(1, el_n);
-    node_n = lane < ND ? p.dofs[e1 * ND + lane] : 0;
-  }
+    if (es + 1 < n_seq) node_n = lane < ND ? p.dofs[element_at(es + 1) * ND + lane] : 0;
+  };
+  request(0);
 
-  PointResult<3> w;
-  double Ji[9], wd = 0.0;
+  WgsPoint<KIND> s;
   int64_t e = 0;
+#ifdef MH_PROFILE
+  unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last)::"memory");
+#endif
   for (int it = 0; it <= n_seq; ++it) {
     const bool valid = it < n_seq;
     const int par = it & 1;
     // ---- step 0: quadrature-point stage + row 0 ------------------------------------------------
     wgs_barrier();
+    MH_STAMP(0);
     if (valid) {
       double* tab = lds + L::off_tab + par * 6 * NB * NQ;
       if (lane < ND) {
@@ -211,31 +305,14 @@ MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& st
         const int t = rd * 64 + lane;
         if (t < 6 * NB * NQ) tab[t] = tab_r[rd];
       }
+      double Ji[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k) Ji[k] = geo_r[k];
-      wd = geo_r[9];
-      e = e_cur;
+      const double wd = geo_r[9];
+      e = element_at(it);
       __builtin_amdgcn_wave_barrier();
-      // loads of the next element, in flight during the three steps of this one
-      if (it + 1 < n_seq) {
-        e_cur = element_of(it + 1, el_c);
-        node_c = node_n;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) ue_r[c] = p.u[(int64_t)node_c * 3 + c];
-#pragma unroll
-        for (int rd = 0; rd < TROUNDS; ++rd) {
-          const int t = rd * 64 + lane;
-          tab_r[rd] = *table_src(el_c, t < 6 * NB * NQ ? t : 0);
-        }
-        const double* g = p.geo + e_cur * 10 * NQ3 + lane;
-#pragma unroll
-        for (int k = 0; k < 10; ++k) geo_r[k] = g[(int64_t)k * NQ3];
-        if (it + 2 < n_seq) {
-          const int64_t e2 = element_of(it + 2, el_n);
-          node_n = lane < ND ? p.dofs[e2 * ND + lane] : 0;
-        }
-      }
       // F at the quadrature point of this lane, q = q0 + 4 q1 + 16 q2
+      double F[9];
       {
         const int q0 = lane & 3, q1 = (lane >> 2) & 3, q2 = lane >> 4;
         double b0[NB], d0[NB], b1[NB], d1[NB], b2[NB], d2[NB];
@@ -269,7 +346,6 @@ MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& st
               }
             }
           }
-        double F[9];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -279,20 +355,36 @@ MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& st
             for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * Ji[m * 3 + J];
             F[i + J * 3] = sf;
           }
-        status |= evaluate_pk1<3>(p.mat, p.dt, p.state, e * NQ3 + lane, F, w);
       }
-      wgs_x_row<0>(p, lds, lane, e, par, w, Ji, wd);
+      status |= wgs_x_point<KIND>(p, e * NQ3 + lane, F, Ji, wd, s);
+      MH_STAMP(1);
+      wgs_x_row<KIND, 0>(p, lds, lane, e, par, s);
+      MH_STAMP(2);
     }
     wgs_barrier();
+    MH_STAMP(3);
     // ---- step 1: row 1 ---------------------------------------------------------------------------
     wgs_barrier();
-    if (valid) wgs_x_row<1>(p, lds, lane, e, par, w, Ji, wd);
+    MH_STAMP(0);
+    if (valid) wgs_x_row<KIND, 1>(p, lds, lane, e, par, s);
+    MH_STAMP(2);
     wgs_barrier();
-    // ---- step 2: row 2 ---------------------------------------------------------------------------
+    MH_STAMP(3);
+    // ---- step 2: row 2, then the requests of the next element ---------------------------------------
     wgs_barrier();
-    if (valid) wgs_x_row<2>(p, lds, lane, e, par, w, Ji, wd);
+    MH_STAMP(0);
+    if (valid) {
+      wgs_x_row<KIND, 2>(p, lds, lane, e, par, s);
+      if (it + 1 < n_seq) request(it + 1);
+    }
+    MH_STAMP(2);
     wgs_barrier();
+    MH_STAMP(3);
   }
+#ifdef MH_PROFILE
+  if (lane == 0 && p.prof)
+    for (int k = 0; k < 6; ++k) atomicAdd(&p.prof[k], prof_acc[k]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -355,6 +447,11 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
       lds[L::off_tab + 6 * NB * NQ + 64 + lane] = 0.0;
     }
   }
+#ifdef MH_PROFILE
+  unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last)::"memory");
+#endif
   for (int it = 0; it <= n_seq; ++it) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -401,7 +498,9 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
 #pragma unroll
           for (int n = 0; n < 3; ++n) ah[m * 3 + n] = AH[((m * 3 + j) * 3 + n) * NQ3 + lane];
       }
+      MH_STAMP(6);
       wgs_barrier();
+      MH_STAMP(7);
       // ---- compute window ------------------------------------------------------------------------
       {
         const bool last = es + 1 >= n_seq;
@@ -436,6 +535,7 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
 #pragma unroll
             for (int c = 0; c < NB2; ++c) WGS_PIN(E[g][c]);
           }
+        MH_STAMP(8);
         // S3 transposed: rows (a2,b2) = grp + 4 r, columns (a0,b0); then carry in registers
 #pragma unroll
         for (int a1b1 = 0; a1b1 < NB2; ++a1b1) {
@@ -464,6 +564,7 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
 #endif
           WGS_PIN(C[j][a1b1]);
         }
+        MH_STAMP(9);
 #ifdef WGS_EXP_NOFLUSH
         if (false) {
 #else
@@ -507,10 +608,16 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
             __builtin_amdgcn_wave_barrier();
           }
         }
+        MH_STAMP(10);
       }
       wgs_barrier();
+      MH_STAMP(11);
     }
   }
+#ifdef MH_PROFILE
+  if (I == 0 && lane == 0 && p.prof)
+    for (int k = 6; k < 12; ++k) atomicAdd(&p.prof[k], prof_acc[k]);
+#endif
 }
 
 #ifdef WGS_EXP_SKIP_Y
@@ -524,6 +631,7 @@ MH_DEV void wgs_y_skip(const TensorArgs& p) {
 #define WGS_Y_ARGS p, smem_wgs, eu, ev
 #endif
 
+template<int KIND>
 __global__ __launch_bounds__(256, 2) void tensor_wgs_kernel(TensorArgs p) {
   extern __shared__ __align__(16) double smem_wgs[];
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -540,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void tensor_wgs_kernel(TensorArgs p) {
 #ifdef WGS_EXP_SKIP_X
     for (int it = 0; it < 6 * (p.box_n[2] + 1); ++it) wgs_barrier();
 #else
-    wgs_x_loop(p, smem_wgs, eu, ev, status);
+    wgs_x_loop<KIND>(p, smem_wgs, eu, ev, status);
 #endif
     if (status) atomicOr(p.status, status);
 #ifdef WGS_ONLY_Y
@@ -565,12 +673,9 @@ inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a) {
   a.n_units_u = a.box_n[0];
   a.n_units_v = a.box_n[1];
   const size_t lds = WgsLds::total * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(tensor_wgs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(tensor_wgs_kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
+  auto kernel = h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN ? tensor_wgs_kernel<MIMI_HIP_MAT_NEOHOOKEAN> : tensor_wgs_kernel<MIMI_HIP_MAT_J2>;
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
   MH_HIP(hipGetLastError());
   const int64_t n_nodes = h->n_nodes;
   hipLaunchKernelGGL(tensor_p2_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, h->stream, a, n_nodes);
