@@ -48,13 +48,25 @@ struct WgsLds {
 };
 
 #define WGS_PIN(x) asm volatile("" : "+v"(x))
+#ifndef WGS_S3_GROUP
+#define WGS_S3_GROUP 3
+#endif
 
 MH_DEV void wgs_barrier() {
   // LDS hand-off only: outstanding global loads / stores need not drain here
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-MH_DEV double rot32_f64(int lane, double v) { return bperm_f64(((lane ^ 32) & 63) * 4, v); }
+// v_permlane32_swap(a, b) -> ([a.lo, b.lo], [a.hi, b.hi]) (halves of 32 lanes; checked on gfx950,
+// scratch/pl/pl_test.hip).  One pair of swaps gives both rotations the carry needs:
+//   c_hi_in_lo : lanes 0..31 hold c of lanes 32..63      o_lo_in_hi : lanes 32..63 hold o of lanes 0..31
+MH_DEV void swap32_f64(double c, double o, double& c_hi_in_lo, double& o_lo_in_hi) {
+  const unsigned long long uc = __double_as_longlong(c), uo = __double_as_longlong(o);
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)uc, (unsigned)uo, false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(uc >> 32), (unsigned)(uo >> 32), false, false);
+  o_lo_in_hi = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]);
+  c_hi_in_lo = __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+}
 
 // ------------------------------------------------------------------------------------------------
 // wave X
@@ -504,88 +516,119 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
       // ---- compute window ------------------------------------------------------------------------
       {
         const bool last = es + 1 >= n_seq;
-        // S1 + S2 (see kernels_tensor_2phase.hpp): E_g[a1b1], lane = (q0 on bits 5:4, a2b2 on bits 3:0)
-        double E[4][NB2];
+        // S1 (matrix pipe): D1[(m,n)][q1 | q0, a2b2] = sum_q2 Ahat(m,j,n)(q0 q1; q2) TT2[q2][a2b2]
+        mh_d4 D1[9];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int c = 0; c < NB2; ++c) E[g][c] = 0.0;
-#pragma unroll
-        for (int m = 0; m < 3; ++m)
-#pragma unroll
-          for (int n = 0; n < 3; ++n) {
-            const int v2 = (m == 2 ? 1 : 0) + (n == 2 ? 2 : 0);
-            const int g = (m == 0 ? 1 : 0) + (n == 0 ? 2 : 0);
-            const mh_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[m * 3 + n], aS2[v2], zero4, 0, 0, 0);
-#pragma unroll
-            for (int b1 = 0; b1 < NB; ++b1) {
-              double U[NQ];
-#pragma unroll
-              for (int q1 = 0; q1 < NQ; ++q1) U[q1] = (n == 1 ? uD1[b1][q1] : uB1[b1][q1]) * D1[q1];
-#pragma unroll
-              for (int a1 = 0; a1 < NB; ++a1) {
-                double acc = E[g][a1 * NB + b1];
-#pragma unroll
-                for (int q1 = 0; q1 < NQ; ++q1) acc += (m == 1 ? uD1[a1][q1] : uB1[a1][q1]) * U[q1];
-                E[g][a1 * NB + b1] = acc;
-              }
-            }
-            // pin the program order of the contraction blocks (the selector otherwise interleaves
-            // all nine and spills): every E of this block is final before the next block starts
-#pragma unroll
-            for (int c = 0; c < NB2; ++c) WGS_PIN(E[g][c]);
-          }
-        MH_STAMP(8);
-        // S3 transposed: rows (a2,b2) = grp + 4 r, columns (a0,b0); then carry in registers
-#pragma unroll
-        for (int a1b1 = 0; a1b1 < NB2; ++a1b1) {
-          mh_d4 Kt = zero4;
-#pragma unroll
-          for (int g = 0; g < 4; ++g) Kt = __builtin_amdgcn_mfma_f64_16x16x4f64(E[g][a1b1], aS0[g], Kt, 0, 0, 0);
-#ifdef WGS_EXP_NOCARRY
-          const double c = 0.0;
-#else
-          const double c = C[j][a1b1];
-#endif
-          const double c_rot = rot32_f64(lane, c);       // group 0 sees the row-4 carry parked in group 2
-          const double out0 = Kt[0] + (grp != 2 ? c : 0.0);
-          const double out1 = Kt[1] + (grp == 0 ? c_rot : 0.0);
-          const double out2 = Kt[2];
-          const int off = (a1b1 / NB) * 0 + (a1b1 % NB) * 9 + j;  // + a1 * stride (lane dependent)
-          const int a1 = a1b1 / NB;
-          if (col_ok) ST[base0 + a1 * stride0 + off] = out0;
-          if (col_ok && grp == 2) ST[base1 + a1 * (3 * ND) + off] = out1;
-          // rows 4, 5, 7 -> rows 0, 1, 3 of the next element; row 8 (group 0) -> row 4, parked in group 2
-          const double o2_rot = rot32_f64(lane, out2);
-#ifndef WGS_EXP_NOCARRY
-          C[j][a1b1] = grp == 2 ? o2_rot : out1;
-#else
-          if (o2_rot == 1.2345) ST[0] = o2_rot;
-#endif
-          WGS_PIN(C[j][a1b1]);
+        for (int mn = 0; mn < 9; ++mn) {
+          const int m = mn / 3, n = mn % 3;
+          const int v2 = (m == 2 ? 1 : 0) + (n == 2 ? 2 : 0);
+          D1[mn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[mn], aS2[v2], zero4, 0, 0, 0);
         }
+        // S2 (vector pipe) and S3 (matrix pipe) software-pipelined over b1: while the matrix pipe
+        // contracts q0 for the three (a1, b1) of one b1, the vector pipe contracts q1 for the next b1.
+        //   S2: E_g[a1] = sum_(m,n) sum_q1 T1^m[a1][q1] T1^n[b1][q1] D1[(m,n)][q1]   (g = direction-0 variant)
+        //   S3: Kt[a1][(a2,b2) rows | (a0,b0) cols] = sum_g sum_q0 E_g[a1][q0 | a2b2] TT0^g[q0][a0b0]
+        // then the carry in registers: rows 4, 5, 7 -> rows 0, 1, 3 of the next element; row 8 (group 0)
+        // -> row 4, parked in the lanes of group 2 (whose own row 2 receives nothing).
+        mh_d4 Kt[NB];
+        auto carry_and_stage = [&](int b1) {
+#pragma unroll
+          for (int a1 = 0; a1 < NB; ++a1) {
+            const int a1b1 = a1 * NB + b1;
+            const double cin = C[j][a1b1];
+            double c_rot, o2_rot;
+            swap32_f64(cin, Kt[a1][2], c_rot, o2_rot);
+            const double out0 = Kt[a1][0] + (grp != 2 ? cin : 0.0);
+            const double out1 = Kt[a1][1] + (grp == 0 ? c_rot : 0.0);
+            const int off = b1 * 9 + j;
+            if (col_ok) ST[base0 + a1 * stride0 + off] = out0;
+            if (col_ok && grp == 2) ST[base1 + a1 * (3 * ND) + off] = out1;
+            C[j][a1b1] = grp == 2 ? o2_rot : out1;
+          }
+        };
+#pragma unroll
+        for (int b1 = 0; b1 < NB; ++b1) {
+          double Ec[4][NB];
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int a1 = 0; a1 < NB; ++a1) Ec[g][a1] = 0.0;
+#ifdef WGS_EXP_NO_S2
+#pragma unroll
+          for (int mn = 0; mn < 9; ++mn) Ec[mn & 3][mn % 3] += D1[mn][b1];
+#else
+#pragma unroll
+          for (int mn = 0; mn < 9; ++mn) {
+            const int m = mn / 3, n = mn % 3;
+            const int g = (m == 0 ? 1 : 0) + (n == 0 ? 2 : 0);
+            double U[NQ];
+#pragma unroll
+            for (int q1 = 0; q1 < NQ; ++q1) U[q1] = (n == 1 ? uD1[b1][q1] : uB1[b1][q1]) * D1[mn][q1];
+#pragma unroll
+            for (int a1 = 0; a1 < NB; ++a1) {
+              double acc = Ec[g][a1];
+#pragma unroll
+              for (int q1 = 0; q1 < NQ; ++q1) acc += (m == 1 ? uD1[a1][q1] : uB1[a1][q1]) * U[q1];
+              Ec[g][a1] = acc;
+            }
+          }
+#endif
+          // the previous b1's matrix results are due by now
+          if (b1 > 0) carry_and_stage(b1 - 1);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int a1 = 0; a1 < NB; ++a1) WGS_PIN(Ec[g][a1]);
+#ifdef WGS_EXP_NO_S3
+#pragma unroll
+          for (int a1 = 0; a1 < NB; ++a1) {
+            Kt[a1][0] = Ec[0][a1] + aS0[0];
+            Kt[a1][1] = Ec[1][a1] + aS0[1];
+            Kt[a1][2] = Ec[2][a1] + aS0[2];
+            Kt[a1][3] = Ec[3][a1] + aS0[3];
+          }
+#else
+#pragma unroll
+          for (int a1 = 0; a1 < NB; ++a1) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ec[0][a1], aS0[0], zero4, 0, 0, 0);
+#pragma unroll
+          for (int g = 1; g < 4; ++g)
+#pragma unroll
+            for (int a1 = 0; a1 < NB; ++a1) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ec[g][a1], aS0[g], Kt[a1], 0, 0, 0);
+#endif
+        }
+        carry_and_stage(NB - 1);
+        MH_STAMP(8);
+        (void)last;
         MH_STAMP(9);
 #ifdef WGS_EXP_NOFLUSH
         if (false) {
 #else
         if (j == 2 && valid) {
 #endif
-          // ---- flush: compact slots -> this (element, I)'s dense scratch piece, coalesced -----------
+          // ---- flush: compact slots -> this (element, I)'s dense scratch piece ---------------------
+          // Affine addressing only (uniform base + lane + immediate): slots s < 729 map to themselves;
+          // the 18 rows of 27 after them go to the first 27 entries of rows 9..26 of the piece.
           __builtin_amdgcn_wave_barrier();
           double* S = p.scratch_k + ((eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * es)) * 3 + I) * (int64_t)NK;
-          constexpr int NR = (L::n_final + 63) / 64;  // 19
-          double v[NR];
+          {
+            constexpr int NA = (9 * NROW + 63) / 64;  // 12
+            double v[NA];
 #pragma unroll
-          for (int c = 0; c < NR; ++c) {
-            const int s = c * 64 + lane;
-            v[c] = s < L::n_final ? ST[s] : 0.0;
+            for (int c = 0; c < NA; ++c) v[c] = ST[c * 64 + (c * 64 + 63 < 9 * NROW ? lane : (lane < 9 * NROW - c * 64 ? lane : 0))];
+#pragma unroll
+            for (int c = 0; c < NA; ++c)
+              if (c * 64 + 63 < 9 * NROW || lane < 9 * NROW - c * 64) S[(unsigned)(c * 64 + lane)] = v[c];
           }
+          {
+            // two rows of 27 per instruction: lanes 0..53
+            const unsigned l54 = lane < 54 ? lane : 0;
+            const unsigned gofs = 9 * NROW + (l54 >= ND ? NROW + l54 - ND : l54);
+            double v[9];
 #pragma unroll
-          for (int c = 0; c < NR; ++c) {
-            const int s = c * 64 + lane;
-            const int t = s - 9 * NROW;
-            const int kk = t < 0 ? s : 9 * NROW + (t / ND) * NROW + t % ND;
-            if (s < L::n_final) S[kk] = v[c];
+            for (int c = 0; c < 9; ++c) v[c] = ST[9 * NROW + 54 * c + l54];
+#pragma unroll
+            for (int c = 0; c < 9; ++c)
+              if (lane < 54) S[gofs + (unsigned)(c * 2 * NROW)] = v[c];
           }
           __builtin_amdgcn_wave_barrier();
           if (last) {
@@ -596,14 +639,12 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
               for (int a1b1 = 0; a1b1 < NB2; ++a1b1)
                 if (col_ok) ST[basec + (a1b1 / NB) * (3 * 54) + (a1b1 % NB) * 9 + jj] = C[jj][a1b1];
             __builtin_amdgcn_wave_barrier();
-            constexpr int NRC = (L::n_carry + 63) / 64;  // 16
+            // 18 rows of 54 (b2 = 1, 2): slot 54 r + l -> entry (9 + r) 81 + 27 + l
+            const unsigned l54 = lane < 54 ? lane : 0;
 #pragma unroll
-            for (int c = 0; c < NRC; ++c) {
-              const int s = c * 64 + lane;
-              if (s < L::n_carry) {
-                const int kk = (9 + s / 54) * NROW + ND + s % 54;
-                S[kk] = ST[s];
-              }
+            for (int r = 0; r < 18; ++r) {
+              const double v = ST[54 * r + l54];
+              if (lane < 54) S[(unsigned)((9 + r) * NROW + ND) + l54] = v;
             }
             __builtin_amdgcn_wave_barrier();
           }
@@ -634,7 +675,12 @@ MH_DEV void wgs_y_skip(const TensorArgs& p) {
 template<int KIND>
 __global__ __launch_bounds__(256, 2) void tensor_wgs_kernel(TensorArgs p) {
   extern __shared__ __align__(16) double smem_wgs[];
-  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // Wave w of a workgroup lands on SIMD w; the point wave idles more than the contraction waves, so
+  // the role of a wave rotates with the workgroup and every SIMD hosts a mix of roles.
+#ifndef WGS_ROT
+#define WGS_ROT(b) ((b) >> 3)
+#endif
+  const int role = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) + WGS_ROT(blockIdx.x)) & 3);
   const int unit = blockIdx.x;
   const int eu = unit % p.box_n[0], ev = unit / p.box_n[0];
 #ifdef WGS_ONLY_X
