@@ -429,11 +429,23 @@ __global__ __launch_bounds__(64) void tensor_p1_kernel(TensorArgs p) {
 
 // phase 2: gather.  Requires: lexicographic numbering, structured CSR, first[e] == e (no repeated
 // interior knots), walk axis == 2.
+//
+// One wave per node A (its three CSR rows).  The wave walks the <= 27 elements that contain A; of
+// each piece (element, i) it needs row a = local index of A: 81 contiguous doubles [b2][b1][b0][j]
+// (or the first 27, b2 = 0, when the element is not the one that stored the (a2 >= 1) entries).
+// lane = position in that row, so the reads are contiguous runs; the position of (b, j) in A's CSR
+// row is  t = t_base(element) + t_off(lane)  with a per-lane constant t_off.  Row sums are built
+// in LDS (one wave adds piece after piece: fixed order, no conflicts inside an instruction), then
+// A[row] += grad_factor * sum is one coalesced read-modify-write per row.
 __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_nodes) {
   constexpr int P = 2, NB = 3, ND = 27, NROW = 81, NK = ND * NROW;
-  const int64_t A = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int LMAX = 3 * 125;
+  __shared__ double sums_all[4][3][LMAX + 1];
+  const int wave = threadIdx.x >> 6;
+  const int64_t A = (int64_t)blockIdx.x * 4 + wave;
   const int lane = threadIdx.x & 63;
   if (A >= n_nodes) return;
+  double (*sums)[LMAX + 1] = sums_all[wave];
   const int n0 = p.n_ctrl[0], n1 = p.n_ctrl[1], n2 = p.n_ctrl[2];
   const int A0 = A % n0, A1 = (A / n0) % n1, A2 = A / ((int64_t)n0 * n1);
   // elements of THIS shard containing node A: e_d in [A_d - P, A_d] clipped to the box
@@ -449,41 +461,80 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
   auto elem = [&](int ex, int ey, int ez) -> int64_t {
     return (ex - bx0) + (int64_t)p.box_n[0] * ((ey - bx1) + (int64_t)p.box_n[1] * (ez - bx2));
   };
+  for (int t = lane; t < L; t += 64) {
+    sums[0][t] = 0.0;
+    sums[1][t] = 0.0;
+    sums[2][t] = 0.0;
+  }
+  // lane constants: row positions k0 = lane and k1 = lane + 64 (< 81), k = ((b2 3 + b1) 3 + b0) 3 + j
+  const int k1 = lane + 64;
+  const int toff0 = 3 * ((lane / 3) % 3 + w0 * ((lane / 9) % 3 + w1 * (lane / 27))) + lane % 3;
+  const int toff1 = 3 * ((k1 / 3) % 3 + w0 * ((k1 / 9) % 3 + w1 * (k1 / 27))) + k1 % 3;
+  __builtin_amdgcn_wave_barrier();
+  for (int ez = ez_lo; ez <= ez_hi; ++ez) {
+    const int a2 = A2 - ez;
+    const int nb = (a2 == 0 || ez == last_ez) ? NROW : ND;
+    const bool act0 = lane < nb, act1 = k1 < nb;
+    // P2_BATCH pieces in flight per wave (registers against occupancy)
+#ifndef P2_BATCH
+#define P2_BATCH 3
+#endif
+    for (int c0 = 0; c0 < 9; c0 += P2_BATCH) {
+      double v0[P2_BATCH][3], v1[P2_BATCH][3];
+#pragma unroll
+      for (int cc = 0; cc < P2_BATCH; ++cc) {
+        const int c = c0 + cc;
+        const int ey = ey_lo + c / 3, ex = ex_lo + c % 3;
+        const bool in = c < 9 && ey <= ey_hi && ex <= ex_hi;
+        const int a = (A0 - ex) + NB * ((A1 - ey) + NB * a2);
+        const double* src = p.scratch_k + (elem(in ? ex : ex_lo, in ? ey : ey_lo, ez) * 3) * (int64_t)NK + (in ? a : 0) * NROW;
+#pragma unroll
+        for (int I = 0; I < 3; ++I) {
+          v0[cc][I] = (in && act0) ? src[I * NK + lane] : 0.0;
+          v1[cc][I] = (in && act1) ? src[I * NK + k1] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < P2_BATCH; ++cc) {
+        const int c = c0 + cc;
+        const int ey = ey_lo + c / 3, ex = ex_lo + c % 3;
+        const bool in = c < 9 && ey <= ey_hi && ex <= ex_hi;
+        const int tbase = 3 * ((ex - lo0) + w0 * ((ey - lo1) + w1 * (ez - lo2)));
+        if (in) {
+#pragma unroll
+          for (int I = 0; I < 3; ++I) {
+            if (act0) sums[I][tbase + toff0] += v0[cc][I];
+            if (act1) sums[I][tbase + toff1] += v1[cc][I];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
   for (int I = 0; I < 3; ++I) {
     double* row = p.A + p.rowptr[A * 3 + I];
-    for (int t = lane; t < L; t += 64) {
-      const int j = t % 3;
-      int nb = t / 3;
-      const int B0 = lo0 + nb % w0;
-      nb /= w0;
-      const int B1 = lo1 + nb % w1;
-      const int B2 = lo2 + nb / w1;
-      // the storing element of pair (A, B) in a column: the highest one containing both nodes
-      const int ez = min(min(A2, B2), last_ez);
-      double s = 0.0;
-      if (ez >= max(max(A2, B2) - P, bx2)) {
-        const int a2 = A2 - ez, b2 = B2 - ez;
-        const int cx_lo = max(max(A0, B0) - P, bx0), cx_hi = min(min(A0, B0), bx0 + p.box_n[0] - 1);
-        const int cy_lo = max(max(A1, B1) - P, bx1), cy_hi = min(min(A1, B1), bx1 + p.box_n[1] - 1);
-        for (int ey = cy_lo; ey <= cy_hi; ++ey)
-          for (int ex = cx_lo; ex <= cx_hi; ++ex) {
-            const int a = (A0 - ex) + NB * ((A1 - ey) + NB * a2);
-            const int slot = a * NROW + (b2 * NB + (B1 - ey)) * 9 + (B0 - ex) * 3 + j;
-            s += p.scratch_k[(elem(ex, ey, ez) * 3 + I) * (int64_t)NK + slot];
-          }
-      }
-      row[t] += p.grad_factor * s;
+    for (int t = lane; t < L; t += 64) row[t] += p.grad_factor * sums[I][t];
+  }
+  // residual rows: lane = element (dz, dy, dx) of the 3 x 3 x 3 neighbourhood, fixed-shape tree sum
+  {
+    const int dz = lane / 9, dy = (lane / 3) % 3, dx = lane % 3;
+    const int ez = ez_lo + dz, ey = ey_lo + dy, ex = ex_lo + dx;
+    const bool in = lane < ND && ez <= ez_hi && ey <= ey_hi && ex <= ex_hi;
+    const int a = in ? (A0 - ex) + NB * ((A1 - ey) + NB * (A2 - ez)) : 0;
+    const int64_t e = in ? elem(ex, ey, ez) : 0;
+    double rs[3];
+#pragma unroll
+    for (int I = 0; I < 3; ++I) rs[I] = in ? p.scratch_r[(e * 3 + I) * ND + a] : 0.0;
+#pragma unroll
+    for (int I = 0; I < 3; ++I) {
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) rs[I] += __shfl_down(rs[I], off, 32);
     }
-    // residual row: sum of the element residual pieces
     if (lane == 0) {
-      double s = 0.0;
-      for (int ez = ez_lo; ez <= ez_hi; ++ez)
-        for (int ey = ey_lo; ey <= ey_hi; ++ey)
-          for (int ex = ex_lo; ex <= ex_hi; ++ex) {
-            const int a = (A0 - ex) + NB * ((A1 - ey) + NB * (A2 - ez));
-            s += p.scratch_r[(elem(ex, ey, ez) * 3 + I) * ND + a];
-          }
-      p.r[A * 3 + I] += s;
+#pragma unroll
+      for (int I = 0; I < 3; ++I) p.r[A * 3 + I] += rs[I];
     }
   }
 }
