@@ -33,7 +33,7 @@ def pmc(dirs):
                 "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_block_size), max(scratch_size) "
                 "from counters_collection group by kernel_name, counter_name order by 1, 2").fetchall()
             for k, cn, n, avg, mn, mx, vg, ag, sg, lds, scr in rows:
-                if not any(t in k for t in ("tensor_", "general", "contact")):
+                if not any(t in k for t in ("tensor_", "general", "contact", "read8", "read16", "write8")):
                     continue
                 print("%-70s %-14s dispatches %3d mean %.6g min %.6g max %.6g  (vgpr %s agpr %s sgpr %s lds %s scratch %s)"
                       % (k[:70], cn, n, avg, mn, mx, vg, ag, sg, lds, scr))
