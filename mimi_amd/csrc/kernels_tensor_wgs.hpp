@@ -185,6 +185,8 @@ MH_DEV void wgs_x_row(const TensorArgs& p, double* lds, int lane, int64_t e, int
     mm.kind = KIND;
     double A[27];
     tangent_row_of<3, I>(mm, s.w, A);
+#pragma unroll
+    for (int k = 0; k < 27; ++k) WGS_PIN(A[k]);
     // one column component j at a time: T[J][n] = sum_L A[J][j][L] Jinv[n][L], then Ahat[m][j][n]
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -207,6 +209,7 @@ MH_DEV void wgs_x_row(const TensorArgs& p, double* lds, int lane, int64_t e, int
           for (int J = 0; J < 3; ++J) sa += Ji[m * 3 + J] * T[J * 3 + n];
           AH[((m * 3 + j) * 3 + n) * NQ3 + lane] = wd * sa;
         }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // residual row I by sum factorisation (as kernels_tensor_2phase.hpp)
@@ -672,8 +675,10 @@ MH_DEV void wgs_y_skip(const TensorArgs& p) {
 #define WGS_Y_ARGS p, smem_wgs, eu, ev
 #endif
 
+// Two workgroups per CU (256 registers per wave) for neo-Hookean; the J2 point wave (return mapping,
+// dual-number hardening, generic tangent row) does not fit that budget yet and runs one workgroup per CU.
 template<int KIND>
-__global__ __launch_bounds__(256, 2) void tensor_wgs_kernel(TensorArgs p) {
+__global__ __launch_bounds__(256, KIND == MIMI_HIP_MAT_NEOHOOKEAN ? 2 : 1) void tensor_wgs_kernel(TensorArgs p) {
   extern __shared__ __align__(16) double smem_wgs[];
   // Wave w of a workgroup lands on SIMD w; the point wave idles more than the contraction waves, so
   // the role of a wave rotates with the workgroup and every SIMD hosts a mix of roles.
