@@ -11,6 +11,7 @@
 #include "kernels_tensor_mfma.hpp"
 #include "kernels_tensor_2phase.hpp"
 #include "kernels_tensor_wgs.hpp"
+#include "kernels_tensor_wgsym.hpp"
 
 #include <algorithm>
 #include <cmath>

@@ -360,6 +360,9 @@ MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& st
                 H[i * 3 + 2] += uu * dn2;
               }
             }
+            // keep the LDS reads of later (a1, a2) where they are (hoisted together they need 162 registers)
+            #pragma unroll
+            for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(H[k]) : : "memory");
           }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
