@@ -29,6 +29,10 @@
 
 namespace mimi_hip {
 
+#ifndef WGSYM_DIAG_MODE
+#define WGSYM_DIAG_MODE 2   // 2: contract only the a1 >= b1 chains of a diagonal block; 0: all nine
+#endif
+
 struct WgsLane {
   int lane, grp;
   bool col_ok;
@@ -68,8 +72,12 @@ MH_DEV WgsLane wgs_lane_constants() {
 
 // One (i, j) block of one element in a contraction wave: S1, then S2 / S3 pipelined over b1, the
 // carry in registers, finished entries into the store-transposition buffer(s).
-// st_n / jn: buffer of piece i and the column component j; st_t / jt: buffer of piece j and i (TRANSPOSE).
-template<bool TRANSPOSE>
+// st_n / jn: buffer of piece i and the column component j; st_t / jt: buffer of piece j and i.
+// MODE 0: plain block.  MODE 1 (off-diagonal block, i > j): every entry is also stored transposed.
+// MODE 2 (diagonal block, i == j): the block is symmetric itself, K[(a1 ..), (b1 ..)] = K[(b1 ..), (a1 ..)]^T, so
+// only the six chains with a1 >= b1 are contracted and those with a1 > b1 are also stored transposed
+// (st_t == st_n, jt == jn).
+template<int MODE>
 MH_DEV void wgs_contract_block(const WgsLane& lc, const double (&ah)[9], const double (&aS0)[4], const double (&aS2)[4],
                                const double (&uB1)[3][4], const double (&uD1)[3][4], double (&C)[9],
                                double* st_n, int jn, double* st_t, int jt) {
@@ -87,6 +95,7 @@ MH_DEV void wgs_contract_block(const WgsLane& lc, const double (&ah)[9], const d
   auto carry_and_stage = [&](int b1) {
 #pragma unroll
     for (int a1 = 0; a1 < NB; ++a1) {
+      if (MODE == 2 && a1 < b1) continue;
       const int a1b1 = a1 * NB + b1;
       const double cin = C[a1b1];
       double c_rot, o2_rot;
@@ -95,7 +104,7 @@ MH_DEV void wgs_contract_block(const WgsLane& lc, const double (&ah)[9], const d
       const double out1 = Kt[a1][1] + (grp == 0 ? c_rot : 0.0);
       if (lc.col_ok) st_n[lc.base0 + a1 * lc.stride0 + b1 * 9 + jn] = out0;
       if (lc.col_ok && grp == 2) st_n[lc.base1 + a1 * (3 * ND) + b1 * 9 + jn] = out1;
-      if (TRANSPOSE) {
+      if (MODE == 1 || (MODE == 2 && a1 > b1)) {
         if (lc.col_ok) st_t[lc.baseT0 + b1 * lc.strideT0 + a1 * 9 + jt] = out0;
         if (lc.col_ok && grp == 2) st_t[lc.baseT1 + b1 * (3 * NROW) + a1 * 9 + jt] = out1;
       }
@@ -118,6 +127,7 @@ MH_DEV void wgs_contract_block(const WgsLane& lc, const double (&ah)[9], const d
       for (int q1 = 0; q1 < NQ; ++q1) U[q1] = (n == 1 ? uD1[b1][q1] : uB1[b1][q1]) * D1[mn][q1];
 #pragma unroll
       for (int a1 = 0; a1 < NB; ++a1) {
+        if (MODE == 2 && a1 < b1) continue;
         double acc = Ec[g][a1];
 #pragma unroll
         for (int q1 = 0; q1 < NQ; ++q1) acc += (m == 1 ? uD1[a1][q1] : uB1[a1][q1]) * U[q1];
@@ -128,26 +138,30 @@ MH_DEV void wgs_contract_block(const WgsLane& lc, const double (&ah)[9], const d
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int a1 = 0; a1 < NB; ++a1) WGS_PIN(Ec[g][a1]);
+      for (int a1 = 0; a1 < NB; ++a1)
+        if (!(MODE == 2 && a1 < b1)) WGS_PIN(Ec[g][a1]);
 #pragma unroll
-    for (int a1 = 0; a1 < NB; ++a1) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ec[0][a1], aS0[0], zero4, 0, 0, 0);
+    for (int a1 = 0; a1 < NB; ++a1)
+      if (!(MODE == 2 && a1 < b1)) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ec[0][a1], aS0[0], zero4, 0, 0, 0);
 #pragma unroll
     for (int g = 1; g < 4; ++g)
 #pragma unroll
-      for (int a1 = 0; a1 < NB; ++a1) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ec[g][a1], aS0[g], Kt[a1], 0, 0, 0);
+      for (int a1 = 0; a1 < NB; ++a1)
+        if (!(MODE == 2 && a1 < b1)) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ec[g][a1], aS0[g], Kt[a1], 0, 0, 0);
   }
   carry_and_stage(NB - 1);
 }
 
 // carried rows of the last element of a column -> store-transposition buffer(s)
-template<bool TRANSPOSE>
+template<int MODE>
 MH_DEV void wgs_stage_carry(const WgsLane& lc, const double (&C)[9], double* st_n, int jn, double* st_t, int jt) {
   constexpr int NB = 3;
 #pragma unroll
   for (int a1b1 = 0; a1b1 < 9; ++a1b1) {
     const int a1 = a1b1 / NB, b1 = a1b1 % NB;
+    if (MODE == 2 && a1 < b1) continue;
     if (lc.col_ok) st_n[lc.basec + a1 * 162 + b1 * 9 + jn] = C[a1b1];
-    if (TRANSPOSE && lc.col_ok) st_t[lc.basecT + b1 * 162 + a1 * 9 + jt] = C[a1b1];
+    if ((MODE == 1 || (MODE == 2 && a1 > b1)) && lc.col_ok) st_t[lc.basecT + b1 * 162 + a1 * 9 + jt] = C[a1b1];
   }
 }
 
@@ -371,7 +385,7 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
 #pragma unroll
         for (int n = 0; n < 3; ++n) ah[m * 3 + n] = AH1[((m * 3 + J1) * 3 + n) * NQ3 + lane];
       wgs_barrier();
-      wgs_contract_block<(I1 != J1)>(lc, ah, aS0, aS2, uB1, uD1, C1, st_of(I1), J1, st_of(J1), I1);
+      wgs_contract_block<(I1 != J1 ? 1 : WGSYM_DIAG_MODE)>(lc, ah, aS0, aS2, uB1, uD1, C1, st_of(I1), J1, st_of(J1), I1);
       wgs_barrier();
     }
     // ---- step B(it): flush element it - 1, block (I0, J0) of element it --------------------------------------
@@ -414,11 +428,11 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
         for (int n = 0; n < 3; ++n) ah[m * 3 + n] = AH0[((m * 3 + J0) * 3 + n) * NQ3 + lane];
       wgs_barrier();
       if (it < n_seq) {
-        wgs_contract_block<(I0 != J0)>(lc, ah, aS0, aS2, uB1, uD1, C0, st_of(I0), J0, st_of(J0), I0);
+        wgs_contract_block<(I0 != J0 ? 1 : WGSYM_DIAG_MODE)>(lc, ah, aS0, aS2, uB1, uD1, C0, st_of(I0), J0, st_of(J0), I0);
       } else {
         // past the last element: the carried rows have no successor and are stored as well
-        wgs_stage_carry<(I0 != J0)>(lc, C0, st_of(I0), J0, st_of(J0), I0);
-        wgs_stage_carry<(I1 != J1)>(lc, C1, st_of(I1), J1, st_of(J1), I1);
+        wgs_stage_carry<(I0 != J0 ? 1 : WGSYM_DIAG_MODE)>(lc, C0, st_of(I0), J0, st_of(J0), I0);
+        wgs_stage_carry<(I1 != J1 ? 1 : WGSYM_DIAG_MODE)>(lc, C1, st_of(I1), J1, st_of(J1), I1);
       }
       wgs_barrier();
     }
