@@ -1,0 +1,124 @@
+"""Size-independent properties of the assembled residual / tangent at BASELINE.json's full size
+(128x128x16 p=2 neo-Hookean, the bench workload), where the oracle is too slow to be the checker:
+
+* partition of unity: the internal forces sum to zero per component, sum_a R_(a,i) = 0;
+* rigid translations are in the null space of the tangent, K t_j = 0;
+* major symmetry of the hyperelastic tangent, x.(K y) = y.(K x);
+* slab additivity: integrating two element slabs separately and adding gives the whole (the multi-GPU
+  decomposition on one GPU);
+* run-to-run bitwise reproducibility and exact linearity in grad_factor.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_EL, P = (128, 128, 16), 2
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import torch
+    import bench
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    dev = torch.device("cuda", 0)
+    patch = mimi_amd.BSplinePatch.block(N_EL, P)
+    pattern = CSRPattern.of_bspline_patch(patch, on_device=True)
+    G = NonlinearSolid("domain", bench.make_material("neohookean"), pattern, patch=patch).Prepare()
+    assert G.path_ == 1
+    u = torch.from_numpy(bench.synthetic_u(patch)).to(dev)
+    r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
+    A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
+    G.AddDomainResidualAndGrad(u, 1.0, r, A)
+    G.Synchronize()
+    return dict(torch=torch, dev=dev, patch=patch, pattern=pattern, G=G, u=u, r=r, A=A)
+
+
+def csr_matvec(s, values, x):
+    """y = K x by padding the rows to a dense [n_rows, 375] array (unique scatter, then a row sum).
+    torch's sparse-CSR product aborts in hipSPARSE at this size and an atomic index_add_ of 313 M fp64
+    values takes minutes."""
+    torch = s["torch"]
+    if "dense_idx" not in s:
+        pat = s["pattern"]
+        crow = pat.rowptr if isinstance(pat.rowptr, torch.Tensor) else torch.from_numpy(np.asarray(pat.rowptr))
+        col = pat.col if isinstance(pat.col, torch.Tensor) else torch.from_numpy(np.asarray(pat.col))
+        crow = crow.to(s["dev"]).long()
+        lengths = crow[1:] - crow[:-1]
+        s["width"] = int(lengths.max())
+        rows = torch.repeat_interleave(torch.arange(crow.numel() - 1, device=s["dev"]), lengths)
+        s["dense_idx"] = rows * s["width"] + (torch.arange(rows.numel(), device=s["dev"]) - crow[rows])
+        del rows
+        s["cols"] = col.to(s["dev"]).long()
+    dense = torch.zeros(x.numel() * s["width"], dtype=torch.float64, device=s["dev"])
+    dense[s["dense_idx"]] = values * x[s["cols"]]
+    return dense.view(x.numel(), s["width"]).sum(1)
+
+
+def test_internal_forces_sum_to_zero(setup):
+    r = setup["r"].view(-1, 3)
+    scale = float(r.abs().sum(0).max())
+    assert scale > 0
+    assert float(r.sum(0).abs().max()) < 1e-11 * scale
+
+
+def test_rigid_translation_in_null_space(setup):
+    torch = setup["torch"]
+    n = setup["patch"].n_vdofs
+    Aabs = float(setup["A"].abs().max())
+    for j in range(3):
+        t = torch.zeros(n, dtype=torch.float64, device=setup["dev"])
+        t[j::3] = 1.0
+        y = csr_matvec(setup, setup["A"], t)
+        assert float(y.abs().max()) < 1e-10 * Aabs * 375
+
+
+def test_tangent_major_symmetry(setup):
+    torch = setup["torch"]
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n = setup["patch"].n_vdofs
+    x = torch.randn(n, dtype=torch.float64, generator=g).to(setup["dev"])
+    y = torch.randn(n, dtype=torch.float64, generator=g).to(setup["dev"])
+    a = float(x @ csr_matvec(setup, setup["A"], y))
+    b = float(y @ csr_matvec(setup, setup["A"], x))
+    assert abs(a - b) < 1e-10 * max(abs(a), abs(b), float(setup["A"].abs().max()) * n ** 0.5)
+
+
+def test_bitwise_reproducible_and_linear_in_grad_factor(setup):
+    torch = setup["torch"]
+    G, u = setup["G"], setup["u"]
+    r2 = torch.zeros_like(setup["r"])
+    A2 = torch.zeros_like(setup["A"])
+    G.AddDomainResidualAndGrad(u, 1.0, r2, A2)
+    G.Synchronize()
+    assert torch.equal(r2, setup["r"])
+    assert torch.equal(A2, setup["A"])
+    r2.zero_()
+    A2.zero_()
+    G.AddDomainResidualAndGrad(u, 2.0, r2, A2)      # a power of two: exact
+    G.Synchronize()
+    assert torch.equal(r2, setup["r"])
+    assert torch.equal(A2, 2.0 * setup["A"])
+
+
+def test_slab_additivity(setup):
+    """Two element slabs along the sharding axis, integrated by separate handles into the same r / A."""
+    torch = setup["torch"]
+    import bench
+    from mimi_amd import parallel
+    from mimi_amd.integrators import NonlinearSolid
+    patch, pattern, u = setup["patch"], setup["pattern"], setup["u"]
+    r2 = torch.zeros_like(setup["r"])
+    A2 = torch.zeros_like(setup["A"])
+    for rank in range(2):
+        shard = parallel.SlabShard(patch, pattern, rank, 2)
+        G = NonlinearSolid("domain", bench.make_material("neohookean"), pattern, patch=patch,
+                           element_box=shard.element_box).Prepare()
+        G.AddDomainResidualAndGrad(u, 1.0, r2, A2)
+        G.Synchronize()
+        del G
+    rs = float(setup["r"].abs().max())
+    As = float(setup["A"].abs().max())
+    assert float((r2 - setup["r"]).abs().max()) < 1e-12 * rs
+    assert float((A2 - setup["A"]).abs().max()) < 1e-12 * As
