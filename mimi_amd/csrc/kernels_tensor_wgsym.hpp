@@ -449,16 +449,23 @@ __global__ __launch_bounds__(256, 2) void tensor_wgsym_kernel(TensorArgs p) {
   const int role = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) + WGS_ROT(blockIdx.x)) & 3);
   const int unit = blockIdx.x;
   const int eu = unit % p.box_n[0], ev = unit / p.box_n[0];
+  // (WGSYM_EXP_SKIP_X / _Y: timing experiments only — the skipped role just keeps the barrier count)
   if (role == 0) {
     int status = 0;
+#ifdef WGSYM_EXP_SKIP_X
+    for (int k = 0; k < 2 * (2 * p.box_n[2] + 3); ++k) wgs_barrier();
+#else
     wgsym_x_loop<KIND>(p, smem_wgsym, eu, ev, status);
+#endif
     if (status) atomicOr(p.status, status);
-  } else if (role == 1) {
-    wgsym_y_loop<0>(p, smem_wgsym, eu, ev);
-  } else if (role == 2) {
-    wgsym_y_loop<1>(p, smem_wgsym, eu, ev);
   } else {
-    wgsym_y_loop<2>(p, smem_wgsym, eu, ev);
+#ifdef WGSYM_EXP_SKIP_Y
+    for (int k = 0; k < 2 * (2 * p.box_n[2] + 3); ++k) wgs_barrier();
+#else
+    if (role == 1) wgsym_y_loop<0>(p, smem_wgsym, eu, ev);
+    else if (role == 2) wgsym_y_loop<1>(p, smem_wgsym, eu, ev);
+    else wgsym_y_loop<2>(p, smem_wgsym, eu, ev);
+#endif
   }
 }
 
