@@ -34,7 +34,7 @@ struct mimi_hip_domain_s {
   mimi_hip::DeviceBuffer<int64_t> node_ids;  // lexicographic -> global, empty = identity
   bool structured_csr = false;               // CSR positions computable arithmetically
   bool first_is_identity = false;            // span e's first basis function is e (no repeated interior knots)
-  mimi_hip::DeviceBuffer<double> scratch_k, scratch_r;  // two-phase tangent path
+  mimi_hip::DeviceBuffer<double> scratch_k, scratch_r, scratch_pt;  // two-phase tangent path
 
   // J2 state, SoA over points
   mimi_hip::DeviceBuffer<double> eqps, temperature, plastic_strain;

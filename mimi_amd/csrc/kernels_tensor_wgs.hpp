@@ -69,6 +69,104 @@ MH_DEV void swap32_f64(double c, double o, double& c_hi_in_lo, double& o_lo_in_h
 }
 
 // ------------------------------------------------------------------------------------------------
+// J2: material pre-pass.  The return mapping (scalar Newton with dual-number Johnson-Cook hardening:
+// pow / log in fp64) costs tens of thousands of cycles per point; inside the workgroup it would run in
+// the single point wave and bound the whole kernel.  Here every wave of the chip takes one element
+// (lane = quadrature point) and leaves the PointResult in scratch_pt[element][field][point].
+// ------------------------------------------------------------------------------------------------
+constexpr int WGS_PT_FIELDS = 41;  // P 9, Finv 9, detF, sigma 9, s_trial 9, q, delta, hprime, plastic
+
+MH_DEV void wgs_point_store(double* rec, int lane, const PointResult<3>& w) {
+  constexpr int NQ3 = 64;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    rec[(0 + k) * NQ3 + lane] = w.P[k];
+    rec[(9 + k) * NQ3 + lane] = w.Finv[k];
+    rec[(19 + k) * NQ3 + lane] = w.sigma[k];
+    rec[(28 + k) * NQ3 + lane] = w.s_trial[k];
+  }
+  rec[18 * NQ3 + lane] = w.detF;
+  rec[37 * NQ3 + lane] = w.q;
+  rec[38 * NQ3 + lane] = w.delta;
+  rec[39 * NQ3 + lane] = w.hprime;
+  rec[40 * NQ3 + lane] = w.plastic ? 1.0 : 0.0;
+}
+
+MH_DEV void wgs_point_load(const double* rec, int lane, PointResult<3>& w) {
+  constexpr int NQ3 = 64;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    w.P[k] = rec[(0 + k) * NQ3 + lane];
+    w.Finv[k] = rec[(9 + k) * NQ3 + lane];
+    w.sigma[k] = rec[(19 + k) * NQ3 + lane];
+    w.s_trial[k] = rec[(28 + k) * NQ3 + lane];
+  }
+  w.detF = rec[18 * NQ3 + lane];
+  w.q = rec[37 * NQ3 + lane];
+  w.delta = rec[38 * NQ3 + lane];
+  w.hprime = rec[39 * NQ3 + lane];
+  w.plastic = rec[40 * NQ3 + lane] != 0.0;
+}
+
+__global__ __launch_bounds__(256) void tensor_point_kernel(TensorArgs p, int n_el) {
+  constexpr int P = 2, NB = 3, NQ = 4, ND = 27, NQ3 = 64;
+  __shared__ double ue_all[4][3 * ND];
+  __shared__ double tab_all[4][6 * NB * NQ];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
+  if (e >= n_el) return;
+  double* ue = ue_all[wave];
+  double* tab = tab_all[wave];
+  int el[3];
+  el[0] = e % p.box_n[0];
+  el[1] = (e / p.box_n[0]) % p.box_n[1];
+  el[2] = e / ((int64_t)p.box_n[0] * p.box_n[1]);
+  const int32_t* dofs = p.dofs + e * ND;
+  for (int a = lane; a < ND; a += 64) {
+    const int64_t node = dofs[a];
+    for (int c = 0; c < 3; ++c) ue[c * ND + a] = p.u[node * 3 + c];
+  }
+  for (int t = lane; t < 6 * NB * NQ; t += 64) {
+    const int dir = t / (2 * NB * NQ), rem = t % (2 * NB * NQ), isD = rem / (NB * NQ), k = rem % (NB * NQ);
+    const int span = p.box_begin[dir] + el[dir];
+    tab[t] = ((isD ? p.tabD[dir] : p.tabB[dir]) + (int64_t)span * NB * NQ)[k];
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  const int q0 = lane % NQ, q1 = (lane / NQ) % NQ, q2 = lane / (NQ * NQ);
+  double H[9];
+  for (int k = 0; k < 9; ++k) H[k] = 0.0;
+  for (int a2 = 0; a2 < NB; ++a2)
+    for (int a1 = 0; a1 < NB; ++a1)
+      for (int a0 = 0; a0 < NB; ++a0) {
+        const int a = a0 + NB * (a1 + NB * a2);
+        const double b0 = tab_ptr<P>(tab, 0, 0)[a0 * NQ + q0], d0 = tab_ptr<P>(tab, 0, 1)[a0 * NQ + q0];
+        const double b1 = tab_ptr<P>(tab, 1, 0)[a1 * NQ + q1], d1 = tab_ptr<P>(tab, 1, 1)[a1 * NQ + q1];
+        const double b2 = tab_ptr<P>(tab, 2, 0)[a2 * NQ + q2], d2 = tab_ptr<P>(tab, 2, 1)[a2 * NQ + q2];
+        // same association as the point wave: d0 * (b1 * b2), b0 * (d1 * b2), b0 * (b1 * d2)
+        const double dn0 = d0 * (b1 * b2), dn1 = b0 * (d1 * b2), dn2 = b0 * (b1 * d2);
+        for (int i = 0; i < 3; ++i) {
+          const double uu = ue[i * ND + a];
+          H[i * 3 + 0] += uu * dn0;
+          H[i * 3 + 1] += uu * dn1;
+          H[i * 3 + 2] += uu * dn2;
+        }
+      }
+  const double* g = p.geo + e * 10 * NQ3 + lane;
+  double F[9];
+  for (int i = 0; i < 3; ++i)
+    for (int J = 0; J < 3; ++J) {
+      double sf = (i == J) ? 1.0 : 0.0;
+      for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * g[(int64_t)(m * 3 + J) * NQ3];
+      F[i + J * 3] = sf;
+    }
+  PointResult<3> w;
+  const int status = evaluate_pk1<3>(p.mat, p.dt, p.state, e * NQ3 + lane, F, w);
+  wgs_point_store(p.scratch_pt + e * (int64_t)(WGS_PT_FIELDS * NQ3), lane, w);
+  if (status) atomicOr(p.status, status);
+}
+
+// ------------------------------------------------------------------------------------------------
 // wave X
 // ------------------------------------------------------------------------------------------------
 // What wave X keeps per quadrature point between its three steps.  KIND is the material kind as a
@@ -326,55 +424,63 @@ MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& st
       const double wd = geo_r[9];
       e = element_at(it);
       __builtin_amdgcn_wave_barrier();
-      // F at the quadrature point of this lane, q = q0 + 4 q1 + 16 q2
-      double F[9];
-      {
-        const int q0 = lane & 3, q1 = (lane >> 2) & 3, q2 = lane >> 4;
-        double b0[NB], d0[NB], b1[NB], d1[NB], b2[NB], d2[NB];
+      if constexpr (KIND == MIMI_HIP_MAT_NEOHOOKEAN) {
+        // F at the quadrature point of this lane, q = q0 + 4 q1 + 16 q2
+        double F[9];
+        {
+          const int q0 = lane & 3, q1 = (lane >> 2) & 3, q2 = lane >> 4;
+          double b0[NB], d0[NB], b1[NB], d1[NB], b2[NB], d2[NB];
 #pragma unroll
-        for (int a = 0; a < NB; ++a) {
-          b0[a] = tab_ptr<P>(tab, 0, 0)[a * NQ + q0];
-          d0[a] = tab_ptr<P>(tab, 0, 1)[a * NQ + q0];
-          b1[a] = tab_ptr<P>(tab, 1, 0)[a * NQ + q1];
-          d1[a] = tab_ptr<P>(tab, 1, 1)[a * NQ + q1];
-          b2[a] = tab_ptr<P>(tab, 2, 0)[a * NQ + q2];
-          d2[a] = tab_ptr<P>(tab, 2, 1)[a * NQ + q2];
-        }
-        double H[9];
+          for (int a = 0; a < NB; ++a) {
+            b0[a] = tab_ptr<P>(tab, 0, 0)[a * NQ + q0];
+            d0[a] = tab_ptr<P>(tab, 0, 1)[a * NQ + q0];
+            b1[a] = tab_ptr<P>(tab, 1, 0)[a * NQ + q1];
+            d1[a] = tab_ptr<P>(tab, 1, 1)[a * NQ + q1];
+            b2[a] = tab_ptr<P>(tab, 2, 0)[a * NQ + q2];
+            d2[a] = tab_ptr<P>(tab, 2, 1)[a * NQ + q2];
+          }
+          double H[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) H[k] = 0.0;
+          for (int k = 0; k < 9; ++k) H[k] = 0.0;
 #pragma unroll
-        for (int a2 = 0; a2 < NB; ++a2)
+          for (int a2 = 0; a2 < NB; ++a2)
 #pragma unroll
-          for (int a1 = 0; a1 < NB; ++a1) {
-            const double tbb = b1[a1] * b2[a2], tdb = d1[a1] * b2[a2], tbd = b1[a1] * d2[a2];
+            for (int a1 = 0; a1 < NB; ++a1) {
+              const double tbb = b1[a1] * b2[a2], tdb = d1[a1] * b2[a2], tbd = b1[a1] * d2[a2];
 #pragma unroll
-            for (int a0 = 0; a0 < NB; ++a0) {
-              const int a = a0 + NB * (a1 + NB * a2);
-              const double dn0 = d0[a0] * tbb, dn1 = b0[a0] * tdb, dn2 = b0[a0] * tbd;
+              for (int a0 = 0; a0 < NB; ++a0) {
+                const int a = a0 + NB * (a1 + NB * a2);
+                const double dn0 = d0[a0] * tbb, dn1 = b0[a0] * tdb, dn2 = b0[a0] * tbd;
 #pragma unroll
-              for (int i = 0; i < 3; ++i) {
-                const double uu = ue[i * ND + a];
-                H[i * 3 + 0] += uu * dn0;
-                H[i * 3 + 1] += uu * dn1;
-                H[i * 3 + 2] += uu * dn2;
+                for (int i = 0; i < 3; ++i) {
+                  const double uu = ue[i * ND + a];
+                  H[i * 3 + 0] += uu * dn0;
+                  H[i * 3 + 1] += uu * dn1;
+                  H[i * 3 + 2] += uu * dn2;
+                }
               }
+              // keep the LDS reads of later (a1, a2) where they are (hoisted together they need 162 registers)
+              #pragma unroll
+              for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(H[k]) : : "memory");
             }
-            // keep the LDS reads of later (a1, a2) where they are (hoisted together they need 162 registers)
-            #pragma unroll
-            for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(H[k]) : : "memory");
-          }
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+          for (int i = 0; i < 3; ++i)
 #pragma unroll
-          for (int J = 0; J < 3; ++J) {
-            double sf = (i == J) ? 1.0 : 0.0;
+            for (int J = 0; J < 3; ++J) {
+              double sf = (i == J) ? 1.0 : 0.0;
 #pragma unroll
-            for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * Ji[m * 3 + J];
-            F[i + J * 3] = sf;
-          }
+              for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * Ji[m * 3 + J];
+              F[i + J * 3] = sf;
+            }
+        }
+        status |= wgs_x_point<KIND>(p, e * NQ3 + lane, F, Ji, wd, s);
+      } else {
+        // J2: the material was evaluated by tensor_point_kernel
+        wgs_point_load(p.scratch_pt + e * (int64_t)(WGS_PT_FIELDS * NQ3), lane, s.w);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s.Ji[k] = Ji[k];
+        s.wd = wd;
       }
-      status |= wgs_x_point<KIND>(p, e * NQ3 + lane, F, Ji, wd, s);
       MH_STAMP(1);
       wgs_x_row<KIND, 0>(p, lds, lane, e, par, s);
       MH_STAMP(2);
@@ -678,10 +784,13 @@ MH_DEV void wgs_y_skip(const TensorArgs& p) {
 #define WGS_Y_ARGS p, smem_wgs, eu, ev
 #endif
 
+#ifndef WGS_J2_OCC
+#define WGS_J2_OCC(KIND) ((KIND) == MIMI_HIP_MAT_NEOHOOKEAN ? 2 : 1)
+#endif
 // Two workgroups per CU (256 registers per wave) for neo-Hookean; the J2 point wave (return mapping,
 // dual-number hardening, generic tangent row) does not fit that budget yet and runs one workgroup per CU.
 template<int KIND>
-__global__ __launch_bounds__(256, KIND == MIMI_HIP_MAT_NEOHOOKEAN ? 2 : 1) void tensor_wgs_kernel(TensorArgs p) {
+__global__ __launch_bounds__(256, WGS_J2_OCC(KIND)) void tensor_wgs_kernel(TensorArgs p) {
   extern __shared__ __align__(16) double smem_wgs[];
   // Wave w of a workgroup lands on SIMD w; the point wave idles more than the contraction waves, so
   // the role of a wave rotates with the workgroup and every SIMD hosts a mix of roles.
@@ -727,6 +836,12 @@ inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a) {
   a.n_units_u = a.box_n[0];
   a.n_units_v = a.box_n[1];
   const size_t lds = WgsLds::total * sizeof(double);
+  if (h->mat.m.kind != MIMI_HIP_MAT_NEOHOOKEAN) {
+    h->scratch_pt.resize((size_t)h->n_el * WGS_PT_FIELDS * 64);
+    a.scratch_pt = h->scratch_pt.ptr;
+    hipLaunchKernelGGL(tensor_point_kernel, dim3((unsigned)((h->n_el + 3) / 4)), dim3(256), 0, h->stream, a, (int)h->n_el);
+    MH_HIP(hipGetLastError());
+  }
   auto kernel = h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN ? tensor_wgs_kernel<MIMI_HIP_MAT_NEOHOOKEAN> : tensor_wgs_kernel<MIMI_HIP_MAT_J2>;
   MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
