@@ -59,60 +59,102 @@ class SlabShard:
 
 class InterfaceExchange:
     """Packed neighbour exchange of interface rows.  `r` and `A` are this rank's (partial)
-    residual and CSR value tensors (torch, any device); rowptr comes from the pattern."""
+    residual and CSR value tensors (torch, any device); rowptr comes from the pattern.
 
-    def __init__(self, shard, r, A, device=None):
+    mode "replicate": both neighbours exchange the rows of all `p` shared node planes and add, so
+    every rank ends with the fully assembled rows of every node its elements touch.
+    mode "owner" (row-partitioned matrix): of the shared planes [e, e+p) between ranks k and k+1 the
+    first p//2 belong to k and the rest to k+1; each rank sends only the rows the neighbour owns and
+    adds what it receives into the rows it owns -- half the traffic of "replicate"."""
+
+    def __init__(self, shard, r, A, device=None, mode="replicate"):
         import torch
         import torch.distributed as dist
+        if mode not in ("replicate", "owner"):
+            raise ValueError(mode)
         self.torch, self.dist = torch, dist
-        self.shard, self.r, self.A = shard, r, A
+        self.shard, self.r, self.A, self.mode = shard, r, A, mode
         device = r.device if device is None else device
         rowptr = shard.pattern.rowptr
         if not isinstance(rowptr, torch.Tensor):
             rowptr = torch.from_numpy(np.ascontiguousarray(rowptr, dtype=np.int64))
         rowptr = rowptr.to(device)
         dim = shard.patch.dim
+        mi_axis = shard.patch.node_multi_index()[shard.axis]
+
+        def row_sets(planes):
+            nodes = torch.from_numpy(np.nonzero(np.isin(mi_axis, planes))[0]).to(device)
+            rows = (nodes[:, None] * dim + torch.arange(dim, device=device)[None, :]).reshape(-1)
+            start = rowptr[rows]
+            length = rowptr[rows + 1] - start
+            total = int(length.sum().item()) if rows.numel() else 0
+            # positions of all values of those rows, row after row
+            offs = torch.cumsum(length, 0) - length
+            idx = torch.repeat_interleave(start - offs, length) + torch.arange(total, device=device)
+            return rows, idx
+
         self.sides = []
         for nb in (shard.rank - 1, shard.rank + 1):
             if nb < 0 or nb >= shard.world_size:
                 continue
-            nodes = torch.from_numpy(shard.interface_nodes(nb)).to(device)
-            rows = (nodes[:, None] * dim + torch.arange(dim, device=device)[None, :]).reshape(-1)
-            start = rowptr[rows]
-            length = rowptr[rows + 1] - start
-            total = int(length.sum().item())
-            # positions of all values of those rows, row after row
-            offs = torch.cumsum(length, 0) - length
-            idx = torch.repeat_interleave(start - offs, length) + torch.arange(total, device=device)
-            self.sides.append(dict(peer=nb, rows=rows, idx=idx,
-                                   send=torch.empty(rows.numel() + total, dtype=r.dtype, device=device),
-                                   recv=torch.empty(rows.numel() + total, dtype=r.dtype, device=device)))
+            planes = shard.interface_node_planes(nb)
+            if mode == "replicate":
+                send_planes = recv_planes = planes
+            else:
+                k = len(planes) // 2
+                lower, upper = planes[:k], planes[k:]          # owned by the lower / the upper rank
+                send_planes, recv_planes = (upper, lower) if nb > shard.rank else (lower, upper)
+            srows, sidx = row_sets(send_planes)
+            rrows, ridx = row_sets(recv_planes)
+            self.sides.append(dict(peer=nb, srows=srows, sidx=sidx, rrows=rrows, ridx=ridx,
+                                   send=torch.empty(srows.numel() + sidx.numel(), dtype=r.dtype, device=device),
+                                   recv=torch.empty(rrows.numel() + ridx.numel(), dtype=r.dtype, device=device)))
+
+    def owned_node_planes(self):
+        """Node planes along the sharding axis whose rows are complete on this rank after an exchange."""
+        sh = self.shard
+        p = sh.patch.degrees[sh.axis]
+        n_planes = int(sh.patch.n_spans[sh.axis]) + p
+        if self.mode == "replicate":
+            return list(range(int(sh.starts[sh.rank]), int(sh.starts[sh.rank + 1]) + p))
+        lo = int(sh.starts[sh.rank]) + p // 2 if sh.rank > 0 else 0
+        hi = int(sh.starts[sh.rank + 1]) + p // 2 if sh.rank < sh.world_size - 1 else n_planes
+        return list(range(lo, hi))
 
     def _exchange(self, with_grad):
         torch, dist = self.torch, self.dist
         ops = []
         for s in self.sides:
-            nr = s["rows"].numel()
-            n = nr + (s["idx"].numel() if with_grad else 0)
-            s["send"][:nr] = self.r[s["rows"]]
+            ns, nr = s["srows"].numel(), s["rrows"].numel()
+            n_send = ns + (s["sidx"].numel() if with_grad else 0)
+            n_recv = nr + (s["ridx"].numel() if with_grad else 0)
+            s["send"][:ns] = self.r[s["srows"]]
             if with_grad:
-                s["send"][nr:] = self.A[s["idx"]]
-            ops.append(dist.P2POp(dist.isend, s["send"][:n], s["peer"]))
-            ops.append(dist.P2POp(dist.irecv, s["recv"][:n], s["peer"]))
+                s["send"][ns:] = self.A[s["sidx"]]
+            if n_send:
+                ops.append(dist.P2POp(dist.isend, s["send"][:n_send], s["peer"]))
+            if n_recv:
+                ops.append(dist.P2POp(dist.irecv, s["recv"][:n_recv], s["peer"]))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         for s in self.sides:
-            nr = s["rows"].numel()
-            self.r[s["rows"]] += s["recv"][:nr]
+            nr = s["rrows"].numel()
+            if nr == 0:
+                continue
+            self.r[s["rrows"]] += s["recv"][:nr]
             if with_grad:
-                self.A[s["idx"]] += s["recv"][nr:nr + s["idx"].numel()]
+                self.A[s["ridx"]] += s["recv"][nr:nr + s["ridx"].numel()]
 
     def zero_interface(self, with_grad=True):
+        """Zero the rows of all shared node planes (sent and received ones)."""
         for s in self.sides:
-            self.r[s["rows"]] = 0.0
-            if with_grad:
-                self.A[s["idx"]] = 0.0
+            for rows, idx in ((s["srows"], s["sidx"]), (s["rrows"], s["ridx"])):
+                if rows.numel() == 0 or (self.mode == "replicate" and rows is s["rrows"]):
+                    continue
+                self.r[rows] = 0.0
+                if with_grad:
+                    self.A[idx] = 0.0
 
     def sum_residual(self):
         self._exchange(False)

@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n_el, p, q):
+def _worker(rank, world, port, n_el, p, mode, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -43,40 +43,48 @@ def _worker(rank, world, port, n_el, p, q):
         A = np.zeros(D.nnz)
         D.add_domain_residual_and_grad(u, 1.0, r, A, rp.TANGENT_EXACT)
         tr, tA = torch.from_numpy(r), torch.from_numpy(A)
-        ex = parallel.InterfaceExchange(shard, tr, tA)
+        ex = parallel.InterfaceExchange(shard, tr, tA, mode=mode)
         ex.sum_residual_and_grad()
         # full assembly for comparison
         Dfull = rp.DomainOracle(P, oracle_material("neohook"))
         rf = np.zeros(P.n_vdofs)
         Af = np.zeros(D.nnz)
         Dfull.add_domain_residual_and_grad(u, 1.0, rf, Af, rp.TANGENT_EXACT)
-        touched = np.unique(D.conn)
+        # "replicate": all nodes the slab touches; "owner": the nodes of the planes this rank owns
+        mi_axis = patch.node_multi_index()[shard.axis]
+        touched = np.nonzero(np.isin(mi_axis, ex.owned_node_planes()))[0]
+        if mode == "replicate":
+            assert np.array_equal(touched, np.unique(D.conn))
         rows = (touched[:, None] * P.dim + np.arange(P.dim)[None, :]).ravel()
         ok = np.allclose(r[rows], rf[rows], rtol=1e-12, atol=1e-12)
         for row in rows:
             s, t = rowptr[row], rowptr[row + 1]
             ok = ok and np.allclose(A[s:t], Af[s:t], rtol=1e-12, atol=1e-10)
-        q.put((rank, bool(ok), len(elements)))
+        q.put((rank, bool(ok), len(elements), len(touched)))
     except Exception as exc:  # pragma: no cover
-        q.put((rank, False, repr(exc)))
+        q.put((rank, False, repr(exc), 0))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["replicate", "owner"])
 @pytest.mark.parametrize("world,n_el,p", [(2, (3, 2, 6), 2), (3, (2, 9), 3), (2, (4, 5, 3), 1)])
-def test_interface_exchange_gloo(world, n_el, p):
+def test_interface_exchange_gloo(world, n_el, p, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_el, p, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_el, p, mode, q)) for r in range(world)]
     for pr in procs:
         pr.start()
     results = [q.get(timeout=240) for _ in range(world)]
     for pr in procs:
         pr.join(timeout=60)
-    assert all(ok is True for _, ok, _ in results), results
-    assert sum(n for _, _, n in results) == int(np.prod(n_el))
+    assert all(ok is True for _, ok, _, _ in results), results
+    assert sum(n for _, _, n, _ in results) == int(np.prod(n_el))
+    if mode == "owner":
+        # the owned planes partition the nodes
+        assert sum(n for _, _, _, n in results) == int(np.prod([n_el[d] + p for d in range(len(n_el))]))
 
 
 def test_slab_shard_boxes():
