@@ -48,9 +48,6 @@ struct WgsLds {
 };
 
 #define WGS_PIN(x) asm volatile("" : "+v"(x))
-#ifndef WGS_S3_GROUP
-#define WGS_S3_GROUP 3
-#endif
 
 MH_DEV void wgs_barrier() {
   // LDS hand-off only: outstanding global loads / stores need not drain here
@@ -396,17 +393,11 @@ MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& st
 
   WgsPoint<KIND> s;
   int64_t e = 0;
-#ifdef MH_PROFILE
-  unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long prof_last;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last)::"memory");
-#endif
   for (int it = 0; it <= n_seq; ++it) {
     const bool valid = it < n_seq;
     const int par = it & 1;
     // ---- step 0: quadrature-point stage + row 0 ------------------------------------------------
     wgs_barrier();
-    MH_STAMP(0);
     if (valid) {
       double* tab = lds + L::off_tab + par * 6 * NB * NQ;
       if (lane < ND) {
@@ -481,75 +472,215 @@ MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& st
         for (int k = 0; k < 9; ++k) s.Ji[k] = Ji[k];
         s.wd = wd;
       }
-      MH_STAMP(1);
       wgs_x_row<KIND, 0>(p, lds, lane, e, par, s);
-      MH_STAMP(2);
     }
     wgs_barrier();
-    MH_STAMP(3);
     // ---- step 1: row 1 ---------------------------------------------------------------------------
     wgs_barrier();
-    MH_STAMP(0);
     if (valid) wgs_x_row<KIND, 1>(p, lds, lane, e, par, s);
-    MH_STAMP(2);
     wgs_barrier();
-    MH_STAMP(3);
     // ---- step 2: row 2, then the requests of the next element ---------------------------------------
     wgs_barrier();
-    MH_STAMP(0);
     if (valid) {
       wgs_x_row<KIND, 2>(p, lds, lane, e, par, s);
       if (it + 1 < n_seq) request(it + 1);
     }
-    MH_STAMP(2);
     wgs_barrier();
-    MH_STAMP(3);
   }
-#ifdef MH_PROFILE
-  if (lane == 0 && p.prof)
-    for (int k = 0; k < 6; ++k) atomicAdd(&p.prof[k], prof_acc[k]);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
-// wave Y_I
+// contraction waves: shared pieces (also used by kernels_tensor_wgsym.hpp)
+// ------------------------------------------------------------------------------------------------
+struct WgsLane {
+  int lane, grp;
+  bool col_ok;
+  // compact store-transposition slots (kernels_tensor_wgs.hpp): as computed ...
+  int base0, stride0, base1, basec;
+  // ... and with the roles of a and b exchanged
+  int baseT0, strideT0, baseT1, basecT;
+};
+
+MH_DEV WgsLane wgs_lane_constants() {
+  constexpr int NB = 3, ND = 27, NROW = 81;
+  WgsLane c;
+  c.lane = threadIdx.x & 63;
+  const int col = c.lane & 15;
+  c.grp = c.lane >> 4;
+  c.col_ok = col < 9;
+  const int a0 = c.col_ok ? col / NB : 0, b0 = c.col_ok ? col % NB : 0;
+  const int grp = c.grp;
+  // rows of register 0: (a2,b2) = (0,0) (0,1) (0,2) (1,0) for grp 0..3; register 1, grp 2: (2,0)
+  c.base0 = grp < 3 ? a0 * NROW + grp * ND + b0 * 3 : 9 * NROW + a0 * ND + b0 * 3;
+  c.stride0 = grp < 3 ? 3 * NROW : 3 * ND;   // per a1
+  c.base1 = 9 * NROW + (a0 + 9) * ND + b0 * 3;  // per a1: 3 * ND
+  c.basec = a0 * 54 + b0 * 3 + (grp == 0 ? 0 : grp == 1 ? ND : grp == 3 ? 9 * 54 : 9 * 54 + ND);  // per a1: 162
+  // transposed: node a' = b, node b' = a.  a2' = b2 == 0 (grp 0, 3; row 6): s = (b0 + 3 b1) 81 + a2 27 + a1 9 + a0 3 + i
+  //             a2' = b2 >= 1 (grp 1, 2):      s = 729 + (b0 + 3 b1 + 9 (b2 - 1)) 27 + a1 9 + a0 3 + i
+  c.baseT0 = grp == 0 ? b0 * NROW + a0 * 3
+           : grp == 3 ? b0 * NROW + ND + a0 * 3
+           : grp == 1 ? 9 * NROW + b0 * ND + a0 * 3
+                      : 9 * NROW + (b0 + 9) * ND + a0 * 3;
+  c.strideT0 = (grp == 0 || grp == 3) ? 3 * NROW : 3 * ND;   // per b1; per a1: 9
+  c.baseT1 = b0 * NROW + 2 * ND + a0 * 3;                      // row 6 (2,0) -> (0,2): per b1 3 * NROW; per a1 9
+  // carried rows: grp 0 row 4 (1,1) -> (1,1); grp 1 row 5 (1,2) -> (2,1); grp 3 row 7 (2,1) -> (1,2); grp 2 row 8 (2,2)
+  //   s' = (a' - 9) 54 + (b2' - 1) 27 + b1' 9 + b0' 3 + i,  a' = b0 + 3 b1 + 9 b2,  b2' = a2
+  c.basecT = b0 * 54 + a0 * 3 + (grp == 0 ? 0 : grp == 1 ? 9 * 54 : grp == 3 ? ND : 9 * 54 + ND);   // per b1: 162; per a1: 9
+  return c;
+}
+
+// One (i, j) block of one element in a contraction wave: S1, then S2 / S3 pipelined over b1, the
+// carry in registers, finished entries into the store-transposition buffer(s).
+// st_n / jn: buffer of piece i and the column component j; st_t / jt: buffer of piece j and i.
+// MODE 0: plain block.  MODE 1 (off-diagonal block, i > j): every entry is also stored transposed.
+// MODE 2 (diagonal block, i == j): the block is symmetric itself, K[(a1 ..), (b1 ..)] = K[(b1 ..), (a1 ..)]^T, so
+// only the six chains with a1 >= b1 are contracted and those with a1 > b1 are also stored transposed
+// (st_t == st_n, jt == jn).
+template<int MODE>
+MH_DEV void wgs_contract_block(const WgsLane& lc, const double (&ah)[9], const double (&aS0)[4], const double (&aS2)[4],
+                               const double (&uB1)[3][4], const double (&uD1)[3][4], double (&C)[9],
+                               double* st_n, int jn, double* st_t, int jt) {
+  constexpr int NB = 3, NQ = 4, ND = 27, NROW = 81;
+  const mh_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
+  const int grp = lc.grp;
+  mh_d4 D1[9];
+#pragma unroll
+  for (int mn = 0; mn < 9; ++mn) {
+    const int m = mn / 3, n = mn % 3;
+    const int v2 = (m == 2 ? 1 : 0) + (n == 2 ? 2 : 0);
+    D1[mn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[mn], aS2[v2], zero4, 0, 0, 0);
+  }
+  mh_d4 Kt[NB];
+  auto carry_and_stage = [&](int b1) {
+#pragma unroll
+    for (int a1 = 0; a1 < NB; ++a1) {
+      if (MODE == 2 && a1 < b1) continue;
+      const int a1b1 = a1 * NB + b1;
+      const double cin = C[a1b1];
+      double c_rot, o2_rot;
+      swap32_f64(cin, Kt[a1][2], c_rot, o2_rot);
+      const double out0 = Kt[a1][0] + (grp != 2 ? cin : 0.0);
+      const double out1 = Kt[a1][1] + (grp == 0 ? c_rot : 0.0);
+      if (lc.col_ok) st_n[lc.base0 + a1 * lc.stride0 + b1 * 9 + jn] = out0;
+      if (lc.col_ok && grp == 2) st_n[lc.base1 + a1 * (3 * ND) + b1 * 9 + jn] = out1;
+      if (MODE == 1 || (MODE == 2 && a1 > b1)) {
+        if (lc.col_ok) st_t[lc.baseT0 + b1 * lc.strideT0 + a1 * 9 + jt] = out0;
+        if (lc.col_ok && grp == 2) st_t[lc.baseT1 + b1 * (3 * NROW) + a1 * 9 + jt] = out1;
+      }
+      C[a1b1] = grp == 2 ? o2_rot : out1;
+    }
+  };
+#pragma unroll
+  for (int b1 = 0; b1 < NB; ++b1) {
+    double Ec[4][NB];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int a1 = 0; a1 < NB; ++a1) Ec[g][a1] = 0.0;
+#pragma unroll
+    for (int mn = 0; mn < 9; ++mn) {
+      const int m = mn / 3, n = mn % 3;
+      const int g = (m == 0 ? 1 : 0) + (n == 0 ? 2 : 0);
+      double U[NQ];
+#pragma unroll
+      for (int q1 = 0; q1 < NQ; ++q1) U[q1] = (n == 1 ? uD1[b1][q1] : uB1[b1][q1]) * D1[mn][q1];
+#pragma unroll
+      for (int a1 = 0; a1 < NB; ++a1) {
+        if (MODE == 2 && a1 < b1) continue;
+        double acc = Ec[g][a1];
+#pragma unroll
+        for (int q1 = 0; q1 < NQ; ++q1) acc += (m == 1 ? uD1[a1][q1] : uB1[a1][q1]) * U[q1];
+        Ec[g][a1] = acc;
+      }
+    }
+    if (b1 > 0) carry_and_stage(b1 - 1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int a1 = 0; a1 < NB; ++a1)
+        if (!(MODE == 2 && a1 < b1)) WGS_PIN(Ec[g][a1]);
+#pragma unroll
+    for (int a1 = 0; a1 < NB; ++a1)
+      if (!(MODE == 2 && a1 < b1)) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ec[0][a1], aS0[0], zero4, 0, 0, 0);
+#pragma unroll
+    for (int g = 1; g < 4; ++g)
+#pragma unroll
+      for (int a1 = 0; a1 < NB; ++a1)
+        if (!(MODE == 2 && a1 < b1)) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ec[g][a1], aS0[g], Kt[a1], 0, 0, 0);
+  }
+  carry_and_stage(NB - 1);
+}
+
+// carried rows of the last element of a column -> store-transposition buffer(s)
+template<int MODE>
+MH_DEV void wgs_stage_carry(const WgsLane& lc, const double (&C)[9], double* st_n, int jn, double* st_t, int jt) {
+  constexpr int NB = 3;
+#pragma unroll
+  for (int a1b1 = 0; a1b1 < 9; ++a1b1) {
+    const int a1 = a1b1 / NB, b1 = a1b1 % NB;
+    if (MODE == 2 && a1 < b1) continue;
+    if (lc.col_ok) st_n[lc.basec + a1 * 162 + b1 * 9 + jn] = C[a1b1];
+    if ((MODE == 1 || (MODE == 2 && a1 > b1)) && lc.col_ok) st_t[lc.basecT + b1 * 162 + a1 * 9 + jt] = C[a1b1];
+  }
+}
+
+// buffer -> dense scratch piece S (affine addressing, see kernels_tensor_wgs.hpp)
+MH_DEV void wgs_flush_final(int lane, const double* ST, double* S) {
+  constexpr int ND = 27, NROW = 81;
+  {
+    constexpr int NA = (9 * NROW + 63) / 64;  // 12
+    double v[NA];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) v[c] = ST[c * 64 + (c * 64 + 63 < 9 * NROW ? lane : (lane < 9 * NROW - c * 64 ? lane : 0))];
+#pragma unroll
+    for (int c = 0; c < NA; ++c)
+      if (c * 64 + 63 < 9 * NROW || lane < 9 * NROW - c * 64) S[(unsigned)(c * 64 + lane)] = v[c];
+  }
+  {
+    const unsigned l54 = lane < 54 ? lane : 0;
+    const unsigned gofs = 9 * NROW + (l54 >= ND ? NROW + l54 - ND : l54);
+    double v[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) v[c] = ST[9 * NROW + 54 * c + l54];
+#pragma unroll
+    for (int c = 0; c < 9; ++c)
+      if (lane < 54) S[gofs + (unsigned)(c * 2 * NROW)] = v[c];
+  }
+}
+
+MH_DEV void wgs_flush_carry(int lane, const double* ST, double* S) {
+  constexpr int ND = 27, NROW = 81;
+  const unsigned l54 = lane < 54 ? lane : 0;
+#pragma unroll
+  for (int r = 0; r < 18; ++r) {
+    const double v = ST[54 * r + l54];
+    if (lane < 54) S[(unsigned)((9 + r) * NROW + ND) + l54] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave Y_I of the nine-block kernel: row I, one column component j per step
 // ------------------------------------------------------------------------------------------------
 template<int I>
 MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
   using L = WgsLds;
   constexpr int P = 2, NB = 3, NQ = 4, NB2 = 9, ND = 27, NQ3 = 64, NROW = 81, NK = ND * NROW;
-  const int lane = threadIdx.x & 63;
-  const double* AH = lds + L::off_ah + I * ND * NQ3;
+  const WgsLane lc = wgs_lane_constants();
+  const int lane = lc.lane;
+  double* AH = lds + L::off_ah + I * ND * NQ3;
   double* ST = lds + L::off_st + I * L::st_size;
   const int n_seq = p.box_n[2];
-
   // matrix-operand lane constants: pair index on bits 3:0, contraction index on bits 5:4
   const int mrow = lane & 15, mk = lane >> 4;
   const bool mrow_ok = mrow < NB2;
   const int mra = mrow_ok ? mrow / NB : 0, mrb = mrow_ok ? mrow % NB : 0;
-  // result tile of S3: row (a2,b2) pair = grp + 4 r, column (a0,b0) pair = lane & 15
-  const int grp = lane >> 4;
-  const bool col_ok = mrow_ok;
-  const int a0 = mra, b0 = mrb;
-  // store-transposition slots (the compact image of the scratch piece, see flush below):
-  //   a2 == 0 : s = (a0 + 3 a1) 81 + b2 27 + b1 9 + b0 3 + j
-  //   a2 >= 1, b2 == 0 : s = 729 + (a0 + 3 a1 + 9 (a2 - 1)) 27 + b1 9 + b0 3 + j
-  // register 0 holds rows 0..3 = (0,0) (0,1) (0,2) (1,0); register 1, group 2 holds row 6 = (2,0)
-  const int base0 = grp < 3 ? a0 * NROW + grp * ND + b0 * 3 : 9 * NROW + a0 * ND + b0 * 3;
-  const int stride0 = grp < 3 ? 3 * NROW : 3 * ND;
-  const int base1 = 9 * NROW + (a0 + 9) * ND + b0 * 3;   // stride 3 * ND
-  // carried rows, stored only by the last element of the column, from the packed carry register:
-  //   group 0: row 4 (1,1)  group 1: row 5 (1,2)  group 3: row 7 (2,1)  group 2: row 8 (2,2)
-  //   s' = (a - 9) 54 + (b2 - 1) 27 + b1 9 + b0 3 + j
-  const int basec = a0 * 54 + b0 * 3 + (grp == 0 ? 0 : grp == 1 ? ND : grp == 3 ? 9 * 54 : 9 * 54 + ND);
 
-  const mh_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
   double C[3][NB2];  // packed carry [j][a1b1]
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int k = 0; k < NB2; ++k) C[j][k] = 0.0;
-  double aS0[4], aS2[4];      // pair tables of directions 0 and 2 (variants B.B, D.B, B.D, D.D)
+  double aS0[4], aS2[4];            // pair tables of directions 0 and 2 (variants B.B, D.B, B.D, D.D)
   double uB1[NB][NQ], uD1[NB][NQ];  // wave-uniform direction-1 tables
 #pragma unroll
   for (int v = 0; v < 4; ++v) aS0[v] = aS2[v] = 0.0;
@@ -557,25 +688,10 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
   for (int a = 0; a < NB; ++a)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) uB1[a][q] = uD1[a][q] = 0.0;
-
-  {
-    double* AHw = lds + L::off_ah + I * ND * NQ3;
+  // the steps before the first element of this wave run on zeros (their results are never stored)
 #pragma unroll
-    for (int c = 0; c < ND; ++c) AHw[c * NQ3 + lane] = 0.0;
-    if (lane < 6 * NB * NQ) {
-      lds[L::off_tab + lane] = 0.0;
-      lds[L::off_tab + 6 * NB * NQ + lane] = 0.0;
-    }
-    if (lane + 64 < 6 * NB * NQ) {
-      lds[L::off_tab + 64 + lane] = 0.0;
-      lds[L::off_tab + 6 * NB * NQ + 64 + lane] = 0.0;
-    }
-  }
-#ifdef MH_PROFILE
-  unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long prof_last;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last)::"memory");
-#endif
+  for (int c = 0; c < ND; ++c) AH[c * NQ3 + lane] = 0.0;
+
   for (int it = 0; it <= n_seq; ++it) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -584,193 +700,60 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
       const bool valid = es >= 0 && es < n_seq;
       double ah[9];
       // ---- read window ---------------------------------------------------------------------------
-      // (steps before the first / after the last element of this wave run on zeros / stale operands:
-      // their results are never stored, and branch-free steps keep the carry in registers)
-      {
-        if (j == 0) {
-          const double* tab = lds + L::off_tab + (es & 1) * 6 * NB * NQ;
-          {
-            const double Ba = tab_ptr<P>(tab, 0, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 0, 1)[mra * NQ + mk];
-            const double Bb = tab_ptr<P>(tab, 0, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 0, 1)[mrb * NQ + mk];
-            aS0[0] = mrow_ok ? Ba * Bb : 0.0;
-            aS0[1] = mrow_ok ? Da * Bb : 0.0;
-            aS0[2] = mrow_ok ? Ba * Db : 0.0;
-            aS0[3] = mrow_ok ? Da * Db : 0.0;
-          }
-          {
-            const double Ba = tab_ptr<P>(tab, 2, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 2, 1)[mra * NQ + mk];
-            const double Bb = tab_ptr<P>(tab, 2, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 2, 1)[mrb * NQ + mk];
-            aS2[0] = mrow_ok ? Ba * Bb : 0.0;
-            aS2[1] = mrow_ok ? Da * Bb : 0.0;
-            aS2[2] = mrow_ok ? Ba * Db : 0.0;
-            aS2[3] = mrow_ok ? Da * Db : 0.0;
-          }
-#pragma unroll
-          for (int a = 0; a < NB; ++a)
-#pragma unroll
-            for (int q1 = 0; q1 < NQ; ++q1) {
-              const unsigned long long vb = __double_as_longlong(tab_ptr<P>(tab, 1, 0)[a * NQ + q1]);
-              const unsigned long long vd = __double_as_longlong(tab_ptr<P>(tab, 1, 1)[a * NQ + q1]);
-              const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)vb), bhi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
-              const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)vd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(vd >> 32));
-              uB1[a][q1] = __longlong_as_double(((unsigned long long)bhi << 32) | blo);
-              uD1[a][q1] = __longlong_as_double(((unsigned long long)dhi << 32) | dlo);
-            }
+      if (j == 0 && valid) {
+        const double* tab = lds + L::off_tab + (es & 1) * 6 * NB * NQ;
+        {
+          const double Ba = tab_ptr<P>(tab, 0, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 0, 1)[mra * NQ + mk];
+          const double Bb = tab_ptr<P>(tab, 0, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 0, 1)[mrb * NQ + mk];
+          aS0[0] = mrow_ok ? Ba * Bb : 0.0;
+          aS0[1] = mrow_ok ? Da * Bb : 0.0;
+          aS0[2] = mrow_ok ? Ba * Db : 0.0;
+          aS0[3] = mrow_ok ? Da * Db : 0.0;
+        }
+        {
+          const double Ba = tab_ptr<P>(tab, 2, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 2, 1)[mra * NQ + mk];
+          const double Bb = tab_ptr<P>(tab, 2, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 2, 1)[mrb * NQ + mk];
+          aS2[0] = mrow_ok ? Ba * Bb : 0.0;
+          aS2[1] = mrow_ok ? Da * Bb : 0.0;
+          aS2[2] = mrow_ok ? Ba * Db : 0.0;
+          aS2[3] = mrow_ok ? Da * Db : 0.0;
         }
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
+        for (int a = 0; a < NB; ++a)
 #pragma unroll
-          for (int n = 0; n < 3; ++n) ah[m * 3 + n] = AH[((m * 3 + j) * 3 + n) * NQ3 + lane];
+          for (int q1 = 0; q1 < NQ; ++q1) {
+            const unsigned long long vb = __double_as_longlong(tab_ptr<P>(tab, 1, 0)[a * NQ + q1]);
+            const unsigned long long vd = __double_as_longlong(tab_ptr<P>(tab, 1, 1)[a * NQ + q1]);
+            const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)vb), bhi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
+            const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)vd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(vd >> 32));
+            uB1[a][q1] = __longlong_as_double(((unsigned long long)bhi << 32) | blo);
+            uD1[a][q1] = __longlong_as_double(((unsigned long long)dhi << 32) | dlo);
+          }
       }
-      MH_STAMP(6);
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) ah[m * 3 + n] = AH[((m * 3 + j) * 3 + n) * NQ3 + lane];
       wgs_barrier();
-      MH_STAMP(7);
-      // ---- compute window ------------------------------------------------------------------------
-      {
-        const bool last = es + 1 >= n_seq;
-        // S1 (matrix pipe): D1[(m,n)][q1 | q0, a2b2] = sum_q2 Ahat(m,j,n)(q0 q1; q2) TT2[q2][a2b2]
-        mh_d4 D1[9];
+      // ---- compute window (branch-free: steps outside the column run on zeros / stale operands) -------
+      wgs_contract_block<0>(lc, ah, aS0, aS2, uB1, uD1, C[j], ST, j, ST, j);
+      if (j == 2 && valid) {
+        __builtin_amdgcn_wave_barrier();
+        double* S = p.scratch_k + ((eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * es)) * 3 + I) * (int64_t)NK;
+        wgs_flush_final(lane, ST, S);
+        __builtin_amdgcn_wave_barrier();
+        if (es + 1 >= n_seq) {
+          // the carried rows of the last element have no successor: store them as well
 #pragma unroll
-        for (int mn = 0; mn < 9; ++mn) {
-          const int m = mn / 3, n = mn % 3;
-          const int v2 = (m == 2 ? 1 : 0) + (n == 2 ? 2 : 0);
-          D1[mn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[mn], aS2[v2], zero4, 0, 0, 0);
-        }
-        // S2 (vector pipe) and S3 (matrix pipe) software-pipelined over b1: while the matrix pipe
-        // contracts q0 for the three (a1, b1) of one b1, the vector pipe contracts q1 for the next b1.
-        //   S2: E_g[a1] = sum_(m,n) sum_q1 T1^m[a1][q1] T1^n[b1][q1] D1[(m,n)][q1]   (g = direction-0 variant)
-        //   S3: Kt[a1][(a2,b2) rows | (a0,b0) cols] = sum_g sum_q0 E_g[a1][q0 | a2b2] TT0^g[q0][a0b0]
-        // then the carry in registers: rows 4, 5, 7 -> rows 0, 1, 3 of the next element; row 8 (group 0)
-        // -> row 4, parked in the lanes of group 2 (whose own row 2 receives nothing).
-        mh_d4 Kt[NB];
-        auto carry_and_stage = [&](int b1) {
-#pragma unroll
-          for (int a1 = 0; a1 < NB; ++a1) {
-            const int a1b1 = a1 * NB + b1;
-            const double cin = C[j][a1b1];
-            double c_rot, o2_rot;
-            swap32_f64(cin, Kt[a1][2], c_rot, o2_rot);
-            const double out0 = Kt[a1][0] + (grp != 2 ? cin : 0.0);
-            const double out1 = Kt[a1][1] + (grp == 0 ? c_rot : 0.0);
-            const int off = b1 * 9 + j;
-            if (col_ok) ST[base0 + a1 * stride0 + off] = out0;
-            if (col_ok && grp == 2) ST[base1 + a1 * (3 * ND) + off] = out1;
-            C[j][a1b1] = grp == 2 ? o2_rot : out1;
-          }
-        };
-#pragma unroll
-        for (int b1 = 0; b1 < NB; ++b1) {
-          double Ec[4][NB];
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int a1 = 0; a1 < NB; ++a1) Ec[g][a1] = 0.0;
-#ifdef WGS_EXP_NO_S2
-#pragma unroll
-          for (int mn = 0; mn < 9; ++mn) Ec[mn & 3][mn % 3] += D1[mn][b1];
-#else
-#pragma unroll
-          for (int mn = 0; mn < 9; ++mn) {
-            const int m = mn / 3, n = mn % 3;
-            const int g = (m == 0 ? 1 : 0) + (n == 0 ? 2 : 0);
-            double U[NQ];
-#pragma unroll
-            for (int q1 = 0; q1 < NQ; ++q1) U[q1] = (n == 1 ? uD1[b1][q1] : uB1[b1][q1]) * D1[mn][q1];
-#pragma unroll
-            for (int a1 = 0; a1 < NB; ++a1) {
-              double acc = Ec[g][a1];
-#pragma unroll
-              for (int q1 = 0; q1 < NQ; ++q1) acc += (m == 1 ? uD1[a1][q1] : uB1[a1][q1]) * U[q1];
-              Ec[g][a1] = acc;
-            }
-          }
-#endif
-          // the previous b1's matrix results are due by now
-          if (b1 > 0) carry_and_stage(b1 - 1);
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int a1 = 0; a1 < NB; ++a1) WGS_PIN(Ec[g][a1]);
-#ifdef WGS_EXP_NO_S3
-#pragma unroll
-          for (int a1 = 0; a1 < NB; ++a1) {
-            Kt[a1][0] = Ec[0][a1] + aS0[0];
-            Kt[a1][1] = Ec[1][a1] + aS0[1];
-            Kt[a1][2] = Ec[2][a1] + aS0[2];
-            Kt[a1][3] = Ec[3][a1] + aS0[3];
-          }
-#else
-#pragma unroll
-          for (int a1 = 0; a1 < NB; ++a1) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ec[0][a1], aS0[0], zero4, 0, 0, 0);
-#pragma unroll
-          for (int g = 1; g < 4; ++g)
-#pragma unroll
-            for (int a1 = 0; a1 < NB; ++a1) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ec[g][a1], aS0[g], Kt[a1], 0, 0, 0);
-#endif
-        }
-        carry_and_stage(NB - 1);
-        MH_STAMP(8);
-        (void)last;
-        MH_STAMP(9);
-#ifdef WGS_EXP_NOFLUSH
-        if (false) {
-#else
-        if (j == 2 && valid) {
-#endif
-          // ---- flush: compact slots -> this (element, I)'s dense scratch piece ---------------------
-          // Affine addressing only (uniform base + lane + immediate): slots s < 729 map to themselves;
-          // the 18 rows of 27 after them go to the first 27 entries of rows 9..26 of the piece.
+          for (int jj = 0; jj < 3; ++jj) wgs_stage_carry<0>(lc, C[jj], ST, jj, ST, jj);
           __builtin_amdgcn_wave_barrier();
-          double* S = p.scratch_k + ((eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * es)) * 3 + I) * (int64_t)NK;
-          {
-            constexpr int NA = (9 * NROW + 63) / 64;  // 12
-            double v[NA];
-#pragma unroll
-            for (int c = 0; c < NA; ++c) v[c] = ST[c * 64 + (c * 64 + 63 < 9 * NROW ? lane : (lane < 9 * NROW - c * 64 ? lane : 0))];
-#pragma unroll
-            for (int c = 0; c < NA; ++c)
-              if (c * 64 + 63 < 9 * NROW || lane < 9 * NROW - c * 64) S[(unsigned)(c * 64 + lane)] = v[c];
-          }
-          {
-            // two rows of 27 per instruction: lanes 0..53
-            const unsigned l54 = lane < 54 ? lane : 0;
-            const unsigned gofs = 9 * NROW + (l54 >= ND ? NROW + l54 - ND : l54);
-            double v[9];
-#pragma unroll
-            for (int c = 0; c < 9; ++c) v[c] = ST[9 * NROW + 54 * c + l54];
-#pragma unroll
-            for (int c = 0; c < 9; ++c)
-              if (lane < 54) S[gofs + (unsigned)(c * 2 * NROW)] = v[c];
-          }
+          wgs_flush_carry(lane, ST, S);
           __builtin_amdgcn_wave_barrier();
-          if (last) {
-            // the carried rows of the last element have no successor: store them as well
-#pragma unroll
-            for (int jj = 0; jj < 3; ++jj)
-#pragma unroll
-              for (int a1b1 = 0; a1b1 < NB2; ++a1b1)
-                if (col_ok) ST[basec + (a1b1 / NB) * (3 * 54) + (a1b1 % NB) * 9 + jj] = C[jj][a1b1];
-            __builtin_amdgcn_wave_barrier();
-            // 18 rows of 54 (b2 = 1, 2): slot 54 r + l -> entry (9 + r) 81 + 27 + l
-            const unsigned l54 = lane < 54 ? lane : 0;
-#pragma unroll
-            for (int r = 0; r < 18; ++r) {
-              const double v = ST[54 * r + l54];
-              if (lane < 54) S[(unsigned)((9 + r) * NROW + ND) + l54] = v;
-            }
-            __builtin_amdgcn_wave_barrier();
-          }
         }
-        MH_STAMP(10);
       }
       wgs_barrier();
-      MH_STAMP(11);
     }
   }
-#ifdef MH_PROFILE
-  if (I == 0 && lane == 0 && p.prof)
-    for (int k = 6; k < 12; ++k) atomicAdd(&p.prof[k], prof_acc[k]);
-#endif
 }
 
 #ifdef WGS_EXP_SKIP_Y
@@ -800,13 +783,7 @@ __global__ __launch_bounds__(256, WGS_J2_OCC(KIND)) void tensor_wgs_kernel(Tenso
   const int role = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) + WGS_ROT(blockIdx.x)) & 3);
   const int unit = blockIdx.x;
   const int eu = unit % p.box_n[0], ev = unit / p.box_n[0];
-#ifdef WGS_ONLY_X
-  if (true) {
-#elif defined(WGS_ONLY_Y)
-  if (false) {
-#else
   if (role == 0) {
-#endif
     int status = 0;
 #ifdef WGS_EXP_SKIP_X
     for (int it = 0; it < 6 * (p.box_n[2] + 1); ++it) wgs_barrier();
@@ -814,11 +791,7 @@ __global__ __launch_bounds__(256, WGS_J2_OCC(KIND)) void tensor_wgs_kernel(Tenso
     wgs_x_loop<KIND>(p, smem_wgs, eu, ev, status);
 #endif
     if (status) atomicOr(p.status, status);
-#ifdef WGS_ONLY_Y
-  } else if (true) {
-#else
   } else if (role == 1) {
-#endif
     wgs_y_loop<0>(WGS_Y_ARGS);
   } else if (role == 2) {
     wgs_y_loop<1>(WGS_Y_ARGS);

@@ -33,172 +33,6 @@ namespace mimi_hip {
 #define WGSYM_DIAG_MODE 2   // 2: contract only the a1 >= b1 chains of a diagonal block; 0: all nine
 #endif
 
-struct WgsLane {
-  int lane, grp;
-  bool col_ok;
-  // compact store-transposition slots (kernels_tensor_wgs.hpp): as computed ...
-  int base0, stride0, base1, basec;
-  // ... and with the roles of a and b exchanged
-  int baseT0, strideT0, baseT1, basecT;
-};
-
-MH_DEV WgsLane wgs_lane_constants() {
-  constexpr int NB = 3, ND = 27, NROW = 81;
-  WgsLane c;
-  c.lane = threadIdx.x & 63;
-  const int col = c.lane & 15;
-  c.grp = c.lane >> 4;
-  c.col_ok = col < 9;
-  const int a0 = c.col_ok ? col / NB : 0, b0 = c.col_ok ? col % NB : 0;
-  const int grp = c.grp;
-  // rows of register 0: (a2,b2) = (0,0) (0,1) (0,2) (1,0) for grp 0..3; register 1, grp 2: (2,0)
-  c.base0 = grp < 3 ? a0 * NROW + grp * ND + b0 * 3 : 9 * NROW + a0 * ND + b0 * 3;
-  c.stride0 = grp < 3 ? 3 * NROW : 3 * ND;   // per a1
-  c.base1 = 9 * NROW + (a0 + 9) * ND + b0 * 3;  // per a1: 3 * ND
-  c.basec = a0 * 54 + b0 * 3 + (grp == 0 ? 0 : grp == 1 ? ND : grp == 3 ? 9 * 54 : 9 * 54 + ND);  // per a1: 162
-  // transposed: node a' = b, node b' = a.  a2' = b2 == 0 (grp 0, 3; row 6): s = (b0 + 3 b1) 81 + a2 27 + a1 9 + a0 3 + i
-  //             a2' = b2 >= 1 (grp 1, 2):      s = 729 + (b0 + 3 b1 + 9 (b2 - 1)) 27 + a1 9 + a0 3 + i
-  c.baseT0 = grp == 0 ? b0 * NROW + a0 * 3
-           : grp == 3 ? b0 * NROW + ND + a0 * 3
-           : grp == 1 ? 9 * NROW + b0 * ND + a0 * 3
-                      : 9 * NROW + (b0 + 9) * ND + a0 * 3;
-  c.strideT0 = (grp == 0 || grp == 3) ? 3 * NROW : 3 * ND;   // per b1; per a1: 9
-  c.baseT1 = b0 * NROW + 2 * ND + a0 * 3;                      // row 6 (2,0) -> (0,2): per b1 3 * NROW; per a1 9
-  // carried rows: grp 0 row 4 (1,1) -> (1,1); grp 1 row 5 (1,2) -> (2,1); grp 3 row 7 (2,1) -> (1,2); grp 2 row 8 (2,2)
-  //   s' = (a' - 9) 54 + (b2' - 1) 27 + b1' 9 + b0' 3 + i,  a' = b0 + 3 b1 + 9 b2,  b2' = a2
-  c.basecT = b0 * 54 + a0 * 3 + (grp == 0 ? 0 : grp == 1 ? 9 * 54 : grp == 3 ? ND : 9 * 54 + ND);   // per b1: 162; per a1: 9
-  return c;
-}
-
-// One (i, j) block of one element in a contraction wave: S1, then S2 / S3 pipelined over b1, the
-// carry in registers, finished entries into the store-transposition buffer(s).
-// st_n / jn: buffer of piece i and the column component j; st_t / jt: buffer of piece j and i.
-// MODE 0: plain block.  MODE 1 (off-diagonal block, i > j): every entry is also stored transposed.
-// MODE 2 (diagonal block, i == j): the block is symmetric itself, K[(a1 ..), (b1 ..)] = K[(b1 ..), (a1 ..)]^T, so
-// only the six chains with a1 >= b1 are contracted and those with a1 > b1 are also stored transposed
-// (st_t == st_n, jt == jn).
-template<int MODE>
-MH_DEV void wgs_contract_block(const WgsLane& lc, const double (&ah)[9], const double (&aS0)[4], const double (&aS2)[4],
-                               const double (&uB1)[3][4], const double (&uD1)[3][4], double (&C)[9],
-                               double* st_n, int jn, double* st_t, int jt) {
-  constexpr int NB = 3, NQ = 4, ND = 27, NROW = 81;
-  const mh_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
-  const int grp = lc.grp;
-  mh_d4 D1[9];
-#pragma unroll
-  for (int mn = 0; mn < 9; ++mn) {
-    const int m = mn / 3, n = mn % 3;
-    const int v2 = (m == 2 ? 1 : 0) + (n == 2 ? 2 : 0);
-    D1[mn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[mn], aS2[v2], zero4, 0, 0, 0);
-  }
-  mh_d4 Kt[NB];
-  auto carry_and_stage = [&](int b1) {
-#pragma unroll
-    for (int a1 = 0; a1 < NB; ++a1) {
-      if (MODE == 2 && a1 < b1) continue;
-      const int a1b1 = a1 * NB + b1;
-      const double cin = C[a1b1];
-      double c_rot, o2_rot;
-      swap32_f64(cin, Kt[a1][2], c_rot, o2_rot);
-      const double out0 = Kt[a1][0] + (grp != 2 ? cin : 0.0);
-      const double out1 = Kt[a1][1] + (grp == 0 ? c_rot : 0.0);
-      if (lc.col_ok) st_n[lc.base0 + a1 * lc.stride0 + b1 * 9 + jn] = out0;
-      if (lc.col_ok && grp == 2) st_n[lc.base1 + a1 * (3 * ND) + b1 * 9 + jn] = out1;
-      if (MODE == 1 || (MODE == 2 && a1 > b1)) {
-        if (lc.col_ok) st_t[lc.baseT0 + b1 * lc.strideT0 + a1 * 9 + jt] = out0;
-        if (lc.col_ok && grp == 2) st_t[lc.baseT1 + b1 * (3 * NROW) + a1 * 9 + jt] = out1;
-      }
-      C[a1b1] = grp == 2 ? o2_rot : out1;
-    }
-  };
-#pragma unroll
-  for (int b1 = 0; b1 < NB; ++b1) {
-    double Ec[4][NB];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int a1 = 0; a1 < NB; ++a1) Ec[g][a1] = 0.0;
-#pragma unroll
-    for (int mn = 0; mn < 9; ++mn) {
-      const int m = mn / 3, n = mn % 3;
-      const int g = (m == 0 ? 1 : 0) + (n == 0 ? 2 : 0);
-      double U[NQ];
-#pragma unroll
-      for (int q1 = 0; q1 < NQ; ++q1) U[q1] = (n == 1 ? uD1[b1][q1] : uB1[b1][q1]) * D1[mn][q1];
-#pragma unroll
-      for (int a1 = 0; a1 < NB; ++a1) {
-        if (MODE == 2 && a1 < b1) continue;
-        double acc = Ec[g][a1];
-#pragma unroll
-        for (int q1 = 0; q1 < NQ; ++q1) acc += (m == 1 ? uD1[a1][q1] : uB1[a1][q1]) * U[q1];
-        Ec[g][a1] = acc;
-      }
-    }
-    if (b1 > 0) carry_and_stage(b1 - 1);
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int a1 = 0; a1 < NB; ++a1)
-        if (!(MODE == 2 && a1 < b1)) WGS_PIN(Ec[g][a1]);
-#pragma unroll
-    for (int a1 = 0; a1 < NB; ++a1)
-      if (!(MODE == 2 && a1 < b1)) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ec[0][a1], aS0[0], zero4, 0, 0, 0);
-#pragma unroll
-    for (int g = 1; g < 4; ++g)
-#pragma unroll
-      for (int a1 = 0; a1 < NB; ++a1)
-        if (!(MODE == 2 && a1 < b1)) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ec[g][a1], aS0[g], Kt[a1], 0, 0, 0);
-  }
-  carry_and_stage(NB - 1);
-}
-
-// carried rows of the last element of a column -> store-transposition buffer(s)
-template<int MODE>
-MH_DEV void wgs_stage_carry(const WgsLane& lc, const double (&C)[9], double* st_n, int jn, double* st_t, int jt) {
-  constexpr int NB = 3;
-#pragma unroll
-  for (int a1b1 = 0; a1b1 < 9; ++a1b1) {
-    const int a1 = a1b1 / NB, b1 = a1b1 % NB;
-    if (MODE == 2 && a1 < b1) continue;
-    if (lc.col_ok) st_n[lc.basec + a1 * 162 + b1 * 9 + jn] = C[a1b1];
-    if ((MODE == 1 || (MODE == 2 && a1 > b1)) && lc.col_ok) st_t[lc.basecT + b1 * 162 + a1 * 9 + jt] = C[a1b1];
-  }
-}
-
-// buffer -> dense scratch piece S (affine addressing, see kernels_tensor_wgs.hpp)
-MH_DEV void wgs_flush_final(int lane, const double* ST, double* S) {
-  constexpr int ND = 27, NROW = 81;
-  {
-    constexpr int NA = (9 * NROW + 63) / 64;  // 12
-    double v[NA];
-#pragma unroll
-    for (int c = 0; c < NA; ++c) v[c] = ST[c * 64 + (c * 64 + 63 < 9 * NROW ? lane : (lane < 9 * NROW - c * 64 ? lane : 0))];
-#pragma unroll
-    for (int c = 0; c < NA; ++c)
-      if (c * 64 + 63 < 9 * NROW || lane < 9 * NROW - c * 64) S[(unsigned)(c * 64 + lane)] = v[c];
-  }
-  {
-    const unsigned l54 = lane < 54 ? lane : 0;
-    const unsigned gofs = 9 * NROW + (l54 >= ND ? NROW + l54 - ND : l54);
-    double v[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) v[c] = ST[9 * NROW + 54 * c + l54];
-#pragma unroll
-    for (int c = 0; c < 9; ++c)
-      if (lane < 54) S[gofs + (unsigned)(c * 2 * NROW)] = v[c];
-  }
-}
-
-MH_DEV void wgs_flush_carry(int lane, const double* ST, double* S) {
-  constexpr int ND = 27, NROW = 81;
-  const unsigned l54 = lane < 54 ? lane : 0;
-#pragma unroll
-  for (int r = 0; r < 18; ++r) {
-    const double v = ST[54 * r + l54];
-    if (lane < 54) S[(unsigned)((9 + r) * NROW + ND) + l54] = v;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // wave X, two steps per element
 // ------------------------------------------------------------------------------------------------

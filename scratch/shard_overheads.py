@@ -14,7 +14,7 @@ for world in (2, 4, 8):
     G = NonlinearSolid("d", bench.make_material("neohookean"), pattern, patch=patch, element_box=shard.element_box).Prepare()
     r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
     A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
-    ex = parallel.InterfaceExchange(shard, r, A, dev)
+    ex = parallel.InterfaceExchange(shard, r, A, dev, mode="owner")
     def timed(f, n=10):
         f(); torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -25,13 +25,13 @@ for world in (2, 4, 8):
     t_z = timed(lambda: ex.zero_interface(True))
     def pack_unpack():
         for s in ex.sides:
-            nr = s["rows"].numel()
-            s["send"][:nr] = r[s["rows"]]
-            s["send"][nr:] = A[s["idx"]]
+            ns = s["srows"].numel()
+            s["send"][:ns] = r[s["srows"]]
+            s["send"][ns:] = A[s["sidx"]]
         for s in ex.sides:
-            nr = s["rows"].numel()
-            r[s["rows"]] += s["send"][:nr]
-            A[s["idx"]] += s["send"][nr:nr + s["idx"].numel()]
+            nr = s["rrows"].numel()
+            r[s["rrows"]] += s["recv"][:nr]
+            A[s["ridx"]] += s["recv"][nr:nr + s["ridx"].numel()]
     t_p = timed(pack_unpack)
     vol = sum(s["send"].numel() for s in ex.sides) * 8 / 1e6
     print(f"world {world}: slab {shard.element_box}: assembly {t_c:.2f} ms, zero_interface {t_z:.2f} ms, pack+unpack {t_p:.2f} ms, "
