@@ -156,3 +156,33 @@ def test_errors_surface_as_runtime_error():
     bad = CSRPattern(pat.rowptr, np.zeros_like(pat.col), pat.nnz)
     with pytest.raises(RuntimeError, match="CSR pattern"):
         NonlinearSolid("domain", product_material("neohook"), bad, patch=patch).Prepare()
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+@pytest.mark.parametrize("matname", ["neohook", "j2"])
+def test_element_boxes_add_up_to_the_whole(axis, matname):
+    """Shards (element boxes, as the multi-GPU path uses them) along every axis, including the walked one:
+    the sum of the boxes' assemblies equals the oracle's assembly of the whole patch."""
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    from oracle import iga, ref_path as rp
+    n_el = (5, 4, 6)
+    P = iga.Patch.block(n_el, 2)
+    D = rp.DomainOracle(P, oracle_material(matname), n_threads=2)
+    D.set_dt(0.5)
+    pattern = CSRPattern(D.rowptr.astype(np.int64), D.col.astype(np.int32), D.nnz)
+    patch = mimi_amd.BSplinePatch.block(n_el, 2)
+    u = synthetic_u(P, scale=0.05 if matname == "neohook" else 0.02)
+    r_o, A_o = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    D.add_domain_residual_and_grad(u, 1.0, r_o, A_o, rp.TANGENT_EXACT)
+    r_g, A_g = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    cuts = [0, 2, n_el[axis]] if axis != 2 else [0, 2, 3, n_el[axis]]   # a one-element slab along the walked axis too
+    for b, e in zip(cuts[:-1], cuts[1:]):
+        begin, end = [0, 0, 0], list(n_el)
+        begin[axis], end[axis] = b, e
+        G = NonlinearSolid("domain", product_material(matname), pattern, patch=patch, element_box=(begin, end)).Prepare()
+        assert G.path_ == 1
+        G.dt_ = 0.5
+        G.AddDomainResidualAndGrad(u, 1.0, r_g, A_g)
+    assert relmax(r_g, r_o) < 1e-12
+    assert relmax(A_g, A_o) < 1e-11
