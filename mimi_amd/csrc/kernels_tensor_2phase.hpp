@@ -440,12 +440,14 @@ __global__ __launch_bounds__(64) void tensor_p1_kernel(TensorArgs p) {
 __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_nodes) {
   constexpr int P = 2, NB = 3, ND = 27, NROW = 81, NK = ND * NROW;
   constexpr int LMAX = 3 * 125;
-  __shared__ double sums_all[4][3][LMAX + 1];
+  __shared__ double sums_all[4][LMAX + 1];
   const int wave = threadIdx.x >> 6;
-  const int64_t A = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;   // one wave per CSR row (node A, component I)
+  const int64_t A = gw / 3;
+  const int I = (int)(gw % 3);
   const int lane = threadIdx.x & 63;
   if (A >= n_nodes) return;
-  double (*sums)[LMAX + 1] = sums_all[wave];
+  double* sums = sums_all[wave];
   const int n0 = p.n_ctrl[0], n1 = p.n_ctrl[1], n2 = p.n_ctrl[2];
   const int A0 = A % n0, A1 = (A / n0) % n1, A2 = A / ((int64_t)n0 * n1);
   // elements of THIS shard containing node A: e_d in [A_d - P, A_d] clipped to the box
@@ -461,11 +463,7 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
   auto elem = [&](int ex, int ey, int ez) -> int64_t {
     return (ex - bx0) + (int64_t)p.box_n[0] * ((ey - bx1) + (int64_t)p.box_n[1] * (ez - bx2));
   };
-  for (int t = lane; t < L; t += 64) {
-    sums[0][t] = 0.0;
-    sums[1][t] = 0.0;
-    sums[2][t] = 0.0;
-  }
+  for (int t = lane; t < L; t += 64) sums[t] = 0.0;
   // lane constants: row positions k0 = lane and k1 = lane + 64 (< 81), k = ((b2 3 + b1) 3 + b0) 3 + j
   const int k1 = lane + 64;
   const int toff0 = 3 * ((lane / 3) % 3 + w0 * ((lane / 9) % 3 + w1 * (lane / 27))) + lane % 3;
@@ -475,67 +473,45 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
     const int a2 = A2 - ez;
     const int nb = (a2 == 0 || ez == last_ez) ? NROW : ND;
     const bool act0 = lane < nb, act1 = k1 < nb;
-    // P2_BATCH pieces in flight per wave (registers against occupancy)
-#ifndef P2_BATCH
-#define P2_BATCH 3
-#endif
-    for (int c0 = 0; c0 < 9; c0 += P2_BATCH) {
-      double v0[P2_BATCH][3], v1[P2_BATCH][3];
+    // all nine pieces of this element layer in flight
+    double v0[9], v1[9];
 #pragma unroll
-      for (int cc = 0; cc < P2_BATCH; ++cc) {
-        const int c = c0 + cc;
-        const int ey = ey_lo + c / 3, ex = ex_lo + c % 3;
-        const bool in = c < 9 && ey <= ey_hi && ex <= ex_hi;
-        const int a = (A0 - ex) + NB * ((A1 - ey) + NB * a2);
-        const double* src = p.scratch_k + (elem(in ? ex : ex_lo, in ? ey : ey_lo, ez) * 3) * (int64_t)NK + (in ? a : 0) * NROW;
+    for (int c = 0; c < 9; ++c) {
+      const int ey = ey_lo + c / 3, ex = ex_lo + c % 3;
+      const bool in = ey <= ey_hi && ex <= ex_hi;
+      const int a = (A0 - ex) + NB * ((A1 - ey) + NB * a2);
+      const double* src = p.scratch_k + (elem(in ? ex : ex_lo, in ? ey : ey_lo, ez) * 3 + I) * (int64_t)NK + (in ? a : 0) * NROW;
+      v0[c] = (in && act0) ? src[lane] : 0.0;
+      v1[c] = (in && act1) ? src[k1] : 0.0;
+    }
 #pragma unroll
-        for (int I = 0; I < 3; ++I) {
-          v0[cc][I] = (in && act0) ? src[I * NK + lane] : 0.0;
-          v1[cc][I] = (in && act1) ? src[I * NK + k1] : 0.0;
-        }
+    for (int c = 0; c < 9; ++c) {
+      const int ey = ey_lo + c / 3, ex = ex_lo + c % 3;
+      const bool in = ey <= ey_hi && ex <= ex_hi;
+      const int tbase = 3 * ((ex - lo0) + w0 * ((ey - lo1) + w1 * (ez - lo2)));
+      if (in) {
+        if (act0) sums[tbase + toff0] += v0[c];
+        if (act1) sums[tbase + toff1] += v1[c];
       }
-#pragma unroll
-      for (int cc = 0; cc < P2_BATCH; ++cc) {
-        const int c = c0 + cc;
-        const int ey = ey_lo + c / 3, ex = ex_lo + c % 3;
-        const bool in = c < 9 && ey <= ey_hi && ex <= ex_hi;
-        const int tbase = 3 * ((ex - lo0) + w0 * ((ey - lo1) + w1 * (ez - lo2)));
-        if (in) {
-#pragma unroll
-          for (int I = 0; I < 3; ++I) {
-            if (act0) sums[I][tbase + toff0] += v0[cc][I];
-            if (act1) sums[I][tbase + toff1] += v1[cc][I];
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int I = 0; I < 3; ++I) {
+  {
     double* row = p.A + p.rowptr[A * 3 + I];
-    for (int t = lane; t < L; t += 64) row[t] += p.grad_factor * sums[I][t];
+    for (int t = lane; t < L; t += 64) row[t] += p.grad_factor * sums[t];
   }
-  // residual rows: lane = element (dz, dy, dx) of the 3 x 3 x 3 neighbourhood, fixed-shape tree sum
+  // residual row: lane = element (dz, dy, dx) of the 3 x 3 x 3 neighbourhood, fixed-shape tree sum
   {
     const int dz = lane / 9, dy = (lane / 3) % 3, dx = lane % 3;
     const int ez = ez_lo + dz, ey = ey_lo + dy, ex = ex_lo + dx;
     const bool in = lane < ND && ez <= ez_hi && ey <= ey_hi && ex <= ex_hi;
     const int a = in ? (A0 - ex) + NB * ((A1 - ey) + NB * (A2 - ez)) : 0;
     const int64_t e = in ? elem(ex, ey, ez) : 0;
-    double rs[3];
+    double rs = in ? p.scratch_r[(e * 3 + I) * ND + a] : 0.0;
 #pragma unroll
-    for (int I = 0; I < 3; ++I) rs[I] = in ? p.scratch_r[(e * 3 + I) * ND + a] : 0.0;
-#pragma unroll
-    for (int I = 0; I < 3; ++I) {
-#pragma unroll
-      for (int off = 16; off >= 1; off >>= 1) rs[I] += __shfl_down(rs[I], off, 32);
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int I = 0; I < 3; ++I) p.r[A * 3 + I] += rs[I];
-    }
+    for (int off = 16; off >= 1; off >>= 1) rs += __shfl_down(rs, off, 32);
+    if (lane == 0) p.r[A * 3 + I] += rs;
   }
 }
 
@@ -560,7 +536,7 @@ inline void launch_tensor_two_phase(mimi_hip_domain_s* h, TensorArgs a) {
   hipLaunchKernelGGL(tensor_p1_kernel, dim3(a.n_units_u * a.n_units_v * 3), dim3(64), lds, h->stream, a);
   MH_HIP(hipGetLastError());
   const int64_t n_nodes = h->n_nodes;
-  hipLaunchKernelGGL(tensor_p2_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, h->stream, a, n_nodes);
+  hipLaunchKernelGGL(tensor_p2_kernel, dim3((unsigned)((3 * n_nodes + 3) / 4)), dim3(256), 0, h->stream, a, n_nodes);
   MH_HIP(hipGetLastError());
 }
 

@@ -820,7 +820,7 @@ inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a) {
   hipLaunchKernelGGL(kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
   MH_HIP(hipGetLastError());
   const int64_t n_nodes = h->n_nodes;
-  hipLaunchKernelGGL(tensor_p2_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, h->stream, a, n_nodes);
+  hipLaunchKernelGGL(tensor_p2_kernel, dim3((unsigned)((3 * n_nodes + 3) / 4)), dim3(256), 0, h->stream, a, n_nodes);
   MH_HIP(hipGetLastError());
 }
 
