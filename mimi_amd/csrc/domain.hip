@@ -441,6 +441,33 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
       h->structured_csr = (*h->status_host == 0);
       MH_HIP(hipMemsetAsync(h->status_dev, 0, sizeof(int), h->stream));
     }
+    // permuted numbering (node_ids given): is the caller's CSR the permuted structured pattern?
+    h->structured_perm = false;
+    if (p->node_ids && dim == 3 && h->degree[0] <= 2 && h->degree[1] <= 2 && h->degree[2] <= 2 &&
+        !(getenv("MIMI_HIP_NO_STRUCTURED") && getenv("MIMI_HIP_NO_STRUCTURED")[0] == '1')) {
+      SparsityDev S{};
+      S.dim = dim;
+      for (int d = 0; d < 3; ++d) {
+        S.n[d] = h->n_ctrl[d];
+        S.p[d] = h->degree[d];
+        S.prefix[d] = nullptr;
+      }
+      DeviceBuffer<int32_t> col_tmp;
+      const int32_t* col_dev = p->csr_col;
+      if (!is_device_pointer(p->csr_col)) {
+        col_tmp.assign(p->csr_col, h->nnz, h->stream);
+        col_dev = col_tmp.ptr;
+      }
+      h->nbr_pos.resize((size_t)n_nodes * 125);
+      MH_HIP(hipMemsetAsync(h->status_dev, 0, sizeof(int), h->stream));
+      hipLaunchKernelGGL(permuted_window_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, h->stream, S, (int64_t)n_nodes,
+                         h->node_ids.ptr, h->rowptr, col_dev, h->nbr_pos.ptr, h->status_dev);
+      MH_HIP(hipGetLastError());
+      MH_HIP(hipMemcpyAsync(h->status_host, h->status_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      MH_HIP(hipStreamSynchronize(h->stream));
+      h->structured_perm = (*h->status_host == 0);
+      MH_HIP(hipMemsetAsync(h->status_dev, 0, sizeof(int), h->stream));
+    }
     init_state(h.get());
     MH_HIP(hipStreamSynchronize(h->stream));
     *out = h.release();
@@ -581,7 +608,7 @@ int64_t mimi_hip_domain_info(mimi_hip_domain_t h, int what) {
   case 3: return h->nnz;
   case 4: return h->n_vdofs;
   case 5: return h->path;
-  case 6: return h->structured_csr ? 1 : 0;
+  case 6: return h->structured_csr ? 1 : (h->structured_perm ? 2 : 0);
   default: return -1;
   }
 }

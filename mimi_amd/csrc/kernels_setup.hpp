@@ -220,4 +220,49 @@ __global__ void structured_col_kernel(SparsityDev S, int64_t n_rows, const int64
   }
 }
 
+// Permuted numbering (node_ids = lexicographic -> caller's node id, e.g. MFEM's NURBS dof map): the CSR row of
+// node perm[A] holds the columns perm[B] of A's (2p+1)^3 window in ascending order of perm[B].  One wave per
+// lexicographic node A: nbr_pos[A][t] = rank of perm[B_t] inside the window (t = lexicographic window index),
+// and a check that the caller's CSR is exactly that pattern.  3-D, p <= 2 (window <= 125 entries, uint8 ranks).
+__global__ void permuted_window_kernel(SparsityDev S, int64_t n_nodes, const int64_t* __restrict__ perm,
+                                       const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                       unsigned char* __restrict__ nbr_pos, int* __restrict__ mismatch) {
+  __shared__ int64_t vals_all[4][128];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t A = (int64_t)blockIdx.x * 4 + wave;
+  if (A >= n_nodes) return;
+  int64_t* vals = vals_all[wave];
+  const int Am[3] = {(int)(A % S.n[0]), (int)((A / S.n[0]) % S.n[1]), (int)(A / ((int64_t)S.n[0] * S.n[1]))};
+  int lo[3], w[3];
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = Am[d] - S.p[d] < 0 ? 0 : Am[d] - S.p[d];
+    w[d] = width_1d(Am[d], S.n[d], S.p[d]);
+  }
+  const int nw = w[0] * w[1] * w[2];
+  for (int t = lane; t < nw; t += 64) {
+    const int t0 = t % w[0], t1 = (t / w[0]) % w[1], t2 = t / (w[0] * w[1]);
+    const int64_t B = (lo[0] + t0) + (int64_t)S.n[0] * ((lo[1] + t1) + (int64_t)S.n[1] * (lo[2] + t2));
+    vals[t] = perm[B];
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  const int64_t gA = perm[A];
+  for (int t = lane; t < nw; t += 64) {
+    const int64_t v = vals[t];
+    int rank = 0;
+    for (int s2 = 0; s2 < nw; ++s2) rank += vals[s2] < v ? 1 : 0;
+    nbr_pos[A * 125 + t] = (unsigned char)rank;
+    for (int i = 0; i < 3; ++i) {
+      const int64_t row = gA * 3 + i;
+      const int64_t start = rowptr[row];
+      if (rowptr[row + 1] - start != 3 * nw) {
+        atomicOr(mismatch, 1);
+      } else {
+        for (int j = 0; j < 3; ++j)
+          if (col[start + 3 * rank + j] != (int32_t)(v * 3 + j)) atomicOr(mismatch, 1);
+      }
+    }
+  }
+}
+
 }  // namespace mimi_hip

@@ -58,6 +58,8 @@ struct TensorArgs {
   double* scratch_k;         // two-phase path: [n_el][3][27*81] element row pieces
   double* scratch_r;         // two-phase path: [n_el][3][27] element residual pieces
   double* scratch_pt;        // two-phase path, J2: [n_el][41][n_q] material results per quadrature point
+  const int64_t* perm;       // two-phase path: lexicographic -> caller's node id (nullptr = identity)
+  const unsigned char* nbr_pos;  // two-phase path, permuted numbering: [n_nodes][125] positions inside a CSR row
 };
 
 // wave-private LDS carve, in doubles
@@ -755,6 +757,8 @@ inline TensorArgs tensor_args(mimi_hip_domain_s* h, const double* u, double* r, 
   a.state = StateView{h->eqps.ptr, h->temperature.ptr, h->plastic_strain.ptr, h->n_pts};
   a.status = h->status_dev;
   a.prof = h->prof_dev;
+  a.perm = h->structured_perm ? h->node_ids.ptr : nullptr;
+  a.nbr_pos = h->structured_perm ? h->nbr_pos.ptr : nullptr;
   return a;
 }
 

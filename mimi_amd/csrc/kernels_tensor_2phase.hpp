@@ -497,9 +497,16 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
     }
   }
   __builtin_amdgcn_wave_barrier();
+  const int64_t gA = p.perm ? p.perm[A] : A;   // the caller's id of node A
   {
-    double* row = p.A + p.rowptr[A * 3 + I];
-    for (int t = lane; t < L; t += 64) row[t] += p.grad_factor * sums[t];
+    double* row = p.A + p.rowptr[gA * 3 + I];
+    if (p.perm) {
+      // permuted numbering: window neighbour t / 3 sits at rank nbr_pos inside the row
+      const unsigned char* pos = p.nbr_pos + A * 125;
+      for (int t = lane; t < L; t += 64) row[3 * (int)pos[t / 3] + t % 3] += p.grad_factor * sums[t];
+    } else {
+      for (int t = lane; t < L; t += 64) row[t] += p.grad_factor * sums[t];
+    }
   }
   // residual row: lane = element (dz, dy, dx) of the 3 x 3 x 3 neighbourhood, fixed-shape tree sum
   {
@@ -511,12 +518,12 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
     double rs = in ? p.scratch_r[(e * 3 + I) * ND + a] : 0.0;
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) rs += __shfl_down(rs, off, 32);
-    if (lane == 0) p.r[A * 3 + I] += rs;
+    if (lane == 0) p.r[gA * 3 + I] += rs;
   }
 }
 
 inline bool two_phase_supported(const mimi_hip_domain_s* h) {
-  if (!h->structured_csr || h->node_ids.ptr || !h->first_is_identity) return false;
+  if (!(h->structured_csr || h->structured_perm) || !h->first_is_identity) return false;
   // walk axis (shortest, ties -> last) must be the third direction
   int seq = 0;
   for (int d = 1; d < 3; ++d)

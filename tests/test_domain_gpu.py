@@ -186,3 +186,46 @@ def test_element_boxes_add_up_to_the_whole(axis, matname):
         G.AddDomainResidualAndGrad(u, 1.0, r_g, A_g)
     assert relmax(r_g, r_o) < 1e-12
     assert relmax(A_g, A_o) < 1e-11
+
+
+@pytest.mark.parametrize("matname", ["neohook", "j2"])
+def test_permuted_node_numbering(matname):
+    """node_ids = lexicographic -> caller's node id (what MFEM's NURBS dof map is for the reference): u, r and
+    the CSR live in the caller's numbering; the two-phase kernels must still be taken (info 6 == 2)."""
+    import scipy.sparse as sp
+    import mimi_amd
+    from mimi_amd import _capi
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    from oracle import iga, ref_path as rp
+    n_el = (5, 4, 4)
+    P = iga.Patch.block(n_el, 2)
+    D = rp.DomainOracle(P, oracle_material(matname), n_threads=2)
+    D.set_dt(0.5)
+    u = synthetic_u(P, scale=0.05 if matname == "neohook" else 0.02)
+    r_o, A_o = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    D.add_domain_residual_and_grad(u, 0.5, r_o, A_o, rp.TANGENT_EXACT)
+    perm = np.random.default_rng(11).permutation(P.n_nodes).astype(np.int64)
+    dofperm = (perm[:, None] * 3 + np.arange(3)[None, :]).ravel()          # lexicographic dof -> caller's dof
+    rows_o = np.repeat(np.arange(P.n_vdofs), np.diff(D.rowptr))
+    # the caller's CSR: same matrix, rows / columns renumbered, columns sorted; slot k of the oracle lands at dst[k]
+    S = sp.coo_matrix((np.arange(1, D.nnz + 1, dtype=np.float64), (dofperm[rows_o], dofperm[D.col])),
+                      shape=(P.n_vdofs, P.n_vdofs)).tocsr()
+    S.sort_indices()
+    dst = np.empty(D.nnz, dtype=np.int64)
+    dst[(S.data - 1).astype(np.int64)] = np.arange(D.nnz)
+    pattern = CSRPattern(S.indptr.astype(np.int64), S.indices.astype(np.int32), D.nnz)
+    patch = mimi_amd.BSplinePatch.block(n_el, 2)
+    G = NonlinearSolid("domain", product_material(matname), pattern, patch=patch, node_ids=perm).Prepare()
+    assert G.path_ == 1
+    assert _capi.lib().mimi_hip_domain_info(G._h, 6) == 2
+    G.dt_ = 0.5
+    u_p = np.empty_like(u)
+    u_p[dofperm] = u
+    r_g, A_g = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    G.AddDomainResidualAndGrad(u_p, 0.5, r_g, A_g)
+    assert relmax(r_g[dofperm], r_o) < 1e-12
+    assert relmax(A_g[dst], A_o) < 1e-11
+    # residual-only call (colour kernel with the pair-position table)
+    r_g[:] = 0.0
+    G.AddDomainResidual(u_p, r_g)
+    assert relmax(r_g[dofperm], r_o) < 1e-12
