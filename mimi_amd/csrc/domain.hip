@@ -12,6 +12,7 @@
 #include "kernels_tensor_2phase.hpp"
 #include "kernels_tensor_wgs.hpp"
 #include "kernels_tensor_wgsym.hpp"
+#include "kernels_tensor_residual.hpp"
 
 #include <algorithm>
 #include <cmath>

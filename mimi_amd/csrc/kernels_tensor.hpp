@@ -787,6 +787,7 @@ inline bool two_phase_supported(const mimi_hip_domain_s* h);                    
 inline void launch_tensor_two_phase(mimi_hip_domain_s* h, TensorArgs a);
 inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a);               // kernels_tensor_wgs.hpp
 inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a);             // kernels_tensor_wgsym.hpp
+inline void launch_tensor_residual(mimi_hip_domain_s* h, TensorArgs a);          // kernels_tensor_residual.hpp
 
 inline void launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, double* r, double* A, double gf) {
   TensorArgs a = tensor_args(h, u, r, A, gf);
@@ -805,6 +806,8 @@ inline void launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, doubl
   }
   else if (grad && want_mfma)
     launch_tensor_mfma(h, grad, a);
+  else if (!grad && !want_valu && two_phase_supported(h))
+    launch_tensor_residual(h, a);
   else
     launch_tensor_p<2>(h, grad, a);
 }
