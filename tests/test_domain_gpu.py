@@ -245,3 +245,22 @@ def test_medium_block_parity(matname):
     G.AddDomainResidualAndGrad(u, 1.0, r_g, A_g)
     assert relmax(r_g, r_o) < 1e-12
     assert relmax(A_g, A_o) < 1e-11
+
+
+@pytest.mark.parametrize("n_el", [(1, 1, 1), (2, 1, 3), (1, 3, 1), (1, 1, 4), (3, 1, 2)], ids=lambda n: "x".join(map(str, n)))
+def test_tiny_blocks(n_el):
+    """Degenerate sizes of the two-phase kernels: single columns, single elements per column, windows cut on
+    both sides (fewer than 2p+1 nodes per direction)."""
+    P, D, G = make_pair(n_el, 2, None, "neohook", "bspline")
+    from oracle import ref_path as rp
+    assert G.path_ == 1
+    u = synthetic_u(P, scale=0.05)
+    r_o, A_o = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    r_g, A_g = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    D.add_domain_residual_and_grad(u, 1.0, r_o, A_o, rp.TANGENT_EXACT)
+    G.AddDomainResidualAndGrad(u, 1.0, r_g, A_g)
+    assert relmax(r_g, r_o) < 1e-12
+    assert relmax(A_g, A_o) < 1e-11
+    r_g[:] = 0.0
+    G.AddDomainResidual(u, r_g)
+    assert relmax(r_g, r_o) < 1e-12
