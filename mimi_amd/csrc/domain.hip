@@ -8,7 +8,6 @@
 #include "kernels_general.hpp"
 #include "kernels_setup.hpp"
 #include "kernels_tensor.hpp"
-#include "kernels_tensor_mfma.hpp"
 #include "kernels_tensor_2phase.hpp"
 #include "kernels_tensor_wgs.hpp"
 #include "kernels_tensor_wgsym.hpp"

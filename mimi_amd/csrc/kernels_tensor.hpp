@@ -782,9 +782,7 @@ inline void launch_tensor_p(mimi_hip_domain_s* h, int grad, TensorArgs a) {
     }
 }
 
-inline void launch_tensor_mfma(mimi_hip_domain_s* h, int grad, TensorArgs a);  // kernels_tensor_mfma.hpp
 inline bool two_phase_supported(const mimi_hip_domain_s* h);                     // kernels_tensor_2phase.hpp
-inline void launch_tensor_two_phase(mimi_hip_domain_s* h, TensorArgs a);
 inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a);               // kernels_tensor_wgs.hpp
 inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a);             // kernels_tensor_wgsym.hpp
 inline void launch_tensor_residual(mimi_hip_domain_s* h, TensorArgs a);          // kernels_tensor_residual.hpp
@@ -792,20 +790,15 @@ inline void launch_tensor_residual(mimi_hip_domain_s* h, TensorArgs a);         
 inline void launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, double* r, double* A, double gf) {
   TensorArgs a = tensor_args(h, u, r, A, gf);
   // MIMI_HIP_TENSOR_VARIANT: default when supported = two-phase with role-specialised workgroups, the
-  // symmetric-half kernel for hyperelastic materials ("wgs" forces the full nine-block kernel);
-  // "2phase" (two-phase, one wave per (column, i)), "mfma", "valu"
+  // symmetric-half kernel for hyperelastic materials; "wgs" forces the full nine-block kernel,
+  // "valu" the colour-partitioned read-modify-write kernel
   static const char* variant = getenv("MIMI_HIP_TENSOR_VARIANT");
   const bool want_valu = variant && variant[0] == 'v';
-  const bool want_mfma = variant && variant[0] == 'm';
-  const bool want_2p = variant && variant[0] == '2';
-  if (grad && !want_valu && !want_mfma && two_phase_supported(h)) {
+  if (grad && !want_valu && two_phase_supported(h)) {
     const bool want_full = variant && variant[0] == 'w';
-    if (want_2p) launch_tensor_two_phase(h, a);
-    else if (h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN && !want_full) launch_tensor_wgsym(h, a);
+    if (h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN && !want_full) launch_tensor_wgsym(h, a);
     else launch_tensor_wgs(h, a);
   }
-  else if (grad && want_mfma)
-    launch_tensor_mfma(h, grad, a);
   else if (!grad && !want_valu && two_phase_supported(h))
     launch_tensor_residual(h, a);
   else

@@ -1,431 +1,27 @@
-// Two-phase tangent assembly for structured p = 2 patches (the benchmarked path).
+// Two-phase tangent assembly for structured p = 2 patches (the benchmarked path): what both phase-1
+// kernels (kernels_tensor_wgsym.hpp, kernels_tensor_wgs.hpp) share.
 //
 // Why two phases: with colour-partitioned read-modify-write inside the integration kernel the
 // wave is bound by its CU's outstanding-request capacity -- every (element, i) touches 243 CSR row
-// segments of 72 B, i.e. partial cache lines, both ways (profiles/r01_*: 58 % of a wave's time in
-// the flush, or the same time in issuing the prefetch).  So the integration kernel now only
-// STORES: its 27 row pieces per (element, i) go, coalesced, to a dense scratch, and a second
+// segments of 72 B, i.e. partial cache lines, both ways (profiles/r01_colour_rmw_*).  So the
+// integration kernel only STORES: its row pieces go, coalesced, to a dense scratch, and a second
 // kernel that owns CSR rows gathers them and does ONE coalesced read-modify-write per row.
 //
-//   phase 1  tensor_p1_kernel: stage 0 / A / R and the MFMA contraction stage of
-//            kernels_tensor_mfma.hpp; no loads of A or r, no colouring (one launch), no
-//            atomics.  Entries shared with the next element of the walked column are carried in
-//            the wave's LDS tile, so each (node pair, element column) is stored exactly once,
-//            by the highest element of the column that contains both nodes.
-//   phase 2  tensor_p2_kernel: one wave per CSR node row block (3 rows); a lane owns row entries
-//            and sums the <= 9 stored pieces (one per element column), in a fixed order, then
-//            A[row] += grad_factor * sum, r += sum of element residual pieces.
+//   phase 1  stores, for every (element, i), the 27 x 81 row piece scratch_k[element][i][a][b2][b1][b0][j]
+//            and the residual piece scratch_r[element][i][a].  Entries shared with the next element of
+//            the walked (third) axis are carried inside the kernel, so each (node pair, element column)
+//            is stored exactly once, by the highest element of the column that contains both nodes.
+//   phase 2  tensor_p2_kernel below.
 // Results are bitwise reproducible; nothing is atomic.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
-#include "kernels_tensor_mfma.hpp"
+#include "kernels_tensor.hpp"
 
 namespace mimi_hip {
 
-template<int I>
-MH_DEV void tensor_p1_body(const TensorArgs& p, double* lds, int eu, int ev, int& status) {
-  using L = MfmaLds;
-  constexpr int P = 2, NB = 3, NQ = 4, NB2 = 9, ND = 27, NQ3 = 64, NROW = 81;
-  constexpr int TROUNDS = 2;  // 72 table values
-  const int lane = threadIdx.x & 63;
-  double* ue = lds + L::off_ue;
-  double* tab = lds + L::off_tab;
-  double* RS = lds + L::off_r;
-  double* KS = lds + L::off_ks;
-  const bool use_carry = p.seq_axis == 2;
-#ifdef MH_PROFILE
-  unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long prof_last;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last)::"memory");
-#endif
-
-  const int n_seq = p.seq_axis == 0 ? p.box_n[0] : (p.seq_axis == 1 ? p.box_n[1] : p.box_n[2]);
-  auto element_of = [&](int es, int* el) -> int64_t {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) el[d] = (d == p.seq_axis) ? es : (d == p.u_axis ? eu : ev);
-    return el[0] + (int64_t)p.box_n[0] * (el[1] + (int64_t)p.box_n[1] * el[2]);
-  };
-  auto table_src = [&](const int* el, int t) -> const double* {
-    const int dir = t / (2 * NB * NQ);
-    const int rem = t % (2 * NB * NQ);
-    const int isD = rem / (NB * NQ);
-    const int k = rem % (NB * NQ);
-    const int span = (dir == 0 ? p.box_begin[0] + el[0] : dir == 1 ? p.box_begin[1] + el[1] : p.box_begin[2] + el[2]);
-    return (isD ? (dir == 0 ? p.tabD[0] : dir == 1 ? p.tabD[1] : p.tabD[2])
-                : (dir == 0 ? p.tabB[0] : dir == 1 ? p.tabB[1] : p.tabB[2])) + (int64_t)span * NB * NQ + k;
-  };
-
-  // lane constants of the matrix stages
-  const int mrow = lane & 15, mk = lane >> 4;
-  const bool mrow_ok = mrow < NB2;
-  const int mra = mrow_ok ? mrow / NB : 0, mrb = mrow_ok ? mrow % NB : 0;
-  const int idx1 = 4 * ((lane & 3) + 4 * (lane >> 4) + 16 * ((lane >> 2) & 3));
-  const int idx2 = 4 * ((lane >> 4) + 4 * (lane & 3) + 16 * ((lane >> 2) & 3));
-
-  for (int k = lane; k < ND * NROW; k += 64) KS[k] = 0.0;
-  // bit c: slot k = 64 c + lane has a2 >= 1 and b2 >= 1 (shared with the next element of the column)
-  unsigned long long carry_mask = 0;
-  for (int c = 0; c < (ND * NROW + 63) / 64; ++c) {
-    const int k = c * 64 + lane;
-    if (k < ND * NROW && (k / NROW) / NB2 >= 1 && (k % NROW) / (NB * 9) >= 1) carry_mask |= 1ull << c;
-  }
-
-  // ---- pipeline prologue ------------------------------------------------------------------------
-  int el_c[3], el_n[3];
-  int64_t e_cur = element_of(0, el_c);
-  int32_t node_c = lane < ND ? p.dofs[e_cur * ND + lane] : 0, node_n = 0;
-  double ue_r[3];
-  double tab_r[TROUNDS];
-  double geo_r[10];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) ue_r[c] = p.u[(int64_t)node_c * 3 + c];
-#pragma unroll
-  for (int rd = 0; rd < TROUNDS; ++rd) {
-    const int t = rd * 64 + lane;
-    tab_r[rd] = *table_src(el_c, t < 6 * NB * NQ ? t : 0);
-  }
-  {
-    const double* g = p.geo + e_cur * 10 * NQ3 + lane;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) geo_r[k] = g[(int64_t)k * NQ3];
-  }
-  if (n_seq > 1) {
-    const int64_t e1 = element_of(1, el_n);
-    node_n = lane < ND ? p.dofs[e1 * ND + lane] : 0;
-  }
-
-  for (int es = 0; es < n_seq; ++es) {
-    MH_STAMP(0);
-    // ---- stage 0: registers -> LDS, then issue the loads of the NEXT element -------------------
-    if (lane < ND) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) ue[c * ND + lane] = ue_r[c];
-    }
-#pragma unroll
-    for (int rd = 0; rd < TROUNDS; ++rd) {
-      const int t = rd * 64 + lane;
-      if (t < 6 * NB * NQ) tab[t] = tab_r[rd];
-    }
-    double Ji[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Ji[k] = geo_r[k];
-    const double wd = geo_r[9];
-    const int64_t e = e_cur;
-    int el_w[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) el_w[d] = el_c[d];
-    __builtin_amdgcn_wave_barrier();
-
-    constexpr int NK = ND * NROW;   // 2187 slots
-    const bool last = es + 1 >= n_seq;
-
-    MH_STAMP(1);
-    // ---- stage A: constitutive update, lane = quadrature point q = q0 + 4 q1 + 16 q2 -------------
-    double Ahat[27];  // [(m*3 + j)*3 + n] for row I
-    double Phat[3];
-    {
-      const int q0 = lane & 3, q1 = (lane >> 2) & 3, q2 = lane >> 4;
-      double b0[NB], d0[NB], b1[NB], d1[NB], b2[NB], d2[NB];
-#pragma unroll
-      for (int a = 0; a < NB; ++a) {
-        b0[a] = tab_ptr<P>(tab, 0, 0)[a * NQ + q0];
-        d0[a] = tab_ptr<P>(tab, 0, 1)[a * NQ + q0];
-        b1[a] = tab_ptr<P>(tab, 1, 0)[a * NQ + q1];
-        d1[a] = tab_ptr<P>(tab, 1, 1)[a * NQ + q1];
-        b2[a] = tab_ptr<P>(tab, 2, 0)[a * NQ + q2];
-        d2[a] = tab_ptr<P>(tab, 2, 1)[a * NQ + q2];
-      }
-      double H[9];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) H[k] = 0.0;
-#pragma unroll
-      for (int a2 = 0; a2 < NB; ++a2)
-#pragma unroll
-        for (int a1 = 0; a1 < NB; ++a1) {
-          const double tbb = b1[a1] * b2[a2], tdb = d1[a1] * b2[a2], tbd = b1[a1] * d2[a2];
-#pragma unroll
-          for (int a0 = 0; a0 < NB; ++a0) {
-            const int a = a0 + NB * (a1 + NB * a2);
-            const double dn0 = d0[a0] * tbb, dn1 = b0[a0] * tdb, dn2 = b0[a0] * tbd;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              const double uu = ue[i * ND + a];
-              H[i * 3 + 0] += uu * dn0;
-              H[i * 3 + 1] += uu * dn1;
-              H[i * 3 + 2] += uu * dn2;
-            }
-          }
-        }
-      double F[9];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int J = 0; J < 3; ++J) {
-          double sf = (i == J) ? 1.0 : 0.0;
-#pragma unroll
-          for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * Ji[m * 3 + J];
-          F[i + J * 3] = sf;
-        }
-      PointResult<3> w;
-      status |= evaluate_pk1<3>(p.mat, p.dt, p.state, e * NQ3 + lane, F, w);
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        double sp = 0.0;
-#pragma unroll
-        for (int J = 0; J < 3; ++J) sp += w.P[I + J * 3] * Ji[m * 3 + J];
-        Phat[m] = wd * sp;
-      }
-      double A[27];
-      tangent_row_of<3, I>(p.mat.m, w, A);
-      double T[27];
-#pragma unroll
-      for (int J = 0; J < 3; ++J)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int n = 0; n < 3; ++n) {
-            double st = 0.0;
-#pragma unroll
-            for (int Lx = 0; Lx < 3; ++Lx) st += A[(J * 3 + j) * 3 + Lx] * Ji[n * 3 + Lx];
-            T[(J * 3 + j) * 3 + n] = st;
-          }
-#pragma unroll
-      for (int m = 0; m < 3; ++m)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-          for (int n = 0; n < 3; ++n) {
-            double sa = 0.0;
-#pragma unroll
-            for (int J = 0; J < 3; ++J) sa += Ji[m * 3 + J] * T[(J * 3 + j) * 3 + n];
-            Ahat[(m * 3 + j) * 3 + n] = wd * sa;
-          }
-    }
-
-    MH_STAMP(2);
-    // ---- stage R: residual row I by sum factorisation ---------------------------------------------
-    {
-      double* PH = RS;                   // [3 m][64]
-      double* V = PH + 3 * NQ3;          // [3 m][3 a2][16]
-      double* W = V + 3 * NB * NQ * NQ;  // [3 m][9 a1a2][4]
-#pragma unroll
-      for (int m = 0; m < 3; ++m) PH[m * NQ3 + lane] = Phat[m];
-      __builtin_amdgcn_wave_barrier();
-      if (lane < NB * NQ * NQ) {
-        const int q01 = lane % (NQ * NQ), a2 = lane / (NQ * NQ);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          const double* T2 = tab_ptr<P>(tab, 2, m == 2 ? 1 : 0) + a2 * NQ;
-          double sv = 0.0;
-#pragma unroll
-          for (int q2 = 0; q2 < NQ; ++q2) sv += T2[q2] * PH[m * NQ3 + q01 + NQ * NQ * q2];
-          V[(m * NB + a2) * NQ * NQ + q01] = sv;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (lane < NB2 * NQ) {
-        const int q0 = lane % NQ, a12 = lane / NQ, a1 = a12 % NB, a2 = a12 / NB;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          const double* T1 = tab_ptr<P>(tab, 1, m == 1 ? 1 : 0) + a1 * NQ;
-          double sw = 0.0;
-#pragma unroll
-          for (int q1 = 0; q1 < NQ; ++q1) sw += T1[q1] * V[(m * NB + a2) * NQ * NQ + q0 + NQ * q1];
-          W[(m * NB2 + a12) * NQ + q0] = sw;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (lane < ND) {
-        const int a0 = lane % NB, a12 = lane / NB;
-        double sr = 0.0;
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-          const double* T0 = tab_ptr<P>(tab, 0, m == 0 ? 1 : 0) + a0 * NQ;
-#pragma unroll
-          for (int q0 = 0; q0 < NQ; ++q0) sr += T0[q0] * W[(m * NB2 + a12) * NQ + q0];
-        }
-        p.scratch_r[(e * 3 + I) * ND + lane] = sr;
-      }
-    }
-
-    MH_STAMP(3);
-    // ---- loads of the NEXT element, in flight during the matrix stage ------------------------------
-    if (es + 1 < n_seq) {
-      e_cur = element_of(es + 1, el_c);
-      node_c = node_n;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) ue_r[c] = p.u[(int64_t)node_c * 3 + c];
-    #pragma unroll
-      for (int rd = 0; rd < TROUNDS; ++rd) {
-        const int t = rd * 64 + lane;
-        tab_r[rd] = *table_src(el_c, t < 6 * NB * NQ ? t : 0);
-      }
-      const double* g = p.geo + e_cur * 10 * NQ3 + lane;
-#pragma unroll
-      for (int k = 0; k < 10; ++k) geo_r[k] = g[(int64_t)k * NQ3];
-      if (es + 2 < n_seq) {
-        const int64_t e2 = element_of(es + 2, el_n);
-        node_n = lane < ND ? p.dofs[e2 * ND + lane] : 0;
-      }
-    }
-    MH_STAMP(4);
-    // ---- stage C on the matrix pipe ----------------------------------------------------------------
-    // A operands: pair tables of the three directions, lane = (row = pair index, k = quadrature index)
-    double aS[3][4];  // [dir][variant]: 0 B.B, 1 D(a).B(b), 2 B(a).D(b), 3 D.D
-#pragma unroll
-    for (int dir = 0; dir < 3; ++dir) {
-      const double Ba = tab_ptr<P>(tab, dir, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, dir, 1)[mra * NQ + mk];
-      const double Bb = tab_ptr<P>(tab, dir, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, dir, 1)[mrb * NQ + mk];
-      aS[dir][0] = mrow_ok ? Ba * Bb : 0.0;
-      aS[dir][1] = mrow_ok ? Da * Bb : 0.0;
-      aS[dir][2] = mrow_ok ? Ba * Db : 0.0;
-      aS[dir][3] = mrow_ok ? Da * Db : 0.0;
-    }
-    // Contraction chain (no LDS, no lane shuffles):
-    //   S1 (matrix pipe)  D1[q1][q0 | a2b2] = sum_q2 Ahat(q0 q1; q2) TT2[q2][a2b2]
-    //        the constitutive stage's lane = q layout is also the A-operand layout (row = q0 + 4 q1,
-    //        k = q2); the result has q1 on the 4 accumulator registers, q0 on lane bits 5:4.
-    //   S2 (vector pipe)  E_g[a1b1][q0 | a2b2] += sum_q1 T1^m[a1][q1] T1^n[b1][q1] D1[q1]
-    //        a linear combination of the 4 accumulator registers with wave-uniform coefficients,
-    //        grouped by the direction-0 variant g = (m == 0) + 2 (n == 0).
-    //   S3 (matrix pipe)  K[a1b1][a0b0 | a2b2] = sum_g sum_q0 TT0^g[a0b0][q0] E_g[a1b1][q0 | a2b2]
-    //        E is already a B operand (k = q0 on lane bits 5:4, col = a2b2).
-    // pair-table variant of direction d for (m, n): v_d = (m == d) + 2 (n == d)
-    const mh_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
-    // wave-uniform direction-1 tables in scalar registers
-    double uB1[NB][NQ], uD1[NB][NQ];
-#pragma unroll
-    for (int a = 0; a < NB; ++a)
-#pragma unroll
-      for (int q1 = 0; q1 < NQ; ++q1) {
-        const unsigned long long vb = __double_as_longlong(tab_ptr<P>(tab, 1, 0)[a * NQ + q1]);
-        const unsigned long long vd = __double_as_longlong(tab_ptr<P>(tab, 1, 1)[a * NQ + q1]);
-        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)vb), bhi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
-        const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)vd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(vd >> 32));
-        uB1[a][q1] = __longlong_as_double(((unsigned long long)bhi << 32) | blo);
-        uD1[a][q1] = __longlong_as_double(((unsigned long long)dhi << 32) | dlo);
-      }
-    MH_STAMP(5);
-#pragma unroll 1
-    for (int j = 0; j < 3; ++j) {
-      double E[4][NB2];  // [g][a1b1], lane = (q0 on bits 5:4, a2b2 on bits 3:0)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int k = 0; k < NB2; ++k) E[g][k] = 0.0;
-#pragma unroll
-      for (int m = 0; m < 3; ++m)
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-          const int v2 = (m == 2 ? 1 : 0) + (n == 2 ? 2 : 0);
-          const int g = (m == 0 ? 1 : 0) + (n == 0 ? 2 : 0);
-          // static selection of the j-th entry (the j loop stays rolled)
-          const double ah = j == 0 ? Ahat[(m * 3 + 0) * 3 + n] : j == 1 ? Ahat[(m * 3 + 1) * 3 + n] : Ahat[(m * 3 + 2) * 3 + n];
-          const mh_d4 D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ah, aS[2][v2], zero4, 0, 0, 0);
-#pragma unroll
-          for (int b1 = 0; b1 < NB; ++b1) {
-            double U[NQ];
-#pragma unroll
-            for (int q1 = 0; q1 < NQ; ++q1) U[q1] = (n == 1 ? uD1[b1][q1] : uB1[b1][q1]) * D1[q1];
-#pragma unroll
-            for (int a1 = 0; a1 < NB; ++a1) {
-              double acc = E[g][a1 * NB + b1];
-#pragma unroll
-              for (int q1 = 0; q1 < NQ; ++q1) acc += (m == 1 ? uD1[a1][q1] : uB1[a1][q1]) * U[q1];
-              E[g][a1 * NB + b1] = acc;
-            }
-          }
-        }
-      MH_STAMP(6);
-      // S3, then accumulation into KS: all reads first, then all writes (the slots of one block are
-      // distinct; written this way the LDS accesses are not serialised by may-alias ordering)
-      mh_d4 K[NB2];
-#pragma unroll
-      for (int a1b1 = 0; a1b1 < NB2; ++a1b1) {
-        K[a1b1] = zero4;  // rows a0b0 = (lane>>4) + 4 r, cols a2b2
-#pragma unroll
-        for (int g = 0; g < 4; ++g) K[a1b1] = __builtin_amdgcn_mfma_f64_16x16x4f64(aS[0][g], E[g][a1b1], K[a1b1], 0, 0, 0);
-      }
-      MH_STAMP(7);
-      const int ab2 = lane & 15;
-      const bool col_ok = ab2 < NB2;
-      const int a2 = col_ok ? ab2 / NB : 0, b2 = col_ok ? ab2 % NB : 0;
-      double prev[NB2][3];
-#pragma unroll
-      for (int a1b1 = 0; a1b1 < NB2; ++a1b1)
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const int a0b0 = (lane >> 4) + 4 * r;
-          const bool ok = col_ok && a0b0 < NB2;
-          const int a0 = ok ? a0b0 / NB : 0, b0 = ok ? a0b0 % NB : 0;
-          const int idx = (a0 + NB * (a1b1 / NB + NB * a2)) * NROW + (b2 * NB + a1b1 % NB) * 9 + b0 * 3 + j;
-          prev[a1b1][r] = ok ? KS[idx] : 0.0;
-        }
-#pragma unroll
-      for (int a1b1 = 0; a1b1 < NB2; ++a1b1)
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const int a0b0 = (lane >> 4) + 4 * r;
-          const bool ok = col_ok && a0b0 < NB2;
-          const int a0 = ok ? a0b0 / NB : 0, b0 = ok ? a0b0 % NB : 0;
-          const int idx = (a0 + NB * (a1b1 / NB + NB * a2)) * NROW + (b2 * NB + a1b1 % NB) * 9 + b0 * 3 + j;
-          if (ok) KS[idx] = prev[a1b1][r] + K[a1b1][r];
-        }
-      MH_STAMP(8);
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    MH_STAMP(10);
-    // ---- flush: entries shared with the next element of the column stay in KS (moved to their
-    // (a2-1, b2-1) slots); all others go to this (element, I)'s dense scratch piece, coalesced.
-    // Reads, LDS writes and global stores in separate passes (no may-alias serialisation).
-    {
-      double* S = p.scratch_k + (e * 3 + I) * (int64_t)NK;
-      constexpr int NR = (NK + 63) / 64;  // 35
-      double v[NR];
-#pragma unroll
-      for (int c = 0; c < NR; ++c) {
-        const int k = c * 64 + lane;
-        v[c] = k < NK ? KS[k] : 0.0;
-      }
-      const bool do_carry = use_carry && !last;
-#pragma unroll
-      for (int c = 0; c < NR; ++c) {
-        const int k = c * 64 + lane;
-        if (k < NK) KS[k] = 0.0;
-      }
-#pragma unroll
-      for (int c = 0; c < NR; ++c) {
-        const int k = c * 64 + lane;
-        const bool cr = do_carry && ((carry_mask >> c) & 1);
-        if (k < NK) {
-          if (cr) KS[k - (NB2 * NROW + NB * 9)] = v[c];
-          else S[k] = v[c];
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    MH_STAMP(11);
-  }
-#ifdef MH_PROFILE
-  if (lane == 0 && p.prof)
-    for (int k = 0; k < 12; ++k) atomicAdd(&p.prof[k], prof_acc[k]);
-#endif
-}
-
-
-__global__ __launch_bounds__(64) void tensor_p1_kernel(TensorArgs p) {
-  extern __shared__ __align__(16) double smem_p1[];
-  const int comp = blockIdx.x % 3, unit = blockIdx.x / 3;
-  const int eu = unit % p.n_units_u, ev = unit / p.n_units_u;
-  int status = 0;
-  if (comp == 0) tensor_p1_body<0>(p, smem_p1, eu, ev, status);
-  else if (comp == 1) tensor_p1_body<1>(p, smem_p1, eu, ev, status);
-  else tensor_p1_body<2>(p, smem_p1, eu, ev, status);
-  if (status) atomicOr(p.status, status);
-}
+typedef double mh_d4 __attribute__((ext_vector_type(4)));
 
 // phase 2: gather.  Requires: lexicographic numbering, structured CSR, first[e] == e (no repeated
 // interior knots), walk axis == 2.
@@ -529,22 +125,6 @@ inline bool two_phase_supported(const mimi_hip_domain_s* h) {
   for (int d = 1; d < 3; ++d)
     if (h->el_end[d] - h->el_begin[d] <= h->el_end[seq] - h->el_begin[seq]) seq = d;
   return seq == 2;
-}
-
-inline void launch_tensor_two_phase(mimi_hip_domain_s* h, TensorArgs a) {
-  constexpr int NK = 27 * 81;
-  h->scratch_k.resize((size_t)h->n_el * 3 * NK);
-  h->scratch_r.resize((size_t)h->n_el * 3 * 27);
-  a.scratch_k = h->scratch_k.ptr;
-  a.scratch_r = h->scratch_r.ptr;
-  a.n_units_u = a.box_n[a.u_axis];
-  a.n_units_v = a.box_n[a.v_axis];
-  const size_t lds = MfmaLds::total * sizeof(double);
-  hipLaunchKernelGGL(tensor_p1_kernel, dim3(a.n_units_u * a.n_units_v * 3), dim3(64), lds, h->stream, a);
-  MH_HIP(hipGetLastError());
-  const int64_t n_nodes = h->n_nodes;
-  hipLaunchKernelGGL(tensor_p2_kernel, dim3((unsigned)((3 * n_nodes + 3) / 4)), dim3(256), 0, h->stream, a, n_nodes);
-  MH_HIP(hipGetLastError());
 }
 
 }  // namespace mimi_hip
