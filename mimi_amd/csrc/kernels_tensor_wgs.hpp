@@ -181,11 +181,74 @@ struct WgsPoint<MIMI_HIP_MAT_NEOHOOKEAN> {
   double mu_w, c1_w, c2_w;     // coefficients times wd
 };
 
+// J2 (small-strain return mapping inside finite kinematics, materials.hpp tangent_row_of): with G = Jinv F^-1,
+// N = G Jinv^T, Q[n][j] = sum_L s_jL Jinv[n][L], S_i[m] = sum_k sigma_ik G[m][k], Ts_i[m] = sum_k s_ik G[m][k]
+// (s = trial deviator), the pulled-back tangent row is
+//   Ahat_i[m][j][n] = wd J ( G[n][j] S_i[m] - G[m][j] S_i[n] + (K - beta 2G/3) G[m][i] Jinv[n][j]
+//                            + beta G (d_ij N[m][n] + G[m][j] Jinv[n][i]) - 2G gamma Ts_i[m] Q[n][j] )
 template<>
 struct WgsPoint<MIMI_HIP_MAT_J2> {
-  PointResult<3> w;
-  double Ji[9], wd;
+  double G[9], Ji[9], N[9], Q[9], sig[9], st[9], Phat[9];
+  double wdJ, Kc, hb, gg;   // wd J, K - beta 2G/3, beta G, 2G gamma
 };
+
+// fills WgsPoint<J2> from the PointResult of the material pre-pass
+MH_DEV void wgs_j2_point(const mimi_hip_material& m, const PointResult<3>& w, const double* Ji, double wd,
+                         WgsPoint<MIMI_HIP_MAT_J2>& s) {
+  double beta = 1.0, gamma = 0.0;
+  if (w.plastic) {
+    const double q = w.q, G = m.G;
+    beta = 1.0 - 3.0 * G * w.delta / q;
+    gamma = 3.0 * G * (1.5 / q) * (1.0 / ((3.0 * G + w.hprime) * q) - w.delta / (q * q));
+  }
+  const double G2 = 2.0 * m.G;
+  s.wdJ = wd * w.detF;
+  s.Kc = m.K - beta * G2 / 3.0;
+  s.hb = 0.5 * beta * G2;
+  s.gg = G2 * gamma;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    s.Ji[k] = Ji[k];
+    s.sig[k] = w.sigma[k];
+    s.st[k] = w.s_trial[k];
+  }
+#pragma unroll
+  for (int mm = 0; mm < 3; ++mm)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double g = 0.0;
+#pragma unroll
+      for (int Jx = 0; Jx < 3; ++Jx) g += Ji[mm * 3 + Jx] * w.Finv[Jx + c * 3];
+      s.G[mm * 3 + c] = g;
+    }
+#pragma unroll
+  for (int mm = 0; mm < 3; ++mm)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      double v = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v += s.G[mm * 3 + k] * Ji[n * 3 + k];
+      s.N[mm * 3 + n] = v;
+    }
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double v = 0.0;
+#pragma unroll
+      for (int Lx = 0; Lx < 3; ++Lx) v += w.s_trial[j + Lx * 3] * Ji[n * 3 + Lx];
+      s.Q[n * 3 + j] = v;
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int mm = 0; mm < 3; ++mm) {
+      double sp = 0.0;
+#pragma unroll
+      for (int Jx = 0; Jx < 3; ++Jx) sp += w.P[i + Jx * 3] * Ji[mm * 3 + Jx];
+      s.Phat[i * 3 + mm] = wd * sp;
+    }
+}
 
 template<int KIND>
 MH_DEV int wgs_x_point(const TensorArgs& p, int64_t pt, const double* F, const double* Ji, double wd, WgsPoint<KIND>& s) {
@@ -230,10 +293,10 @@ MH_DEV int wgs_x_point(const TensorArgs& p, int64_t pt, const double* F, const d
   } else {
     MaterialDev mat = p.mat;
     mat.m.kind = KIND;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) s.Ji[k] = Ji[k];
-    s.wd = wd;
-    return evaluate_pk1<3>(mat, p.dt, p.state, pt, F, s.w);
+    PointResult<3> w;
+    const int status = evaluate_pk1<3>(mat, p.dt, p.state, pt, F, w);
+    wgs_j2_point(p.mat.m, w, Ji, wd, s);
+    return status;
   }
 }
 
@@ -267,45 +330,32 @@ MH_DEV void wgs_x_row(const TensorArgs& p, double* lds, int lane, int64_t e, int
       }
     }
   } else {
-    const double* Ji = s.Ji;
-    const double wd = s.wd;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) Phat[m] = s.Phat[I * 3 + m];
+    double S[3], Ts[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
-      double sp = 0.0;
+      double a = 0.0, b = 0.0;
 #pragma unroll
-      for (int J = 0; J < 3; ++J) sp += s.w.P[I + J * 3] * Ji[m * 3 + J];
-      Phat[m] = wd * sp;
+      for (int k = 0; k < 3; ++k) {
+        a += s.sig[I + k * 3] * s.G[m * 3 + k];
+        b += s.st[I + k * 3] * s.G[m * 3 + k];
+      }
+      S[m] = a;
+      Ts[m] = b;
     }
-    mimi_hip_material mm = p.mat.m;
-    mm.kind = KIND;
-    double A[27];
-    tangent_row_of<3, I>(mm, s.w, A);
 #pragma unroll
-    for (int k = 0; k < 27; ++k) WGS_PIN(A[k]);
-    // one column component j at a time: T[J][n] = sum_L A[J][j][L] Jinv[n][L], then Ahat[m][j][n]
+    for (int m = 0; m < 3; ++m)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      double T[9];
-#pragma unroll
-      for (int J = 0; J < 3; ++J)
+      for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
-          double st = 0.0;
-#pragma unroll
-          for (int Lx = 0; Lx < 3; ++Lx) st += A[(J * 3 + j) * 3 + Lx] * Ji[n * 3 + Lx];
-          T[J * 3 + n] = st;
+          double v = s.G[n * 3 + j] * S[m] - s.G[m * 3 + j] * S[n];
+          v += s.Kc * s.G[m * 3 + I] * s.Ji[n * 3 + j];
+          v += s.hb * ((I == j ? s.N[m * 3 + n] : 0.0) + s.G[m * 3 + j] * s.Ji[n * 3 + I]);
+          v -= s.gg * Ts[m] * s.Q[n * 3 + j];
+          AH[((m * 3 + j) * 3 + n) * NQ3 + lane] = s.wdJ * v;
         }
-#pragma unroll
-      for (int m = 0; m < 3; ++m)
-#pragma unroll
-        for (int n = 0; n < 3; ++n) {
-          double sa = 0.0;
-#pragma unroll
-          for (int J = 0; J < 3; ++J) sa += Ji[m * 3 + J] * T[J * 3 + n];
-          AH[((m * 3 + j) * 3 + n) * NQ3 + lane] = wd * sa;
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    }
   }
   // residual row I by sum factorisation (as kernels_tensor_2phase.hpp)
   double* PH = RS;                   // [3 m][64]
@@ -467,10 +517,9 @@ MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& st
         status |= wgs_x_point<KIND>(p, e * NQ3 + lane, F, Ji, wd, s);
       } else {
         // J2: the material was evaluated by tensor_point_kernel
-        wgs_point_load(p.scratch_pt + e * (int64_t)(WGS_PT_FIELDS * NQ3), lane, s.w);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) s.Ji[k] = Ji[k];
-        s.wd = wd;
+        PointResult<3> w;
+        wgs_point_load(p.scratch_pt + e * (int64_t)(WGS_PT_FIELDS * NQ3), lane, w);
+        wgs_j2_point(p.mat.m, w, Ji, wd, s);
       }
       wgs_x_row<KIND, 0>(p, lds, lane, e, par, s);
     }
@@ -691,6 +740,7 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
   // the steps before the first element of this wave run on zeros (their results are never stored)
 #pragma unroll
   for (int c = 0; c < ND; ++c) AH[c * NQ3 + lane] = 0.0;
+  for (int t = lane; t < 2 * 6 * NB * NQ; t += 64) lds[L::off_tab + t] = 0.0;
 
   for (int it = 0; it <= n_seq; ++it) {
 #pragma unroll
@@ -700,7 +750,7 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
       const bool valid = es >= 0 && es < n_seq;
       double ah[9];
       // ---- read window ---------------------------------------------------------------------------
-      if (j == 0 && valid) {
+      if (j == 0) {   // (branch-free in the step loop: before the first element the tables read as zeros)
         const double* tab = lds + L::off_tab + (es & 1) * 6 * NB * NQ;
         {
           const double Ba = tab_ptr<P>(tab, 0, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 0, 1)[mra * NQ + mk];
@@ -767,13 +817,9 @@ MH_DEV void wgs_y_skip(const TensorArgs& p) {
 #define WGS_Y_ARGS p, smem_wgs, eu, ev
 #endif
 
-#ifndef WGS_J2_OCC
-#define WGS_J2_OCC(KIND) ((KIND) == MIMI_HIP_MAT_NEOHOOKEAN ? 2 : 1)
-#endif
-// Two workgroups per CU (256 registers per wave) for neo-Hookean; the J2 point wave (return mapping,
-// dual-number hardening, generic tangent row) does not fit that budget yet and runs one workgroup per CU.
+// Two workgroups per CU (256 registers per wave) for both materials.
 template<int KIND>
-__global__ __launch_bounds__(256, WGS_J2_OCC(KIND)) void tensor_wgs_kernel(TensorArgs p) {
+__global__ __launch_bounds__(256, 2) void tensor_wgs_kernel(TensorArgs p) {
   extern __shared__ __align__(16) double smem_wgs[];
   // Wave w of a workgroup lands on SIMD w; the point wave idles more than the contraction waves, so
   // the role of a wave rotates with the workgroup and every SIMD hosts a mix of roles.
