@@ -123,6 +123,7 @@ class InterfaceExchange:
 
     def _exchange(self, with_grad):
         torch, dist = self.torch, self.dist
+        staged = self.r.is_cuda and dist.get_backend() == "gloo"
         ops = []
         for s in self.sides:
             ns, nr = s["srows"].numel(), s["rrows"].numel()
@@ -131,6 +132,15 @@ class InterfaceExchange:
             s["send"][:ns] = self.r[s["srows"]]
             if with_grad:
                 s["send"][ns:] = self.A[s["sidx"]]
+            if staged:
+                # gloo moves host memory only: stage device buffers through the host (test rigs without RCCL)
+                s["send_host"] = s["send"][:n_send].cpu()
+                s["recv_host"] = torch.empty(n_recv, dtype=self.r.dtype)
+                if n_send:
+                    ops.append(dist.P2POp(dist.isend, s["send_host"], s["peer"]))
+                if n_recv:
+                    ops.append(dist.P2POp(dist.irecv, s["recv_host"], s["peer"]))
+                continue
             if n_send:
                 ops.append(dist.P2POp(dist.isend, s["send"][:n_send], s["peer"]))
             if n_recv:
@@ -142,6 +152,8 @@ class InterfaceExchange:
             nr = s["rrows"].numel()
             if nr == 0:
                 continue
+            if staged:
+                s["recv"][:s["recv_host"].numel()] = s["recv_host"].to(self.r.device)
             self.r[s["rrows"]] += s["recv"][:nr]
             if with_grad:
                 self.A[s["ridx"]] += s["recv"][nr:nr + s["ridx"].numel()]

@@ -1,0 +1,94 @@
+"""N > 1 path with the HIP kernels: two (three) processes share the one GPU of the test box, each integrates
+its element slab, the interface rows travel through `gloo` (staged through the host; RCCL needs one GPU per
+rank); every rank then checks the rows it owns against its own whole-patch assembly."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n_el, mode, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        import mimi_amd
+        from mimi_amd import parallel
+        from mimi_amd.integrators import CSRPattern, NonlinearSolid
+        dev = torch.device("cuda", 0)
+        patch = mimi_amd.BSplinePatch.block(n_el, 2)
+        pattern = CSRPattern.of_bspline_patch(patch, on_device=True)
+        shard = parallel.SlabShard(patch, pattern, rank, world)
+        G = NonlinearSolid("domain", bench.make_material("neohookean"), pattern, patch=patch,
+                           element_box=shard.element_box).Prepare()
+        # the library enqueues on the stream it is given: the same (non-default: a null handle means "the
+        # handle's own stream") one the exchange's torch ops use, as in bench.py
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        G.SetStream(stream.cuda_stream)
+        u = torch.from_numpy(bench.synthetic_u(patch)).to(dev)
+        r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
+        A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
+        ex = parallel.InterfaceExchange(shard, r, A, dev, mode=mode)
+        for _ in range(2):                        # twice: zero_interface must reset the shared rows
+            ex.zero_interface(True)
+            G.AddDomainResidualAndGrad(u, 1.0, r, A)
+            ex.sum_residual_and_grad()
+        G.Synchronize()
+        Gf = NonlinearSolid("domain", bench.make_material("neohookean"), pattern, patch=patch).Prepare()
+        rf = torch.zeros_like(r)
+        Af = torch.zeros_like(A)
+        Gf.AddDomainResidualAndGrad(u, 1.0, rf, Af)
+        Gf.Synchronize()
+        # rows of the owned node planes that are interface planes hold one step's sum; interior rows two steps'
+        mi_axis = patch.node_multi_index()[shard.axis]
+        owned = np.nonzero(np.isin(mi_axis, ex.owned_node_planes()))[0]
+        shared_planes = set()
+        for nb in (rank - 1, rank + 1):
+            if 0 <= nb < world:
+                shared_planes.update(shard.interface_node_planes(nb))
+        rowptr = pattern.rowptr.cpu().numpy() if hasattr(pattern.rowptr, "cpu") else np.asarray(pattern.rowptr)
+        r_h, A_h, rf_h, Af_h = r.cpu().numpy(), A.cpu().numpy(), rf.cpu().numpy(), Af.cpu().numpy()
+        ok = True
+        worst = [0.0, 0.0, 0.0, 0.0]   # r / A error on shared planes, on interior planes
+        for node in owned:
+            shared = mi_axis[node] in shared_planes
+            mult = 1.0 if shared else 2.0
+            for i in range(3):
+                row = node * 3 + i
+                s, t = rowptr[row], rowptr[row + 1]
+                worst[0 if shared else 2] = max(worst[0 if shared else 2], abs(r_h[row] - mult * rf_h[row]))
+                worst[1 if shared else 3] = max(worst[1 if shared else 3], np.abs(A_h[s:t] - mult * Af_h[s:t]).max())
+        scale_r, scale_A = np.abs(rf_h).max(), np.abs(Af_h).max()
+        ok = worst[0] < 1e-12 * scale_r and worst[2] < 1e-12 * scale_r and worst[1] < 1e-12 * scale_A and worst[3] < 1e-12 * scale_A
+        q.put((rank, bool(ok), len(owned) if ok else repr(worst)))
+    except Exception as exc:  # pragma: no cover
+        q.put((rank, False, repr(exc)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_el,mode", [(2, (4, 6, 3), "owner"), (3, (3, 4, 9), "owner"), (2, (5, 4, 3), "replicate")])
+def test_slabs_on_one_gpu(world, n_el, mode):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_el, mode, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(ok is True for _, ok, _ in results), results
+    if mode == "owner":
+        assert sum(n for _, _, n in results) == int(np.prod([n + 2 for n in n_el]))
