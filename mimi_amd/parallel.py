@@ -109,6 +109,14 @@ class InterfaceExchange:
             self.sides.append(dict(peer=nb, srows=srows, sidx=sidx, rrows=rrows, ridx=ridx,
                                    send=torch.empty(srows.numel() + sidx.numel(), dtype=r.dtype, device=device),
                                    recv=torch.empty(rrows.numel() + ridx.numel(), dtype=r.dtype, device=device)))
+        # all shared rows / values of this rank in one index set each (zero_interface: two kernels per step)
+        if self.sides:
+            if mode == "replicate":
+                self._zero_rows = torch.cat([s["srows"] for s in self.sides])
+                self._zero_idx = torch.cat([s["sidx"] for s in self.sides])
+            else:
+                self._zero_rows = torch.cat([t for s in self.sides for t in (s["srows"], s["rrows"])])
+                self._zero_idx = torch.cat([t for s in self.sides for t in (s["sidx"], s["ridx"])])
 
     def owned_node_planes(self):
         """Node planes along the sharding axis whose rows are complete on this rank after an exchange."""
@@ -129,9 +137,10 @@ class InterfaceExchange:
             ns, nr = s["srows"].numel(), s["rrows"].numel()
             n_send = ns + (s["sidx"].numel() if with_grad else 0)
             n_recv = nr + (s["ridx"].numel() if with_grad else 0)
-            s["send"][:ns] = self.r[s["srows"]]
-            if with_grad:
-                s["send"][ns:] = self.A[s["sidx"]]
+            if ns:
+                torch.index_select(self.r, 0, s["srows"], out=s["send"][:ns])
+                if with_grad:
+                    torch.index_select(self.A, 0, s["sidx"], out=s["send"][ns:n_send])
             if staged:
                 # gloo moves host memory only: stage device buffers through the host (test rigs without RCCL)
                 s["send_host"] = s["send"][:n_send].cpu()
@@ -154,19 +163,17 @@ class InterfaceExchange:
                 continue
             if staged:
                 s["recv"][:s["recv_host"].numel()] = s["recv_host"].to(self.r.device)
-            self.r[s["rrows"]] += s["recv"][:nr]
+            self.r.index_add_(0, s["rrows"], s["recv"][:nr])          # the indices are unique
             if with_grad:
-                self.A[s["ridx"]] += s["recv"][nr:nr + s["ridx"].numel()]
+                self.A.index_add_(0, s["ridx"], s["recv"][nr:nr + s["ridx"].numel()])
 
     def zero_interface(self, with_grad=True):
         """Zero the rows of all shared node planes (sent and received ones)."""
-        for s in self.sides:
-            for rows, idx in ((s["srows"], s["sidx"]), (s["rrows"], s["ridx"])):
-                if rows.numel() == 0 or (self.mode == "replicate" and rows is s["rrows"]):
-                    continue
-                self.r[rows] = 0.0
-                if with_grad:
-                    self.A[idx] = 0.0
+        if not self.sides:
+            return
+        self.r.index_fill_(0, self._zero_rows, 0.0)
+        if with_grad:
+            self.A.index_fill_(0, self._zero_idx, 0.0)
 
     def sum_residual(self):
         self._exchange(False)

@@ -26,12 +26,12 @@ for world in (2, 4, 8):
     def pack_unpack():
         for s in ex.sides:
             ns = s["srows"].numel()
-            s["send"][:ns] = r[s["srows"]]
-            s["send"][ns:] = A[s["sidx"]]
+            torch.index_select(r, 0, s["srows"], out=s["send"][:ns])
+            torch.index_select(A, 0, s["sidx"], out=s["send"][ns:ns + s["sidx"].numel()])
         for s in ex.sides:
             nr = s["rrows"].numel()
-            r[s["rrows"]] += s["recv"][:nr]
-            A[s["ridx"]] += s["recv"][nr:nr + s["ridx"].numel()]
+            r.index_add_(0, s["rrows"], s["recv"][:nr])
+            A.index_add_(0, s["ridx"], s["recv"][nr:nr + s["ridx"].numel()])
     t_p = timed(pack_unpack)
     vol = sum(s["send"].numel() for s in ex.sides) * 8 / 1e6
     print(f"world {world}: slab {shard.element_box}: assembly {t_c:.2f} ms, zero_interface {t_z:.2f} ms, pack+unpack {t_p:.2f} ms, "
