@@ -39,13 +39,17 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
   __shared__ double sums_all[4][LMAX + 1];
   const int wave = threadIdx.x >> 6;
   const int64_t gw = (int64_t)blockIdx.x * 4 + wave;   // one wave per CSR row (node A, component I)
-  const int64_t A = gw / 3;
+  const int64_t Al = gw / 3;                            // node index inside the shard's node box
   const int I = (int)(gw % 3);
   const int lane = threadIdx.x & 63;
-  if (A >= n_nodes) return;
+  if (Al >= n_nodes) return;
   double* sums = sums_all[wave];
   const int n0 = p.n_ctrl[0], n1 = p.n_ctrl[1], n2 = p.n_ctrl[2];
-  const int A0 = A % n0, A1 = (A / n0) % n1, A2 = A / ((int64_t)n0 * n1);
+  // the nodes this shard's elements touch: box_begin[d] .. box_begin[d] + box_n[d] + P - 1 per direction
+  const int m0 = p.box_n[0] + P, m1 = p.box_n[1] + P;
+  const int A0 = p.box_begin[0] + (int)(Al % m0), A1 = p.box_begin[1] + (int)((Al / m0) % m1);
+  const int A2 = p.box_begin[2] + (int)(Al / ((int64_t)m0 * m1));
+  const int64_t A = A0 + (int64_t)n0 * (A1 + (int64_t)n1 * A2);
   // elements of THIS shard containing node A: e_d in [A_d - P, A_d] clipped to the box
   const int bx0 = p.box_begin[0], bx1 = p.box_begin[1], bx2 = p.box_begin[2];
   const int ex_lo = max(A0 - P, bx0), ex_hi = min(A0, bx0 + p.box_n[0] - 1);
@@ -119,12 +123,8 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
 }
 
 inline bool two_phase_supported(const mimi_hip_domain_s* h) {
-  if (!(h->structured_csr || h->structured_perm) || !h->first_is_identity) return false;
-  // walk axis (shortest, ties -> last) must be the third direction
-  int seq = 0;
-  for (int d = 1; d < 3; ++d)
-    if (h->el_end[d] - h->el_begin[d] <= h->el_end[seq] - h->el_begin[seq]) seq = d;
-  return seq == 2;
+  // (the phase-1 kernels always walk the third direction, whatever the shape of the element box)
+  return (h->structured_csr || h->structured_perm) && h->first_is_identity;
 }
 
 }  // namespace mimi_hip

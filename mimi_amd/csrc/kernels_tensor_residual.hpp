@@ -163,11 +163,14 @@ __global__ __launch_bounds__(256) void tensor_residual_kernel(TensorArgs p, int 
 // one wave per node: lane = element (dz, dy, dx) of the 3 x 3 x 3 neighbourhood, fixed-shape tree sum
 __global__ __launch_bounds__(256) void tensor_residual_gather_kernel(TensorArgs p, int64_t n_nodes) {
   constexpr int P = 2, NB = 3, ND = 27;
-  const int64_t A = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t Al = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // node index inside the shard's node box
   const int lane = threadIdx.x & 63;
-  if (A >= n_nodes) return;
+  if (Al >= n_nodes) return;
   const int n0 = p.n_ctrl[0], n1 = p.n_ctrl[1];
-  const int A0 = A % n0, A1 = (A / n0) % n1, A2 = A / ((int64_t)n0 * n1);
+  const int m0 = p.box_n[0] + P, m1 = p.box_n[1] + P;
+  const int A0 = p.box_begin[0] + (int)(Al % m0), A1 = p.box_begin[1] + (int)((Al / m0) % m1);
+  const int A2 = p.box_begin[2] + (int)(Al / ((int64_t)m0 * m1));
+  const int64_t A = A0 + (int64_t)n0 * (A1 + (int64_t)n1 * A2);
   const int bx0 = p.box_begin[0], bx1 = p.box_begin[1], bx2 = p.box_begin[2];
   const int ex_lo = max(A0 - P, bx0), ex_hi = min(A0, bx0 + p.box_n[0] - 1);
   const int ey_lo = max(A1 - P, bx1), ey_hi = min(A1, bx1 + p.box_n[1] - 1);
@@ -202,7 +205,7 @@ inline void launch_tensor_residual(mimi_hip_domain_s* h, TensorArgs a) {
   else
     hipLaunchKernelGGL(tensor_residual_kernel<MIMI_HIP_MAT_J2>, dim3(blocks), dim3(256), 0, h->stream, a, (int)h->n_el);
   MH_HIP(hipGetLastError());
-  const int64_t n_nodes = h->n_nodes;
+  const int64_t n_nodes = (int64_t)(a.box_n[0] + 2) * (a.box_n[1] + 2) * (a.box_n[2] + 2);   // nodes of the shard
   hipLaunchKernelGGL(tensor_residual_gather_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, h->stream, a, n_nodes);
   MH_HIP(hipGetLastError());
 }

@@ -40,6 +40,32 @@ class SlabShard:
         self.element_box = (begin, end)
         self.n_local_elements = int(np.prod([end[d] - begin[d] for d in range(patch.dim)]))
 
+    def overlap_boxes(self):
+        """Split of this slab for overlapping the exchange with compute: (boundary boxes, interior box).
+        The rows of the node planes shared with a neighbour only receive contributions from the `p`
+        element layers next to that neighbour, so those layers are integrated first, their interface
+        rows go on the wire, and the interior is integrated while they travel.  ([], whole slab) when
+        the slab is too thin or has no neighbour."""
+        b, e = self.element_box
+        lo, hi = b[self.axis], e[self.axis]
+        p = self.patch.degrees[self.axis]
+        has_lower, has_upper = self.rank > 0, self.rank < self.world_size - 1
+        need = (p if has_lower else 0) + (p if has_upper else 0)
+        if need == 0 or hi - lo < need + 1:
+            return [], (list(b), list(e))
+
+        def box(x0, x1):
+            bb, ee = list(b), list(e)
+            bb[self.axis], ee[self.axis] = x0, x1
+            return bb, ee
+
+        boundary = []
+        if has_lower:
+            boundary.append(box(lo, lo + p))
+        if has_upper:
+            boundary.append(box(hi - p, hi))
+        return boundary, box(lo + (p if has_lower else 0), hi - (p if has_upper else 0))
+
     def interface_node_planes(self, neighbour):
         """Node-plane indices along `axis` shared with rank `neighbour` (= rank +- 1)."""
         p = self.patch.degrees[self.axis]
@@ -129,7 +155,8 @@ class InterfaceExchange:
         hi = int(sh.starts[sh.rank + 1]) + p // 2 if sh.rank < sh.world_size - 1 else n_planes
         return list(range(lo, hi))
 
-    def _exchange(self, with_grad):
+    def start(self, with_grad):
+        """Pack the rows the neighbours need and put them on the wire (asynchronous with "nccl")."""
         torch, dist = self.torch, self.dist
         staged = self.r.is_cuda and dist.get_backend() == "gloo"
         ops = []
@@ -154,9 +181,14 @@ class InterfaceExchange:
                 ops.append(dist.P2POp(dist.isend, s["send"][:n_send], s["peer"]))
             if n_recv:
                 ops.append(dist.P2POp(dist.irecv, s["recv"][:n_recv], s["peer"]))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        self._pending = (dist.batch_isend_irecv(ops) if ops else [], staged, with_grad)
+
+    def finish(self):
+        """Wait for the neighbours' rows and add them into the rows this rank owns."""
+        reqs, staged, with_grad = self._pending
+        self._pending = None
+        for req in reqs:
+            req.wait()
         for s in self.sides:
             nr = s["rrows"].numel()
             if nr == 0:
@@ -166,6 +198,10 @@ class InterfaceExchange:
             self.r.index_add_(0, s["rrows"], s["recv"][:nr])          # the indices are unique
             if with_grad:
                 self.A.index_add_(0, s["ridx"], s["recv"][nr:nr + s["ridx"].numel()])
+
+    def _exchange(self, with_grad):
+        self.start(with_grad)
+        self.finish()
 
     def zero_interface(self, with_grad=True):
         """Zero the rows of all shared node planes (sent and received ones)."""

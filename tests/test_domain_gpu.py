@@ -10,7 +10,7 @@ from _cases import JC_TEST, oracle_material, synthetic_u
 pytestmark = pytest.mark.gpu
 
 # (5,6,4) and (4,4,5): columns of 4 / 5 elements along the walked (third) axis, so that the two-step carry
-# (2,2) -> (1,1) -> (0,0) of the two-phase kernels is exercised; (4,5,6) walks the FIRST axis (fallback kernels)
+# (2,2) -> (1,1) -> (0,0) of the two-phase kernels is exercised; (4,5,6): the walked (third) axis is the longest one
 CASES = [((2, 2), 3, [5.0, 1.0]), ((3, 4), 2, None), ((3, 2, 2), 2, None), ((2, 2, 1), 3, None),
          ((4, 3, 2), 1, None), ((8, 8, 2), 2, None), ((5, 6, 4), 2, [2.5, 3.0, 1.0]), ((5, 5, 5), 2, None),
          ((4, 5, 6), 2, None)]

@@ -28,22 +28,36 @@ def _worker(rank, world, port, n_el, mode, q):
         patch = mimi_amd.BSplinePatch.block(n_el, 2)
         pattern = CSRPattern.of_bspline_patch(patch, on_device=True)
         shard = parallel.SlabShard(patch, pattern, rank, world)
-        G = NonlinearSolid("domain", bench.make_material("neohookean"), pattern, patch=patch,
-                           element_box=shard.element_box).Prepare()
         # the library enqueues on the stream it is given: the same (non-default: a null handle means "the
         # handle's own stream") one the exchange's torch ops use, as in bench.py
         stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(stream)
-        G.SetStream(stream.cuda_stream)
+        overlap = mode.endswith("+overlap")
+        mode = mode.split("+")[0]
+        boundary_boxes, interior_box = shard.overlap_boxes() if overlap else ([], shard.element_box)
+        handles = []
+        for box in boundary_boxes + [interior_box]:
+            g = NonlinearSolid("domain", bench.make_material("neohookean"), pattern, patch=patch, element_box=box).Prepare()
+            g.SetStream(stream.cuda_stream)
+            handles.append(g)
+        assert sum(g.n_elements_ for g in handles) == shard.n_local_elements
         u = torch.from_numpy(bench.synthetic_u(patch)).to(dev)
         r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
         A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
         ex = parallel.InterfaceExchange(shard, r, A, dev, mode=mode)
         for _ in range(2):                        # twice: zero_interface must reset the shared rows
             ex.zero_interface(True)
-            G.AddDomainResidualAndGrad(u, 1.0, r, A)
-            ex.sum_residual_and_grad()
-        G.Synchronize()
+            if len(handles) > 1:
+                for g in handles[:-1]:            # the element layers next to the neighbours first ...
+                    g.AddDomainResidualAndGrad(u, 1.0, r, A)
+                ex.start(True)                    # ... their interface rows travel ...
+                handles[-1].AddDomainResidualAndGrad(u, 1.0, r, A)   # ... while the interior is integrated
+                ex.finish()
+            else:
+                handles[0].AddDomainResidualAndGrad(u, 1.0, r, A)
+                ex.sum_residual_and_grad()
+        for g in handles:
+            g.Synchronize()
         Gf = NonlinearSolid("domain", bench.make_material("neohookean"), pattern, patch=patch).Prepare()
         rf = torch.zeros_like(r)
         Af = torch.zeros_like(A)
@@ -77,7 +91,8 @@ def _worker(rank, world, port, n_el, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_el,mode", [(2, (4, 6, 3), "owner"), (3, (3, 4, 9), "owner"), (2, (5, 4, 3), "replicate")])
+@pytest.mark.parametrize("world,n_el,mode", [(2, (4, 6, 3), "owner"), (3, (3, 4, 9), "owner"), (2, (5, 4, 3), "replicate"),
+                                             (3, (3, 4, 15), "owner+overlap"), (2, (4, 10, 3), "owner+overlap")])
 def test_slabs_on_one_gpu(world, n_el, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -90,5 +105,5 @@ def test_slabs_on_one_gpu(world, n_el, mode):
     for pr in procs:
         pr.join(timeout=60)
     assert all(ok is True for _, ok, _ in results), results
-    if mode == "owner":
+    if mode.startswith("owner"):
         assert sum(n for _, _, n in results) == int(np.prod([n + 2 for n in n_el]))
