@@ -33,7 +33,10 @@ typedef double mh_d4 __attribute__((ext_vector_type(4)));
 // row is  t = t_base(element) + t_off(lane)  with a per-lane constant t_off.  Row sums are built
 // in LDS (one wave adds piece after piece: fixed order, no conflicts inside an instruction), then
 // A[row] += grad_factor * sum is one coalesced read-modify-write per row.
-__global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_nodes) {
+#ifndef P2_WAVES
+#define P2_WAVES 5
+#endif
+__global__ __launch_bounds__(256, P2_WAVES) void tensor_p2_kernel(TensorArgs p, int64_t n_nodes) {
   constexpr int P = 2, NB = 3, ND = 27, NROW = 81, NK = ND * NROW;
   constexpr int LMAX = 3 * 125;
   __shared__ double sums_all[4][LMAX + 1];
