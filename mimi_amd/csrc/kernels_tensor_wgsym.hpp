@@ -316,9 +316,7 @@ inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a) {
   MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
   MH_HIP(hipGetLastError());
-  const int64_t n_nodes = (int64_t)(a.box_n[0] + 2) * (a.box_n[1] + 2) * (a.box_n[2] + 2);   // nodes of the shard
-  hipLaunchKernelGGL(tensor_p2_kernel, dim3((unsigned)((3 * n_nodes + 3) / 4)), dim3(256), 0, h->stream, a, n_nodes);
-  MH_HIP(hipGetLastError());
+  launch_tensor_p2(h, a);
 }
 
 }  // namespace mimi_hip
