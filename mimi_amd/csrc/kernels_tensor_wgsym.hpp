@@ -6,21 +6,20 @@
 // kernels_tensor_2phase.hpp; the stored matrix is exactly symmetric.
 //
 // Workgroup = 4 waves as in kernels_tensor_wgs.hpp (same roles, same register carry, same LDS
-// hand-off), but TWO steps per element instead of three:
+// hand-off), but TWO steps per element instead of three, and homogeneous ones -- the three
+// contraction waves do equally expensive blocks in the same step (a diagonal block costs 0.73 of an
+// off-diagonal one, and a lock step lasts as long as its slowest wave):
 //
-//   step A(e)  [global step 2e-1]   Y0: block (2,1) of element e-1   X: rows 0, 1 of element e
-//                                   Y1: block (2,0)      "
-//                                   Y2: block (2,2)      "
-//   step B(e)  [global step 2e]     Y0: block (0,0) of element e     X: row 2 of element e, then the
-//                                   Y1: block (1,1)      "               quadrature-point stage of e+1
-//                                   Y2: block (1,0)      "
+//   step D(e)   Y0: block (0,0) of element e   Y1: (1,1)   Y2: (2,2)     X: quadrature-point stage of e+1
+//   step O(e)   Y0: block (1,0) of element e   Y1: (2,0)   Y2: (2,1)     X: rows 0, 1, 2 of element e+1
 //   a step = [Y: flush / read operands from LDS] barrier [X, Y: compute, write LDS] barrier
 //
-// Rows 0, 1 of Ahat are read (into registers) in the read window of B(e) and rewritten by X in A(e+1);
-// row 2 is read in A(e+1) and rewritten in B(e+1): one LDS buffer.  The three store-transposition
-// buffers (one per piece i) are written by all three contraction waves during B(e) and A(e+1) and
-// flushed, piece w by wave Y_w, in the read window of B(e+1).  After the last element one more step
-// flushes the carried rows.  Every wave executes 2 (2 n + 3) barriers.
+// The rows of Ahat of element e are written during O(e-1), read (into registers) in the read windows
+// of D(e) and O(e) and rewritten during O(e): one LDS buffer, only the 54 entries (i, j <= i) kept.
+// The three store-transposition buffers (one per piece i) are written by all three contraction waves
+// during D(e) and O(e) and flushed, piece w by wave Y_w, in the read window of D(e+1).  A prologue
+// step lets X write the rows of element 0; after the last element two more steps store the carried
+// rows.  Every wave executes 2 (2 n + 3) barriers.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -33,12 +32,93 @@ namespace mimi_hip {
 #define WGSYM_DIAG_MODE 2   // 2: contract only the a1 >= b1 chains of a diagonal block; 0: all nine
 #endif
 
+struct WgsymLds {
+  static constexpr int NB = 3, NQ = 4, NB2 = 9, ND = 27, NQ3 = 64, NROW = 81;
+  static constexpr int off_ue = 0;                          // [3][27] (+1 pad)              X private
+  static constexpr int off_tab = off_ue + 3 * ND + 1;       // [2 parity][3 dir][2][3][4]     X -> Y
+  static constexpr int off_r = off_tab + 2 * 6 * NB * NQ;   // residual scratch, three rows    X private
+  static constexpr int r_size = 3 * (3 * NQ3 + 3 * NB * NQ * NQ + 3 * NB2 * NQ);
+  static constexpr int off_ah = off_r + r_size;             // [6 blocks (i, j <= i)][9 (m,n)][64]  X -> Y
+  static constexpr int off_st = off_ah + 6 * 9 * NQ3;       // [3 i][1216] store transposition      Y
+  static constexpr int total = off_st + 3 * WgsLds::st_size;
+  // first Ahat entry of block (i, j), j <= i
+  MH_DEV static constexpr int ah_block(int i, int j) { return (i * (i + 1) / 2 + j) * 9; }
+};
+
+// rows 0, 1, 2 of one element in one go: Ahat blocks (i, j <= i) -> LDS, residual pieces -> scratch_r
+// (the three residual rows share their four LDS passes)
+template<int KIND>
+MH_DEV void wgsym_x_rows(const TensorArgs& p, double* lds, int lane, int64_t e, int par, const WgsPoint<KIND>& s) {
+  using L = WgsymLds;
+  constexpr int P = 2, NB = 3, NQ = 4, NB2 = 9, ND = 27, NQ3 = 64;
+  static_assert(KIND == MIMI_HIP_MAT_NEOHOOKEAN, "symmetric-half kernel: hyperelastic materials only");
+  const double* tab = lds + L::off_tab + par * 6 * NB * NQ;
+  double* AH = lds + L::off_ah;
+  double* PH = lds + L::off_r;                  // [3 I][3 m][64]
+  double* V = PH + 9 * NQ3;                     // [3 I][3 m][3 a2][16]
+  double* W = V + 9 * NB * NQ * NQ;             // [3 I][3 m][9 a1a2][4]
+#pragma unroll
+  for (int I = 0; I < 3; ++I)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const double c2gm = s.c2_w * s.G[m * 3 + I];
+#pragma unroll
+      for (int j = 0; j <= I; ++j) {
+        const double c1gm = s.c1_w * s.G[m * 3 + j];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          double v = c2gm * s.G[n * 3 + j] - c1gm * s.G[n * 3 + I];
+          if (I == j) {
+            const int lo = m < n ? m : n, hi = m < n ? n : m;
+            v += s.mu_w * s.M[lo * 3 - lo * (lo - 1) / 2 + (hi - lo)];
+          }
+          AH[(L::ah_block(I, j) + m * 3 + n) * NQ3 + lane] = v;
+        }
+      }
+    }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) PH[k * NQ3 + lane] = s.Phat[k];   // k = I * 3 + m
+  __builtin_amdgcn_wave_barrier();
+  // V[I m][a2][q0 q1] = sum_q2 T2^m[a2][q2] PH[I m][q0 q1 q2]
+  for (int t = lane; t < 9 * NB * NQ * NQ; t += 64) {
+    const int q01 = t % (NQ * NQ), a2 = (t / (NQ * NQ)) % NB, im = t / (NB * NQ * NQ), m = im % 3;
+    const double* T2 = tab_ptr<P>(tab, 2, m == 2 ? 1 : 0) + a2 * NQ;
+    double sv = 0.0;
+#pragma unroll
+    for (int q2 = 0; q2 < NQ; ++q2) sv += T2[q2] * PH[im * NQ3 + q01 + NQ * NQ * q2];
+    V[t] = sv;   // t = (im * NB + a2) * 16 + q01
+  }
+  __builtin_amdgcn_wave_barrier();
+  // W[I m][a1 a2][q0] = sum_q1 T1^m[a1][q1] V[I m][a2][q0 q1]
+  for (int t = lane; t < 9 * NB2 * NQ; t += 64) {
+    const int q0 = t % NQ, a12 = (t / NQ) % NB2, a1 = a12 % NB, a2 = a12 / NB, im = t / (NB2 * NQ), m = im % 3;
+    const double* T1 = tab_ptr<P>(tab, 1, m == 1 ? 1 : 0) + a1 * NQ;
+    double sw = 0.0;
+#pragma unroll
+    for (int q1 = 0; q1 < NQ; ++q1) sw += T1[q1] * V[(im * NB + a2) * NQ * NQ + q0 + NQ * q1];
+    W[t] = sw;   // t = (im * NB2 + a12) * 4 + q0
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int t = lane; t < 3 * ND; t += 64) {
+    const int a = t % ND, I = t / ND, a0 = a % NB, a12 = a / NB;
+    double sr = 0.0;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      const double* T0 = tab_ptr<P>(tab, 0, m == 0 ? 1 : 0) + a0 * NQ;
+#pragma unroll
+      for (int q0 = 0; q0 < NQ; ++q0) sr += T0[q0] * W[((I * 3 + m) * NB2 + a12) * NQ + q0];
+    }
+    p.scratch_r[(e * 3 + I) * ND + a] = sr;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------------------------------------
 // wave X, two steps per element
 // ------------------------------------------------------------------------------------------------
 template<int KIND>
 MH_DEV void wgsym_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& status) {
-  using L = WgsLds;
+  using L = WgsymLds;
   constexpr int P = 2, NB = 3, NQ = 4, ND = 27, NQ3 = 64;
   constexpr int TROUNDS = 2;
   const int lane = threadIdx.x & 63;
@@ -142,47 +222,45 @@ MH_DEV void wgsym_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& 
   request(0);
   point_stage(0);
   if (1 < n_seq) request(1);
-  for (int it = 0; it <= n_seq; ++it) {
-    const bool valid = it < n_seq;
-    // ---- step A(it): rows 0, 1 of element it ---------------------------------------------------------
+  // ---- prologue step: rows of element 0 ---------------------------------------------------------------------
+  wgs_barrier();
+  wgsym_x_rows<KIND>(p, lds, lane, element_at(0), 0, s);
+  wgs_barrier();
+  for (int it = 0; it < n_seq; ++it) {
+    // ---- step D(it): quadrature-point stage of element it + 1 -----------------------------------------------
     wgs_barrier();
-    if (valid) {
-      wgs_x_row<KIND, 0>(p, lds, lane, element_at(it), it & 1, s);
-      wgs_x_row<KIND, 1>(p, lds, lane, element_at(it), it & 1, s);
+    if (it + 1 < n_seq) {
+      point_stage(it + 1);
+      if (it + 2 < n_seq) request(it + 2);
     }
     wgs_barrier();
-    // ---- step B(it): row 2 of element it, then the point stage of element it + 1 -----------------------
+    // ---- step O(it): rows of element it + 1 ---------------------------------------------------------------------
     wgs_barrier();
-    if (valid) {
-      wgs_x_row<KIND, 2>(p, lds, lane, element_at(it), it & 1, s);
-      if (it + 1 < n_seq) {
-        point_stage(it + 1);
-        if (it + 2 < n_seq) request(it + 2);
-      }
-    }
+    if (it + 1 < n_seq) wgsym_x_rows<KIND>(p, lds, lane, element_at(it + 1), (it + 1) & 1, s);
     wgs_barrier();
   }
-  // ---- final step: the contraction waves flush the carried rows ------------------------------------------
+  // ---- two final steps: the contraction waves store the carried rows ------------------------------------------
+  wgs_barrier();
+  wgs_barrier();
   wgs_barrier();
   wgs_barrier();
 }
 
 // ------------------------------------------------------------------------------------------------
-// wave Y_W: blocks (I0, J0) in step B and (I1, J1) in step A; flushes piece W
+// wave Y_W: diagonal block (W, W) in step D, off-diagonal block (I1, J1) in step O; flushes piece W
 // ------------------------------------------------------------------------------------------------
 template<int W>
 MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
-  using L = WgsLds;
+  using L = WgsymLds;
   constexpr int P = 2, NB = 3, NQ = 4, NB2 = 9, ND = 27, NQ3 = 64, NROW = 81, NK = ND * NROW;
-  // step B blocks: Y0 (0,0), Y1 (1,1), Y2 (1,0);  step A blocks: Y0 (2,1), Y1 (2,0), Y2 (2,2)
-  constexpr int I0 = W == 0 ? 0 : 1, J0 = W == 0 ? 0 : W == 1 ? 1 : 0;
-  constexpr int I1 = 2, J1 = W == 0 ? 1 : W == 1 ? 0 : 2;
+  // step O blocks: Y0 (1,0), Y1 (2,0), Y2 (2,1)
+  constexpr int I1 = W == 0 ? 1 : 2, J1 = W == 2 ? 1 : 0;
   const WgsLane lc = wgs_lane_constants();
   const int lane = lc.lane;
   const int n_seq = p.box_n[2];
-  const double* AH0 = lds + L::off_ah + I0 * ND * NQ3;
-  const double* AH1 = lds + L::off_ah + I1 * ND * NQ3;
-  auto st_of = [&](int piece) -> double* { return lds + L::off_st + piece * L::st_size; };
+  const double* AH0 = lds + L::off_ah + L::ah_block(W, W) * NQ3;
+  const double* AH1 = lds + L::off_ah + L::ah_block(I1, J1) * NQ3;
+  auto st_of = [&](int piece) -> double* { return lds + L::off_st + piece * WgsLds::st_size; };
   auto piece_of = [&](int es) -> double* {
     return p.scratch_k + ((eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * es)) * 3 + W) * (int64_t)NK;
   };
@@ -195,83 +273,65 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
   for (int k = 0; k < NB2; ++k) C0[k] = C1[k] = 0.0;
   double aS0[4], aS2[4];
   double uB1[NB][NQ], uD1[NB][NQ];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) aS0[v] = aS2[v] = 0.0;
-#pragma unroll
-  for (int a = 0; a < NB; ++a)
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) uB1[a][q] = uD1[a][q] = 0.0;
-  {
-    // step A(0) runs on zeros (element -1: its results are never stored): the slots this wave reads then
-    double* AHw = lds + L::off_ah + I1 * ND * NQ3;
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
-#pragma unroll
-      for (int n = 0; n < 3; ++n) AHw[((m * 3 + J1) * 3 + n) * NQ3 + lane] = 0.0;
-  }
 
-  for (int it = 0; it <= n_seq; ++it) {
-    // ---- step A(it): block (I1, J1) of element it - 1 -----------------------------------------------------
-    {
-      double ah[9];
-#pragma unroll
-      for (int m = 0; m < 3; ++m)
-#pragma unroll
-        for (int n = 0; n < 3; ++n) ah[m * 3 + n] = AH1[((m * 3 + J1) * 3 + n) * NQ3 + lane];
-      wgs_barrier();
-      wgs_contract_block<(I1 != J1 ? 1 : WGSYM_DIAG_MODE)>(lc, ah, aS0, aS2, uB1, uD1, C1, st_of(I1), J1, st_of(J1), I1);
-      wgs_barrier();
-    }
-    // ---- step B(it): flush element it - 1, block (I0, J0) of element it --------------------------------------
+  // ---- prologue step: X writes the rows of element 0 ----------------------------------------------------------
+  wgs_barrier();
+  wgs_barrier();
+  for (int it = 0; it < n_seq; ++it) {
+    // ---- step D(it): flush element it - 1, tables of element it, diagonal block ------------------------------
     {
       if (it >= 1) wgs_flush_final(lane, st_of(W), piece_of(it - 1));
-      if (it < n_seq) {
-        const double* tab = lds + L::off_tab + (it & 1) * 6 * NB * NQ;
-        {
-          const double Ba = tab_ptr<P>(tab, 0, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 0, 1)[mra * NQ + mk];
-          const double Bb = tab_ptr<P>(tab, 0, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 0, 1)[mrb * NQ + mk];
-          aS0[0] = mrow_ok ? Ba * Bb : 0.0;
-          aS0[1] = mrow_ok ? Da * Bb : 0.0;
-          aS0[2] = mrow_ok ? Ba * Db : 0.0;
-          aS0[3] = mrow_ok ? Da * Db : 0.0;
-        }
-        {
-          const double Ba = tab_ptr<P>(tab, 2, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 2, 1)[mra * NQ + mk];
-          const double Bb = tab_ptr<P>(tab, 2, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 2, 1)[mrb * NQ + mk];
-          aS2[0] = mrow_ok ? Ba * Bb : 0.0;
-          aS2[1] = mrow_ok ? Da * Bb : 0.0;
-          aS2[2] = mrow_ok ? Ba * Db : 0.0;
-          aS2[3] = mrow_ok ? Da * Db : 0.0;
-        }
-#pragma unroll
-        for (int a = 0; a < NB; ++a)
-#pragma unroll
-          for (int q1 = 0; q1 < NQ; ++q1) {
-            const unsigned long long vb = __double_as_longlong(tab_ptr<P>(tab, 1, 0)[a * NQ + q1]);
-            const unsigned long long vd = __double_as_longlong(tab_ptr<P>(tab, 1, 1)[a * NQ + q1]);
-            const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)vb), bhi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
-            const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)vd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(vd >> 32));
-            uB1[a][q1] = __longlong_as_double(((unsigned long long)bhi << 32) | blo);
-            uD1[a][q1] = __longlong_as_double(((unsigned long long)dhi << 32) | dlo);
-          }
+      const double* tab = lds + L::off_tab + (it & 1) * 6 * NB * NQ;
+      {
+        const double Ba = tab_ptr<P>(tab, 0, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 0, 1)[mra * NQ + mk];
+        const double Bb = tab_ptr<P>(tab, 0, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 0, 1)[mrb * NQ + mk];
+        aS0[0] = mrow_ok ? Ba * Bb : 0.0;
+        aS0[1] = mrow_ok ? Da * Bb : 0.0;
+        aS0[2] = mrow_ok ? Ba * Db : 0.0;
+        aS0[3] = mrow_ok ? Da * Db : 0.0;
       }
+      {
+        const double Ba = tab_ptr<P>(tab, 2, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 2, 1)[mra * NQ + mk];
+        const double Bb = tab_ptr<P>(tab, 2, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 2, 1)[mrb * NQ + mk];
+        aS2[0] = mrow_ok ? Ba * Bb : 0.0;
+        aS2[1] = mrow_ok ? Da * Bb : 0.0;
+        aS2[2] = mrow_ok ? Ba * Db : 0.0;
+        aS2[3] = mrow_ok ? Da * Db : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int q1 = 0; q1 < NQ; ++q1) {
+          const unsigned long long vb = __double_as_longlong(tab_ptr<P>(tab, 1, 0)[a * NQ + q1]);
+          const unsigned long long vd = __double_as_longlong(tab_ptr<P>(tab, 1, 1)[a * NQ + q1]);
+          const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)vb), bhi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
+          const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)vd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(vd >> 32));
+          uB1[a][q1] = __longlong_as_double(((unsigned long long)bhi << 32) | blo);
+          uD1[a][q1] = __longlong_as_double(((unsigned long long)dhi << 32) | dlo);
+        }
       double ah[9];
 #pragma unroll
-      for (int m = 0; m < 3; ++m)
-#pragma unroll
-        for (int n = 0; n < 3; ++n) ah[m * 3 + n] = AH0[((m * 3 + J0) * 3 + n) * NQ3 + lane];
+      for (int k = 0; k < 9; ++k) ah[k] = AH0[k * NQ3 + lane];
       wgs_barrier();
-      if (it < n_seq) {
-        wgs_contract_block<(I0 != J0 ? 1 : WGSYM_DIAG_MODE)>(lc, ah, aS0, aS2, uB1, uD1, C0, st_of(I0), J0, st_of(J0), I0);
-      } else {
-        // past the last element: the carried rows have no successor and are stored as well
-        wgs_stage_carry<(I0 != J0 ? 1 : WGSYM_DIAG_MODE)>(lc, C0, st_of(I0), J0, st_of(J0), I0);
-        wgs_stage_carry<(I1 != J1 ? 1 : WGSYM_DIAG_MODE)>(lc, C1, st_of(I1), J1, st_of(J1), I1);
-      }
+      wgs_contract_block<WGSYM_DIAG_MODE>(lc, ah, aS0, aS2, uB1, uD1, C0, st_of(W), W, st_of(W), W);
+      wgs_barrier();
+    }
+    // ---- step O(it): off-diagonal block, stored as computed and transposed ------------------------------------
+    {
+      double ah[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) ah[k] = AH1[k * NQ3 + lane];
+      wgs_barrier();
+      wgs_contract_block<1>(lc, ah, aS0, aS2, uB1, uD1, C1, st_of(I1), J1, st_of(J1), I1);
       wgs_barrier();
     }
   }
-  // ---- final step: flush the carried rows of the last element ------------------------------------------------
+  // ---- after the last element: its pieces, then the carried rows (they have no successor) ------------------------
+  wgs_flush_final(lane, st_of(W), piece_of(n_seq - 1));
+  wgs_barrier();
+  wgs_stage_carry<WGSYM_DIAG_MODE>(lc, C0, st_of(W), W, st_of(W), W);
+  wgs_stage_carry<1>(lc, C1, st_of(I1), J1, st_of(J1), I1);
+  wgs_barrier();
   wgs_flush_carry(lane, st_of(W), piece_of(n_seq - 1));
   wgs_barrier();
   wgs_barrier();
@@ -311,7 +371,7 @@ inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a) {
   a.scratch_r = h->scratch_r.ptr;
   a.n_units_u = a.box_n[0];
   a.n_units_v = a.box_n[1];
-  const size_t lds = WgsLds::total * sizeof(double);
+  const size_t lds = WgsymLds::total * sizeof(double);
   auto kernel = tensor_wgsym_kernel<MIMI_HIP_MAT_NEOHOOKEAN>;
   MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
