@@ -7,10 +7,15 @@
 // integration kernel only STORES: its row pieces go, coalesced, to a dense scratch, and a second
 // kernel that owns CSR rows gathers them and does ONE coalesced read-modify-write per row.
 //
-//   phase 1  stores, for every (element, i), the 27 x 81 row piece scratch_k[element][i][a][b2][b1][b0][j]
-//            and the residual piece scratch_r[element][i][a].  Entries shared with the next element of
-//            the walked (third) axis are carried inside the kernel, so each (node pair, element column)
-//            is stored exactly once, by the highest element of the column that contains both nodes.
+//   phase 1  stores, for every (element, i), a piece of 2187 slots in scratch_k and the residual piece
+//            scratch_r[element][i][a].  Entries shared with the next element of the walked (third) axis are
+//            carried inside the kernel, so each (node pair, element column) is stored exactly once, by the
+//            highest element of the column that contains both nodes.  Piece layout (a = a0 + 3 a1 + 9 a2 local
+//            row node, (b2,b1,b0) local column node, j column component), what phase 2 reads contiguously:
+//              [0, 729)      rows a < 9 (a2 = 0):            a 81 + b2 27 + b1 9 + b0 3 + j
+//              [729, 1215)   rows a >= 9, b2 = 0:            729 + (a - 9) 27 + b1 9 + b0 3 + j
+//              [1215, 2187)  rows a >= 9, b2 = 1, 2 (written by the last element of a column only):
+//                                                            1215 + (a - 9) 54 + (b2 - 1) 27 + b1 9 + b0 3 + j
 //   phase 2  tensor_p2_kernel below.
 // Results are bitwise reproducible; nothing is atomic.
 #pragma once
@@ -87,11 +92,15 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
         const int ey = ey_lo + c / 3, ex = ex_lo + c % 3;
         const bool in = c < 9 && ey <= ey_hi && ex <= ex_hi;
         const int a = (A0 - ex) + NB * ((A1 - ey) + NB * a2);
-        const double* src = p.scratch_k + (elem(in ? ex : ex_lo, in ? ey : ey_lo, ez) * 3) * (int64_t)NK + (in ? a : 0) * NROW;
+        const double* piece = p.scratch_k + (elem(in ? ex : ex_lo, in ? ey : ey_lo, ez) * 3) * (int64_t)NK;
+        // row a of the piece: 81 contiguous values (a2 = 0), or 27 (b2 = 0) [+ 54 (b2 = 1, 2) from the last element]
+        const int a9 = in ? a - 9 : 0;
+        const int o0 = !in ? 0 : (a2 == 0 ? a * NROW + lane : (lane < ND ? 9 * NROW + a9 * ND + lane : 15 * NROW + a9 * 54 + lane - ND));
+        const int o1 = !in ? 0 : (a2 == 0 ? a * NROW + k1 : 15 * NROW + a9 * 54 + k1 - ND);
 #pragma unroll
         for (int I = 0; I < 3; ++I) {
-          v0[cc][I] = (in && act0) ? src[I * NK + lane] : 0.0;
-          v1[cc][I] = (in && act1) ? src[I * NK + k1] : 0.0;
+          v0[cc][I] = (in && act0) ? piece[I * NK + o0] : 0.0;
+          v1[cc][I] = (in && act1) ? piece[I * NK + o1] : 0.0;
         }
       }
 #pragma unroll

@@ -675,36 +675,25 @@ MH_DEV void wgs_stage_carry(const WgsLane& lc, const double (&C)[9], double* st_
 
 // buffer -> dense scratch piece S (affine addressing, see kernels_tensor_wgs.hpp)
 MH_DEV void wgs_flush_final(int lane, const double* ST, double* S) {
-  constexpr int ND = 27, NROW = 81;
-  {
-    constexpr int NA = (9 * NROW + 63) / 64;  // 12
-    double v[NA];
+  // the piece layout in scratch_k IS the compact layout of the buffer (kernels_tensor_2phase.hpp): 1215 contiguous values
+  constexpr int N = WgsLds::n_final, NR = (N + 63) / 64;  // 19
+  double v[NR];
 #pragma unroll
-    for (int c = 0; c < NA; ++c) v[c] = ST[c * 64 + (c * 64 + 63 < 9 * NROW ? lane : (lane < 9 * NROW - c * 64 ? lane : 0))];
+  for (int c = 0; c < NR; ++c) v[c] = ST[c * 64 + ((c + 1) * 64 <= N || lane < N - c * 64 ? lane : 0)];
 #pragma unroll
-    for (int c = 0; c < NA; ++c)
-      if (c * 64 + 63 < 9 * NROW || lane < 9 * NROW - c * 64) S[(unsigned)(c * 64 + lane)] = v[c];
-  }
-  {
-    const unsigned l54 = lane < 54 ? lane : 0;
-    const unsigned gofs = 9 * NROW + (l54 >= ND ? NROW + l54 - ND : l54);
-    double v[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) v[c] = ST[9 * NROW + 54 * c + l54];
-#pragma unroll
-    for (int c = 0; c < 9; ++c)
-      if (lane < 54) S[gofs + (unsigned)(c * 2 * NROW)] = v[c];
-  }
+  for (int c = 0; c < NR; ++c)
+    if ((c + 1) * 64 <= N || lane < N - c * 64) S[(unsigned)(c * 64 + lane)] = v[c];
 }
 
 MH_DEV void wgs_flush_carry(int lane, const double* ST, double* S) {
-  constexpr int ND = 27, NROW = 81;
-  const unsigned l54 = lane < 54 ? lane : 0;
+  // carried rows of the last element of a column: the 972 values behind the 1215 final ones
+  constexpr int N = WgsLds::n_carry, NR = (N + 63) / 64;  // 16
+  double v[NR];
 #pragma unroll
-  for (int r = 0; r < 18; ++r) {
-    const double v = ST[54 * r + l54];
-    if (lane < 54) S[(unsigned)((9 + r) * NROW + ND) + l54] = v;
-  }
+  for (int c = 0; c < NR; ++c) v[c] = ST[c * 64 + ((c + 1) * 64 <= N || lane < N - c * 64 ? lane : 0)];
+#pragma unroll
+  for (int c = 0; c < NR; ++c)
+    if ((c + 1) * 64 <= N || lane < N - c * 64) S[(unsigned)(WgsLds::n_final + c * 64 + lane)] = v[c];
 }
 
 // ------------------------------------------------------------------------------------------------
