@@ -122,3 +122,34 @@ def test_slab_additivity(setup):
     As = float(setup["A"].abs().max())
     assert float((r2 - setup["r"]).abs().max()) < 1e-12 * rs
     assert float((A2 - setup["A"]).abs().max()) < 1e-12 * As
+
+
+def test_j2_fullsize_properties():
+    """The J2 route at full size (material pre-pass + nine-block phase 1 + phase 2): force balance, rigid
+    translations in the null space of the (unsymmetric) tangent, run-to-run bitwise reproducibility."""
+    import torch
+    import bench
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    dev = torch.device("cuda", 0)
+    patch = mimi_amd.BSplinePatch.block(N_EL, P)
+    pattern = CSRPattern.of_bspline_patch(patch, on_device=True)
+    G = NonlinearSolid("domain", bench.make_material("j2"), pattern, patch=patch).Prepare()
+    G.dt_ = 0.5
+    u = torch.from_numpy(bench.synthetic_u(patch)).to(dev)
+    r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
+    A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
+    G.AddDomainResidualAndGrad(u, 1.0, r, A)
+    G.Synchronize()
+    rv = r.view(-1, 3)
+    assert float(rv.sum(0).abs().max()) < 1e-11 * float(rv.abs().sum(0).max())
+    s = dict(torch=torch, dev=dev, pattern=pattern)
+    Aabs = float(A.abs().max())
+    for j in range(3):
+        t = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
+        t[j::3] = 1.0
+        assert float(csr_matvec(s, A, t).abs().max()) < 1e-10 * Aabs * 375
+    r2, A2 = torch.zeros_like(r), torch.zeros_like(A)
+    G.AddDomainResidualAndGrad(u, 1.0, r2, A2)
+    G.Synchronize()
+    assert torch.equal(r2, r) and torch.equal(A2, A)
