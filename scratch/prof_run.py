@@ -1,3 +1,6 @@
+"""In-kernel stage stamps of the colour-partitioned tensor kernel: build the library with -DMH_PROFILE
+(scratch/mklib.sh PROF -DMH_PROFILE), put it in place of mimi_amd/lib/libmimi_hip.so and run with
+MIMI_HIP_TENSOR_VARIANT=valu."""
 import sys, os, ctypes as C, numpy as np
 sys.path.insert(0, '/root/repo')
 import torch, mimi_amd
@@ -19,8 +22,8 @@ L.mimi_hip_debug_profile(G._h, out, 1)
 G.AddDomainResidualAndGrad(u, 1.0, r, A); G.Synchronize()
 L.mimi_hip_debug_profile(G._h, out, 1)
 v = np.array(list(out), dtype=np.float64)
-names = ['X wait A', 'X point stage', 'X row (tangent+R)', 'X wait B', '-', '-', 'Y read window', 'Y wait A', 'Y S1+S2', 'Y S3+carry+staging', 'Y flush', 'Y wait B'] if os.environ.get('WGS_NAMES') else ['loop top', 'stage0', 'stageA', 'stageR', 'prefetch issue', 'aS + uniform tables', 'S1+S2 (x3)', 'S3 mfma (x3)', 'KS accumulate (x3)', '-', 'j-loop exit', 'flush'] if os.environ.get('MFMA_NAMES') else ['loop-top/prev-scatter-tail', 'stage0 LDS fill+prefetch', 'stageA material', 'stageR residual', 'issue old loads', 'S12', 'S3', 'carry', 'Kv select', 'scatter stores', '', '']
-n_items = patch.n_elements * 3 if not os.environ.get('WGS_NAMES') else patch.n_elements
+names = ['loop-top/prev-scatter-tail', 'stage0 LDS fill+prefetch', 'stageA material', 'stageR residual', 'issue old loads', 'S12', 'S3', 'carry', 'Kv select', 'scatter stores', '', '']
+n_items = patch.n_elements * 3
 print('shader cycles per (element,i):')
 for k in range(12):
     print('  %-28s %10.1f  (%.1f%%)' % (names[k], v[k] / n_items, 100 * v[k] / v.sum()))
