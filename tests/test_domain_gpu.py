@@ -289,3 +289,19 @@ def test_rational_weights_general_path(n_el, p):
     G.AddDomainResidualAndGrad(u, 1.0, r_g, A_g)
     assert relmax(r_g, r_o) < 1e-12
     assert relmax(A_g, A_o) < 1e-11
+
+
+@pytest.mark.parametrize("env", [{"MIMI_HIP_TENSOR_VARIANT": "valu"}, {"MIMI_HIP_TENSOR_VARIANT": "wgs"},
+                                 {"MIMI_HIP_NO_STRUCTURED": "1"}], ids=["colour-rmw", "nine-block", "pair-pos-tables"])
+def test_fallback_kernel_families(env):
+    """The kernels behind the default route (selected by environment variables the library reads once per process):
+    colour-partitioned read-modify-write, the nine-block workgroup kernel for a hyperelastic material, and the
+    colour kernel with the pair-position tables (CSR not recognised as the structured pattern)."""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ, **env)
+    cmd = [sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+           "-k", "(5x5x5p2 and bspline) or (boxes and neohook) or tiny"]
+    res = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
