@@ -165,15 +165,19 @@ __global__ __launch_bounds__(256) void domain_general_kernel(GeneralArgs p) {
           gb[J] = g[J * n_dof + b];
         }
         const double* Aq = Aw + q * D4;
+        // K(ai,bj) += sum_J ga[J] (sum_L A[iJ,jL] gb[L]): contract L first (DIM^3 + ... multiply-adds instead of 2 DIM^4)
 #pragma unroll
         for (int i = 0; i < DIM; ++i)
 #pragma unroll
           for (int j = 0; j < DIM; ++j) {
             double s = 0.0;
 #pragma unroll
-            for (int J = 0; J < DIM; ++J)
+            for (int J = 0; J < DIM; ++J) {
+              double t = 0.0;
 #pragma unroll
-              for (int L = 0; L < DIM; ++L) s += ga[J] * Aq[((i * DIM + J) * DIM + j) * DIM + L] * gb[L];
+              for (int L = 0; L < DIM; ++L) t += Aq[((i * DIM + J) * DIM + j) * DIM + L] * gb[L];
+              s += ga[J] * t;
+            }
             acc[i * DIM + j] += s;
           }
       }
