@@ -88,9 +88,12 @@ MH_DEV void compute_F_general(int n_dof, const double* __restrict__ g /* [DIM][n
   for (int i = 0; i < DIM; ++i) MH_M(F, i, i) += 1.0;
 }
 
+#ifndef GEN_WAVES
+#define GEN_WAVES 2
+#endif
 // GRAD: 0 residual only, 1 analytic tangent, 2 reference forward difference
 template<int DIM, int GRAD>
-__global__ __launch_bounds__(256) void domain_general_kernel(GeneralArgs p) {
+__global__ __launch_bounds__(256, GEN_WAVES) void domain_general_kernel(GeneralArgs p) {
   constexpr int DD = DIM * DIM;
   constexpr int D4 = DD * DD;
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void domain_general_kernel(GeneralArgs p) {
   double* u_e = reinterpret_cast<double*>(smem_raw);  // [DIM][n_dof]
   double* Pw = u_e + n_tdof;                          // [n_q][DD]   w*det*P
   double* Aw = Pw + n_q * DD;                         // [n_q][D4]   w*det*dP/dF   (GRAD==1)
-  double* R_e = Aw + (GRAD == 1 ? n_q * D4 : 0);      // [n_tdof]                  (GRAD==2)
+  double* R_e = Aw + (GRAD == 1 ? n_q * D4 + n_dof * DD * DIM + 8 * n_tdof : 0);  // [n_tdof] (GRAD==2); GRAD==1: T[n_dof][DIM^3], gC[8][n_tdof] sit before it
   int32_t* node = reinterpret_cast<int32_t*>(R_e + (GRAD == 2 ? n_tdof : 0));  // [n_dof]
 
   const double* gE = p.dN_dX + (int64_t)e * n_q * n_tdof;
@@ -126,10 +129,26 @@ __global__ __launch_bounds__(256) void domain_general_kernel(GeneralArgs p) {
 #pragma unroll
     for (int k = 0; k < DD; ++k) Pw[q * DD + k] = wd * w.P[k];
     if constexpr (GRAD == 1) {
-      double A[D4];
-      tangent_of<DIM>(p.mat.m, w, A);
+      // one row dP_i./dF at a time (DIM^3 values live instead of DIM^4)
+      constexpr int D3r = DD * DIM;
+      {
+        double Ar[D3r];
+        tangent_row_of<DIM, 0>(p.mat.m, w, Ar);
 #pragma unroll
-      for (int k = 0; k < D4; ++k) Aw[q * D4 + k] = wd * A[k];
+        for (int k = 0; k < D3r; ++k) Aw[q * D4 + k] = wd * Ar[k];
+      }
+      {
+        double Ar[D3r];
+        tangent_row_of<DIM, 1>(p.mat.m, w, Ar);
+#pragma unroll
+        for (int k = 0; k < D3r; ++k) Aw[q * D4 + D3r + k] = wd * Ar[k];
+      }
+      if constexpr (DIM == 3) {
+        double Ar[D3r];
+        tangent_row_of<DIM, 2>(p.mat.m, w, Ar);
+#pragma unroll
+        for (int k = 0; k < D3r; ++k) Aw[q * D4 + 2 * D3r + k] = wd * Ar[k];
+      }
     }
   }
   __syncthreads();
@@ -148,46 +167,71 @@ __global__ __launch_bounds__(256) void domain_general_kernel(GeneralArgs p) {
   }
 
   if constexpr (GRAD == 1) {
-    // phase 3: node-pair blocks
+    // phase 3: node-pair blocks K(ai,bj) = sum_q sum_J ga[J] T_b[iJ][j],  T_b[iJ][j] = sum_L A_q[iJ,jL] gb[L].
+    // Per quadrature point T is built once for all nodes b (n_dof DIM^3 values in LDS), then every lane adds its
+    // node pairs (PP per lane and pass): DIM^3 multiply-adds per (pair, point) instead of DIM^4 + DIM^3.
+    constexpr int D3 = DD * DIM;
+    constexpr int PP = 3;
     const int n_pairs = n_dof * n_dof;
-    const int32_t* pp = p.pair_pos + (int64_t)e * n_pairs;
-    for (int pr = tid; pr < n_pairs; pr += blockDim.x) {
-      const int b = pr % n_dof, a = pr / n_dof;
-      double acc[DD];  // acc[i*DIM + j]
+    const int32_t* pp_tab = p.pair_pos + (int64_t)e * n_pairs;
+    constexpr int QC = 8;
+    double* T = Aw + n_q * D4;   // [n_dof][D3]
+    double* gC = T + n_dof * D3;  // [QC][DIM][n_dof]
+    for (int pg0 = 0; pg0 < n_pairs; pg0 += PP * (int)blockDim.x) {
+      double acc[PP][DD];  // acc[.][i*DIM + j]
 #pragma unroll
-      for (int k = 0; k < DD; ++k) acc[k] = 0.0;
-      for (int q = 0; q < n_q; ++q) {
-        const double* g = gE + (int64_t)q * n_tdof;
-        double ga[DIM], gb[DIM];
+      for (int k = 0; k < PP; ++k)
 #pragma unroll
-        for (int J = 0; J < DIM; ++J) {
-          ga[J] = g[J * n_dof + a];
-          gb[J] = g[J * n_dof + b];
-        }
-        const double* Aq = Aw + q * D4;
-        // K(ai,bj) += sum_J ga[J] (sum_L A[iJ,jL] gb[L]): contract L first (DIM^3 + ... multiply-adds instead of 2 DIM^4)
+        for (int c = 0; c < DD; ++c) acc[k][c] = 0.0;
+      for (int q0 = 0; q0 < n_q; q0 += QC) {
+        // the gradients of QC quadrature points -> LDS (one global read per value instead of one per use)
+        const int nqc = n_q - q0 < QC ? n_q - q0 : QC;
+        for (int t = tid; t < nqc * n_tdof; t += blockDim.x) gC[t] = gE[(int64_t)q0 * n_tdof + t];
+        __syncthreads();
+        for (int qq = 0; qq < nqc; ++qq) {
+          const double* g = gC + qq * n_tdof;
+          const double* Aq = Aw + (q0 + qq) * D4;
+          for (int t = tid; t < n_dof * D3; t += blockDim.x) {
+            const int b = t / D3, c = t % D3;   // c = (i*DIM + J)*DIM + j
+            double tv = 0.0;
 #pragma unroll
-        for (int i = 0; i < DIM; ++i)
-#pragma unroll
-          for (int j = 0; j < DIM; ++j) {
-            double s = 0.0;
-#pragma unroll
-            for (int J = 0; J < DIM; ++J) {
-              double t = 0.0;
-#pragma unroll
-              for (int L = 0; L < DIM; ++L) t += Aq[((i * DIM + J) * DIM + j) * DIM + L] * gb[L];
-              s += ga[J] * t;
-            }
-            acc[i * DIM + j] += s;
+            for (int L = 0; L < DIM; ++L) tv += Aq[c * DIM + L] * g[L * n_dof + b];
+            T[t] = tv;
           }
+          __syncthreads();
+#pragma unroll
+          for (int k = 0; k < PP; ++k) {
+            const int pr = pg0 + tid + k * (int)blockDim.x;
+            if (pr < n_pairs) {
+              const int b = pr % n_dof, a = pr / n_dof;
+              const double* Tb = T + b * D3;
+#pragma unroll
+              for (int J = 0; J < DIM; ++J) {
+                const double gaJ = g[J * n_dof + a];
+#pragma unroll
+                for (int i = 0; i < DIM; ++i)
+#pragma unroll
+                  for (int j = 0; j < DIM; ++j) acc[k][i * DIM + j] += gaJ * Tb[(i * DIM + J) * DIM + j];
+              }
+            }
+          }
+          __syncthreads();
+        }
       }
-      const int64_t rowA = (int64_t)node[a] * DIM;
-      const int32_t off = pp[pr];
 #pragma unroll
-      for (int i = 0; i < DIM; ++i) {
-        double* dst = p.A + p.rowptr[rowA + i] + off;
+      for (int k = 0; k < PP; ++k) {
+        const int pr = pg0 + tid + k * (int)blockDim.x;
+        if (pr < n_pairs) {
+          const int a = pr / n_dof;
+          const int64_t rowA = (int64_t)node[a] * DIM;
+          const int32_t off = pp_tab[pr];
 #pragma unroll
-        for (int j = 0; j < DIM; ++j) atomic_add_f64(dst + j, p.grad_factor * acc[i * DIM + j]);
+          for (int i = 0; i < DIM; ++i) {
+            double* dst = p.A + p.rowptr[rowA + i] + off;
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) atomic_add_f64(dst + j, p.grad_factor * acc[k][i * DIM + j]);
+          }
+        }
       }
     }
   }
@@ -260,7 +304,7 @@ __global__ __launch_bounds__(256) void post_time_advance_general_kernel(GeneralA
 inline size_t general_lds_bytes(int dim, int n_dof, int n_q, int grad) {
   const int dd = dim * dim, n_tdof = n_dof * dim;
   size_t doubles = n_tdof + (size_t)n_q * dd;
-  if (grad == 1) doubles += (size_t)n_q * dd * dd;
+  if (grad == 1) doubles += (size_t)n_q * dd * dd + (size_t)n_dof * dd * dim + (size_t)8 * n_tdof;
   if (grad == 2) doubles += n_tdof;
   return doubles * sizeof(double) + (size_t)n_dof * sizeof(int32_t);
 }
