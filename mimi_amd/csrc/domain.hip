@@ -209,7 +209,8 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a)
     MH_HIP(hipGetLastError());
   };
   if (grad == 0) go(domain_general_kernel<DIM, 0>);
-  else if (grad == 1) go(domain_general_kernel<DIM, 1>);
+  else if (grad == 1 && h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, 8>);
+  else if (grad == 1) go(domain_general_kernel<DIM, 1, 3>);
   else go(domain_general_kernel<DIM, 2>);
 }
 

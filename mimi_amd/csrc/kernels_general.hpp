@@ -92,7 +92,9 @@ MH_DEV void compute_F_general(int n_dof, const double* __restrict__ g /* [DIM][n
 #define GEN_WAVES 2
 #endif
 // GRAD: 0 residual only, 1 analytic tangent, 2 reference forward difference
-template<int DIM, int GRAD>
+// PP: node pairs per lane and pass of the node-pair phase (3 covers up to 768 pairs = p <= 2 in 3-D; 8 halves the
+// passes of larger elements)
+template<int DIM, int GRAD, int PP = 3>
 __global__ __launch_bounds__(256, GEN_WAVES) void domain_general_kernel(GeneralArgs p) {
   constexpr int DD = DIM * DIM;
   constexpr int D4 = DD * DD;
@@ -171,7 +173,6 @@ __global__ __launch_bounds__(256, GEN_WAVES) void domain_general_kernel(GeneralA
     // Per quadrature point T is built once for all nodes b (n_dof DIM^3 values in LDS), then every lane adds its
     // node pairs (PP per lane and pass): DIM^3 multiply-adds per (pair, point) instead of DIM^4 + DIM^3.
     constexpr int D3 = DD * DIM;
-    constexpr int PP = 3;
     const int n_pairs = n_dof * n_dof;
     const int32_t* pp_tab = p.pair_pos + (int64_t)e * n_pairs;
     constexpr int QC = 8;
