@@ -198,18 +198,22 @@ static GeneralArgs general_args(mimi_hip_domain_s* h, const double* u, double* r
   return a;
 }
 
+#ifndef GEN_BIG_PP
+#define GEN_BIG_PP 8
+#define GEN_BIG_THREADS 512
+#endif
 template<int DIM>
 static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a) {
   const size_t lds = general_lds_bytes(DIM, h->n_dof, h->n_q, grad);
   if (lds > 160 * 1024) fail("element too large for LDS (%zu bytes)", lds);
-  auto go = [&](auto kernel) {
+  auto go = [&](auto kernel, int threads = 256) {
     if (lds > 64 * 1024)
       MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3(h->n_el), dim3(256), lds, h->stream, a);
+    hipLaunchKernelGGL(kernel, dim3(h->n_el), dim3(threads), lds, h->stream, a);
     MH_HIP(hipGetLastError());
   };
   if (grad == 0) go(domain_general_kernel<DIM, 0>);
-  else if (grad == 1 && h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, 8>);
+  else if (grad == 1 && h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, GEN_BIG_PP, GEN_BIG_THREADS>, GEN_BIG_THREADS);
   else if (grad == 1) go(domain_general_kernel<DIM, 1, 3>);
   else go(domain_general_kernel<DIM, 2>);
 }

@@ -94,8 +94,9 @@ MH_DEV void compute_F_general(int n_dof, const double* __restrict__ g /* [DIM][n
 // GRAD: 0 residual only, 1 analytic tangent, 2 reference forward difference
 // PP: node pairs per lane and pass of the node-pair phase (3 covers up to 768 pairs = p <= 2 in 3-D; 8 halves the
 // passes of larger elements)
-template<int DIM, int GRAD, int PP = 3>
-__global__ __launch_bounds__(256, GEN_WAVES) void domain_general_kernel(GeneralArgs p) {
+// THREADS: workgroup size (256; 512 for elements with more than 768 node pairs: one pass of the node-pair phase for p = 3)
+template<int DIM, int GRAD, int PP = 3, int THREADS = 256>
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domain_general_kernel(GeneralArgs p) {
   constexpr int DD = DIM * DIM;
   constexpr int D4 = DD * DD;
   extern __shared__ __align__(16) unsigned char smem_raw[];
