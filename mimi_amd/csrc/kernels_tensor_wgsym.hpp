@@ -18,8 +18,8 @@
 // of D(e) and O(e) and rewritten during O(e): one LDS buffer, only the 54 entries (i, j <= i) kept.
 // The three store-transposition buffers (one per piece i) are written by all three contraction waves
 // during D(e) and O(e) and flushed, piece w by wave Y_w, in the read window of D(e+1).  A prologue
-// step lets X write the rows of element 0; after the last element two more steps store the carried
-// rows.  Every wave executes 2 (2 n + 3) barriers.
+// step lets X write the rows of element 0; after the last element each contraction wave stores the carried
+// rows (outside the lock steps).  Every wave executes 2 (2 n + 1) barriers.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -239,11 +239,6 @@ MH_DEV void wgsym_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& 
     if (it + 1 < n_seq) wgsym_x_rows<KIND>(p, lds, lane, element_at(it + 1), (it + 1) & 1, s);
     wgs_barrier();
   }
-  // ---- two final steps: the contraction waves store the carried rows ------------------------------------------
-  wgs_barrier();
-  wgs_barrier();
-  wgs_barrier();
-  wgs_barrier();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -326,15 +321,14 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
       wgs_barrier();
     }
   }
-  // ---- after the last element: its pieces, then the carried rows (they have no successor) ------------------------
+  // ---- after the last element (no more lock steps): its pieces from the buffers, and the carried rows, which
+  // have no successor, straight from the registers into the third part of the pieces ------------------------------
   wgs_flush_final(lane, st_of(W), piece_of(n_seq - 1));
-  wgs_barrier();
-  wgs_stage_carry<WGSYM_DIAG_MODE>(lc, C0, st_of(W), W, st_of(W), W);
-  wgs_stage_carry<1>(lc, C1, st_of(I1), J1, st_of(J1), I1);
-  wgs_barrier();
-  wgs_flush_carry(lane, st_of(W), piece_of(n_seq - 1));
-  wgs_barrier();
-  wgs_barrier();
+  auto piece_i = [&](int i) -> double* {
+    return p.scratch_k + ((eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * (n_seq - 1))) * 3 + i) * (int64_t)NK + WgsLds::n_final;
+  };
+  wgs_stage_carry<WGSYM_DIAG_MODE>(lc, C0, piece_i(W), W, piece_i(W), W);
+  wgs_stage_carry<1>(lc, C1, piece_i(I1), J1, piece_i(J1), I1);
 }
 
 template<int KIND>
@@ -347,14 +341,14 @@ __global__ __launch_bounds__(256, 2) void tensor_wgsym_kernel(TensorArgs p) {
   if (role == 0) {
     int status = 0;
 #ifdef WGSYM_EXP_SKIP_X
-    for (int k = 0; k < 2 * (2 * p.box_n[2] + 3); ++k) wgs_barrier();
+    for (int k = 0; k < 2 * (2 * p.box_n[2] + 1); ++k) wgs_barrier();
 #else
     wgsym_x_loop<KIND>(p, smem_wgsym, eu, ev, status);
 #endif
     if (status) atomicOr(p.status, status);
   } else {
 #ifdef WGSYM_EXP_SKIP_Y
-    for (int k = 0; k < 2 * (2 * p.box_n[2] + 3); ++k) wgs_barrier();
+    for (int k = 0; k < 2 * (2 * p.box_n[2] + 1); ++k) wgs_barrier();
 #else
     if (role == 1) wgsym_y_loop<0>(p, smem_wgsym, eu, ev);
     else if (role == 2) wgsym_y_loop<1>(p, smem_wgsym, eu, ev);
