@@ -172,14 +172,21 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
   if constexpr (GRAD == 1) {
     // phase 3: node-pair blocks K(ai,bj) = sum_q sum_J ga[J] T_b[iJ][j],  T_b[iJ][j] = sum_L A_q[iJ,jL] gb[L].
     // Per quadrature point T is built once for all nodes b (n_dof DIM^3 values in LDS), then every lane adds its
-    // node pairs (PP per lane and pass): DIM^3 multiply-adds per (pair, point) instead of DIM^4 + DIM^3.
+    // node pairs: DIM^3 multiply-adds per (pair, point) instead of DIM^4 + DIM^3.
     constexpr int D3 = DD * DIM;
     const int n_pairs = n_dof * n_dof;
     const int32_t* pp_tab = p.pair_pos + (int64_t)e * n_pairs;
     constexpr int QC = 8;
     double* T = Aw + n_q * D4;   // [n_dof][D3]
     double* gC = T + n_dof * D3;  // [QC][DIM][n_dof]
-    for (int pg0 = 0; pg0 < n_pairs; pg0 += PP * (int)blockDim.x) {
+    // a lane owns one column node b and PP row nodes a = ag PP .. ag PP + PP - 1: T_b is read once per point for
+    // all of them (the LDS traffic of this phase is what bounds large elements)
+    const int n_groups = (n_dof + PP - 1) / PP;
+    const int n_slots = n_dof * n_groups;
+    for (int slot0 = 0; slot0 < n_slots; slot0 += (int)blockDim.x) {
+      const int slot = slot0 + tid;
+      const bool active = slot < n_slots;
+      const int b = active ? slot % n_dof : 0, ag = active ? slot / n_dof : 0;
       double acc[PP][DD];  // acc[.][i*DIM + j]
 #pragma unroll
       for (int k = 0; k < PP; ++k)
@@ -194,44 +201,48 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
           const double* g = gC + qq * n_tdof;
           const double* Aq = Aw + (q0 + qq) * D4;
           for (int t = tid; t < n_dof * D3; t += blockDim.x) {
-            const int b = t / D3, c = t % D3;   // c = (i*DIM + J)*DIM + j
+            const int bb = t / D3, c = t % D3;   // c = (i*DIM + J)*DIM + j
             double tv = 0.0;
 #pragma unroll
-            for (int L = 0; L < DIM; ++L) tv += Aq[c * DIM + L] * g[L * n_dof + b];
+            for (int L = 0; L < DIM; ++L) tv += Aq[c * DIM + L] * g[L * n_dof + bb];
             T[t] = tv;
           }
           __syncthreads();
+          if (active) {
+            double Tb[D3];
 #pragma unroll
-          for (int k = 0; k < PP; ++k) {
-            const int pr = pg0 + tid + k * (int)blockDim.x;
-            if (pr < n_pairs) {
-              const int b = pr % n_dof, a = pr / n_dof;
-              const double* Tb = T + b * D3;
+            for (int c = 0; c < D3; ++c) Tb[c] = T[b * D3 + c];
 #pragma unroll
-              for (int J = 0; J < DIM; ++J) {
-                const double gaJ = g[J * n_dof + a];
+            for (int k = 0; k < PP; ++k) {
+              const int a = ag * PP + k;
+              if (a < n_dof) {
 #pragma unroll
-                for (int i = 0; i < DIM; ++i)
+                for (int J = 0; J < DIM; ++J) {
+                  const double gaJ = g[J * n_dof + a];
 #pragma unroll
-                  for (int j = 0; j < DIM; ++j) acc[k][i * DIM + j] += gaJ * Tb[(i * DIM + J) * DIM + j];
+                  for (int i = 0; i < DIM; ++i)
+#pragma unroll
+                    for (int j = 0; j < DIM; ++j) acc[k][i * DIM + j] += gaJ * Tb[(i * DIM + J) * DIM + j];
+                }
               }
             }
           }
           __syncthreads();
         }
       }
+      if (active) {
 #pragma unroll
-      for (int k = 0; k < PP; ++k) {
-        const int pr = pg0 + tid + k * (int)blockDim.x;
-        if (pr < n_pairs) {
-          const int a = pr / n_dof;
-          const int64_t rowA = (int64_t)node[a] * DIM;
-          const int32_t off = pp_tab[pr];
+        for (int k = 0; k < PP; ++k) {
+          const int a = ag * PP + k;
+          if (a < n_dof) {
+            const int64_t rowA = (int64_t)node[a] * DIM;
+            const int32_t off = pp_tab[a * n_dof + b];
 #pragma unroll
-          for (int i = 0; i < DIM; ++i) {
-            double* dst = p.A + p.rowptr[rowA + i] + off;
+            for (int i = 0; i < DIM; ++i) {
+              double* dst = p.A + p.rowptr[rowA + i] + off;
 #pragma unroll
-            for (int j = 0; j < DIM; ++j) atomic_add_f64(dst + j, p.grad_factor * acc[k][i * DIM + j]);
+              for (int j = 0; j < DIM; ++j) atomic_add_f64(dst + j, p.grad_factor * acc[k][i * DIM + j]);
+            }
           }
         }
       }
