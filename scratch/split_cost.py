@@ -27,3 +27,18 @@ for world in (2, 4, 8):
     ti = timed(lambda: hi.AddDomainResidualAndGrad(u, 1.0, r, A))
     print(f"world {world}: whole slab {t1:.2f} ms; boundary layers {tb:.2f} ms + interior {ti:.2f} ms = {tb+ti:.2f} ms")
     del whole, hb, hi
+
+# the two boundary-layer handles of an interior rank on two streams
+print("--- boundary layers on two streams ---")
+for world in (4, 8):
+    shard = parallel.SlabShard(patch, pattern, world // 2, world)
+    bb, ib = shard.overlap_boxes()
+    s2 = torch.cuda.Stream(device=dev)
+    h0 = mk(bb[0]); h1 = mk(bb[1]); h1.SetStream(s2.cuda_stream)
+    def both():
+        s2.wait_stream(stream)
+        h0.AddDomainResidualAndGrad(u, 1.0, r, A)
+        h1.AddDomainResidualAndGrad(u, 1.0, r, A)
+        stream.wait_stream(s2)
+    print(f"world {world}: boundary layers on two streams {timed(both):.2f} ms")
+    del h0, h1
