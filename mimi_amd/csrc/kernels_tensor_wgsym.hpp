@@ -12,14 +12,15 @@
 //
 //   step D(e)   Y0: block (0,0) of element e   Y1: (1,1)   Y2: (2,2)     X: quadrature-point stage of e+1
 //   step O(e)   Y0: block (1,0) of element e   Y1: (2,0)   Y2: (2,1)     X: rows 0, 1, 2 of element e+1
-//   a step = [Y: flush / read operands from LDS] barrier [X, Y: compute, write LDS] barrier
+//   O(e) = [Y: read operands from LDS] barrier [X, Y: compute, write LDS] barrier;  D(e) runs free (no barriers):
+//   what it reads was written before the previous barrier and nothing it writes is read before the next one
 //
 // The rows of Ahat of element e are written during O(e-1), read (into registers) in the read windows
 // of D(e) and O(e) and rewritten during O(e): one LDS buffer, only the 54 entries (i, j <= i) kept.
 // The three store-transposition buffers (one per piece i) are written by all three contraction waves
 // during D(e) and O(e) and flushed, piece w by wave Y_w, in the read window of D(e+1).  A prologue
 // step lets X write the rows of element 0; after the last element each contraction wave stores the carried
-// rows (outside the lock steps).  Every wave executes 2 (2 n + 1) barriers.
+// rows (outside the lock steps).  Every wave executes 2 n + 1 barriers.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -222,19 +223,17 @@ MH_DEV void wgsym_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& 
   request(0);
   point_stage(0);
   if (1 < n_seq) request(1);
-  // ---- prologue step: rows of element 0 ---------------------------------------------------------------------
-  wgs_barrier();
+  // ---- prologue: rows of element 0 ---------------------------------------------------------------------------
   wgsym_x_rows<KIND>(p, lds, lane, element_at(0), 0, s);
   wgs_barrier();
   for (int it = 0; it < n_seq; ++it) {
-    // ---- step D(it): quadrature-point stage of element it + 1 -----------------------------------------------
-    wgs_barrier();
+    // ---- D(it), free running: quadrature-point stage of element it + 1 (touches nothing the other waves read
+    // before the next barrier: its own ue / point data and the table buffer of the OTHER parity) -----------------
     if (it + 1 < n_seq) {
       point_stage(it + 1);
       if (it + 2 < n_seq) request(it + 2);
     }
-    wgs_barrier();
-    // ---- step O(it): rows of element it + 1 ---------------------------------------------------------------------
+    // ---- O(it), lock step: rows of element it + 1 once every contraction wave holds its operands of element it --
     wgs_barrier();
     if (it + 1 < n_seq) wgsym_x_rows<KIND>(p, lds, lane, element_at(it + 1), (it + 1) & 1, s);
     wgs_barrier();
@@ -269,11 +268,10 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
   double aS0[4], aS2[4];
   double uB1[NB][NQ], uD1[NB][NQ];
 
-  // ---- prologue step: X writes the rows of element 0 ----------------------------------------------------------
-  wgs_barrier();
+  // ---- prologue: X writes the rows of element 0 ---------------------------------------------------------------
   wgs_barrier();
   for (int it = 0; it < n_seq; ++it) {
-    // ---- step D(it): flush element it - 1, tables of element it, diagonal block ------------------------------
+    // ---- D(it), free running: flush element it - 1, tables of element it, diagonal block ----------------------
     {
       if (it >= 1) wgs_flush_final(lane, st_of(W), piece_of(it - 1));
       const double* tab = lds + L::off_tab + (it & 1) * 6 * NB * NQ;
@@ -307,11 +305,12 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
       double ah[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k) ah[k] = AH0[k * NQ3 + lane];
-      wgs_barrier();
+      // no barriers around the diagonal block: it reads operands nobody rewrites before O(it)'s first barrier and
+      // writes only slots of this wave's own buffer that no other wave touches (the transposed entries other
+      // waves add to it during O steps use the other two column components)
       wgs_contract_block<WGSYM_DIAG_MODE>(lc, ah, aS0, aS2, uB1, uD1, C0, st_of(W), W, st_of(W), W);
-      wgs_barrier();
     }
-    // ---- step O(it): off-diagonal block, stored as computed and transposed ------------------------------------
+    // ---- O(it), lock step: off-diagonal block, stored as computed and transposed ------------------------------
     {
       double ah[9];
 #pragma unroll
@@ -341,14 +340,14 @@ __global__ __launch_bounds__(256, 2) void tensor_wgsym_kernel(TensorArgs p) {
   if (role == 0) {
     int status = 0;
 #ifdef WGSYM_EXP_SKIP_X
-    for (int k = 0; k < 2 * (2 * p.box_n[2] + 1); ++k) wgs_barrier();
+    for (int k = 0; k < 2 * p.box_n[2] + 1; ++k) wgs_barrier();
 #else
     wgsym_x_loop<KIND>(p, smem_wgsym, eu, ev, status);
 #endif
     if (status) atomicOr(p.status, status);
   } else {
 #ifdef WGSYM_EXP_SKIP_Y
-    for (int k = 0; k < 2 * (2 * p.box_n[2] + 1); ++k) wgs_barrier();
+    for (int k = 0; k < 2 * p.box_n[2] + 1; ++k) wgs_barrier();
 #else
     if (role == 1) wgsym_y_loop<0>(p, smem_wgsym, eu, ev);
     else if (role == 2) wgsym_y_loop<1>(p, smem_wgsym, eu, ev);
