@@ -20,11 +20,13 @@
 //                 read-modify-write; LDS is only used to transpose the finished entries for
 //                 coalesced stores (write once, read once).
 //
-// The four waves run in lock step, three steps per element (X: row k; Y_i: column component j),
-// Y_i lagging X by i + 1 steps, so Ahat needs a single LDS buffer:
-//     step = [Y: read its operands from LDS] barrier [X: compute + write; Y: compute] barrier
-// Every wave executes exactly 6 (n_seq + 1) barriers.  Scratch layout, phase 2 and the bitwise
-// reproducibility of the result are those of kernels_tensor_2phase.hpp.
+// Per element X evaluates the points of the NEXT element and then writes its three Ahat rows; Y_i contracts the
+// column components j = 0, 1, 2 of row i.  Only Ahat is shared, with a single LDS buffer:
+//     Y: [tables, j = 0, j = 1: free running]  [read the j = 2 operands] barrier [j = 2, flush] barrier
+//     X: [point stage of the next element: free running]               barrier [its rows]       barrier
+// (what runs free reads data written before the previous barrier and writes nothing another wave reads before
+// the next one; the store-transposition buffer of a contraction wave is private).  Every wave executes 2 n + 1
+// barriers.  Scratch layout, phase 2 and the bitwise reproducibility of the result: kernels_tensor_2phase.hpp.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -442,98 +444,102 @@ MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& st
   request(0);
 
   WgsPoint<KIND> s;
-  int64_t e = 0;
-  for (int it = 0; it <= n_seq; ++it) {
-    const bool valid = it < n_seq;
-    const int par = it & 1;
-    // ---- step 0: quadrature-point stage + row 0 ------------------------------------------------
-    wgs_barrier();
-    if (valid) {
-      double* tab = lds + L::off_tab + par * 6 * NB * NQ;
-      if (lane < ND) {
+  // quadrature-point stage of element es from the requested operands (tables -> LDS parity es & 1)
+  auto point_stage = [&](int es) {
+    const int par = es & 1;
+    const int64_t e = element_at(es);
+    double* tab = lds + L::off_tab + par * 6 * NB * NQ;
+    if (lane < ND) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) ue[c * ND + lane] = ue_r[c];
-      }
+      for (int c = 0; c < 3; ++c) ue[c * ND + lane] = ue_r[c];
+    }
 #pragma unroll
-      for (int rd = 0; rd < TROUNDS; ++rd) {
-        const int t = rd * 64 + lane;
-        if (t < 6 * NB * NQ) tab[t] = tab_r[rd];
-      }
-      double Ji[9];
+    for (int rd = 0; rd < TROUNDS; ++rd) {
+      const int t = rd * 64 + lane;
+      if (t < 6 * NB * NQ) tab[t] = tab_r[rd];
+    }
+    double Ji[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Ji[k] = geo_r[k];
-      const double wd = geo_r[9];
-      e = element_at(it);
-      __builtin_amdgcn_wave_barrier();
-      if constexpr (KIND == MIMI_HIP_MAT_NEOHOOKEAN) {
-        // F at the quadrature point of this lane, q = q0 + 4 q1 + 16 q2
-        double F[9];
-        {
-          const int q0 = lane & 3, q1 = (lane >> 2) & 3, q2 = lane >> 4;
-          double b0[NB], d0[NB], b1[NB], d1[NB], b2[NB], d2[NB];
+    for (int k = 0; k < 9; ++k) Ji[k] = geo_r[k];
+    const double wd = geo_r[9];
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (KIND == MIMI_HIP_MAT_NEOHOOKEAN) {
+      // F at the quadrature point of this lane, q = q0 + 4 q1 + 16 q2
+      double F[9];
+      {
+        const int q0 = lane & 3, q1 = (lane >> 2) & 3, q2 = lane >> 4;
+        double b0[NB], d0[NB], b1[NB], d1[NB], b2[NB], d2[NB];
 #pragma unroll
-          for (int a = 0; a < NB; ++a) {
-            b0[a] = tab_ptr<P>(tab, 0, 0)[a * NQ + q0];
-            d0[a] = tab_ptr<P>(tab, 0, 1)[a * NQ + q0];
-            b1[a] = tab_ptr<P>(tab, 1, 0)[a * NQ + q1];
-            d1[a] = tab_ptr<P>(tab, 1, 1)[a * NQ + q1];
-            b2[a] = tab_ptr<P>(tab, 2, 0)[a * NQ + q2];
-            d2[a] = tab_ptr<P>(tab, 2, 1)[a * NQ + q2];
-          }
-          double H[9];
-#pragma unroll
-          for (int k = 0; k < 9; ++k) H[k] = 0.0;
-#pragma unroll
-          for (int a2 = 0; a2 < NB; ++a2)
-#pragma unroll
-            for (int a1 = 0; a1 < NB; ++a1) {
-              const double tbb = b1[a1] * b2[a2], tdb = d1[a1] * b2[a2], tbd = b1[a1] * d2[a2];
-#pragma unroll
-              for (int a0 = 0; a0 < NB; ++a0) {
-                const int a = a0 + NB * (a1 + NB * a2);
-                const double dn0 = d0[a0] * tbb, dn1 = b0[a0] * tdb, dn2 = b0[a0] * tbd;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                  const double uu = ue[i * ND + a];
-                  H[i * 3 + 0] += uu * dn0;
-                  H[i * 3 + 1] += uu * dn1;
-                  H[i * 3 + 2] += uu * dn2;
-                }
-              }
-              // keep the LDS reads of later (a1, a2) where they are (hoisted together they need 162 registers)
-              #pragma unroll
-              for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(H[k]) : : "memory");
-            }
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int J = 0; J < 3; ++J) {
-              double sf = (i == J) ? 1.0 : 0.0;
-#pragma unroll
-              for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * Ji[m * 3 + J];
-              F[i + J * 3] = sf;
-            }
+        for (int a = 0; a < NB; ++a) {
+          b0[a] = tab_ptr<P>(tab, 0, 0)[a * NQ + q0];
+          d0[a] = tab_ptr<P>(tab, 0, 1)[a * NQ + q0];
+          b1[a] = tab_ptr<P>(tab, 1, 0)[a * NQ + q1];
+          d1[a] = tab_ptr<P>(tab, 1, 1)[a * NQ + q1];
+          b2[a] = tab_ptr<P>(tab, 2, 0)[a * NQ + q2];
+          d2[a] = tab_ptr<P>(tab, 2, 1)[a * NQ + q2];
         }
-        status |= wgs_x_point<KIND>(p, e * NQ3 + lane, F, Ji, wd, s);
-      } else {
-        // J2: the material was evaluated by tensor_point_kernel
-        PointResult<3> w;
-        wgs_point_load(p.scratch_pt + e * (int64_t)(WGS_PT_FIELDS * NQ3), lane, w);
-        wgs_j2_point(p.mat.m, w, Ji, wd, s);
+        double H[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) H[k] = 0.0;
+#pragma unroll
+        for (int a2 = 0; a2 < NB; ++a2)
+#pragma unroll
+          for (int a1 = 0; a1 < NB; ++a1) {
+            const double tbb = b1[a1] * b2[a2], tdb = d1[a1] * b2[a2], tbd = b1[a1] * d2[a2];
+#pragma unroll
+            for (int a0 = 0; a0 < NB; ++a0) {
+              const int a = a0 + NB * (a1 + NB * a2);
+              const double dn0 = d0[a0] * tbb, dn1 = b0[a0] * tdb, dn2 = b0[a0] * tbd;
+#pragma unroll
+              for (int i = 0; i < 3; ++i) {
+                const double uu = ue[i * ND + a];
+                H[i * 3 + 0] += uu * dn0;
+                H[i * 3 + 1] += uu * dn1;
+                H[i * 3 + 2] += uu * dn2;
+              }
+            }
+            // keep the LDS reads of later (a1, a2) where they are (hoisted together they need 162 registers)
+            #pragma unroll
+            for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(H[k]) : : "memory");
+          }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int J = 0; J < 3; ++J) {
+            double sf = (i == J) ? 1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * Ji[m * 3 + J];
+            F[i + J * 3] = sf;
+          }
       }
-      wgs_x_row<KIND, 0>(p, lds, lane, e, par, s);
+      status |= wgs_x_point<KIND>(p, e * NQ3 + lane, F, Ji, wd, s);
+    } else {
+      // J2: the material was evaluated by tensor_point_kernel
+      PointResult<3> w;
+      wgs_point_load(p.scratch_pt + e * (int64_t)(WGS_PT_FIELDS * NQ3), lane, w);
+      wgs_j2_point(p.mat.m, w, Ji, wd, s);
     }
-    wgs_barrier();
-    // ---- step 1: row 1 ---------------------------------------------------------------------------
-    wgs_barrier();
-    if (valid) wgs_x_row<KIND, 1>(p, lds, lane, e, par, s);
-    wgs_barrier();
-    // ---- step 2: row 2, then the requests of the next element ---------------------------------------
-    wgs_barrier();
-    if (valid) {
-      wgs_x_row<KIND, 2>(p, lds, lane, e, par, s);
-      if (it + 1 < n_seq) request(it + 1);
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto rows = [&](int es) {
+    wgs_x_row<KIND, 0>(p, lds, lane, element_at(es), es & 1, s);
+    wgs_x_row<KIND, 1>(p, lds, lane, element_at(es), es & 1, s);
+    wgs_x_row<KIND, 2>(p, lds, lane, element_at(es), es & 1, s);
+  };
+  // prologue: point stage and rows of element 0
+  point_stage(0);
+  if (1 < n_seq) request(1);
+  rows(0);
+  wgs_barrier();
+  for (int it = 0; it < n_seq; ++it) {
+    // free running: point stage of element it + 1 (its own ue / point data, the table buffer of the OTHER parity)
+    if (it + 1 < n_seq) {
+      point_stage(it + 1);
+      if (it + 2 < n_seq) request(it + 2);
     }
+    // lock step: rows of element it + 1, once every contraction wave holds its last operands of element it
+    wgs_barrier();
+    if (it + 1 < n_seq) rows(it + 1);
     wgs_barrier();
   }
 }
@@ -708,6 +714,9 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
   double* AH = lds + L::off_ah + I * ND * NQ3;
   double* ST = lds + L::off_st + I * L::st_size;
   const int n_seq = p.box_n[2];
+  auto piece_of = [&](int es) -> double* {
+    return p.scratch_k + ((eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * es)) * 3 + I) * (int64_t)NK;
+  };
   // matrix-operand lane constants: pair index on bits 3:0, contraction index on bits 5:4
   const int mrow = lane & 15, mk = lane >> 4;
   const bool mrow_ok = mrow < NB2;
@@ -726,79 +735,82 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
   for (int a = 0; a < NB; ++a)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) uB1[a][q] = uD1[a][q] = 0.0;
-  // the steps before the first element of this wave run on zeros (their results are never stored)
+  auto load_slice = [&](int j, double (&ah)[9]) {
 #pragma unroll
-  for (int c = 0; c < ND; ++c) AH[c * NQ3 + lane] = 0.0;
-  for (int t = lane; t < 2 * 6 * NB * NQ; t += 64) lds[L::off_tab + t] = 0.0;
-
-  for (int it = 0; it <= n_seq; ++it) {
+    for (int m = 0; m < 3; ++m)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int j = (k - I - 1 + 3) % 3;             // compile-time after unrolling
-      const int es = (k >= I + 1) ? it : it - 1;     // element of this step
-      const bool valid = es >= 0 && es < n_seq;
+      for (int n = 0; n < 3; ++n) ah[m * 3 + n] = AH[((m * 3 + j) * 3 + n) * NQ3 + lane];
+  };
+  // prologue: X writes the rows of element 0
+  wgs_barrier();
+  for (int it = 0; it < n_seq; ++it) {
+    // ---- free running: tables, column components j = 0, 1 (the store-transposition buffer of this wave is private;
+    // the operands read here were written before the previous barrier and are rewritten after the next one) -----
+    {
+      const double* tab = lds + L::off_tab + (it & 1) * 6 * NB * NQ;
+      {
+        const double Ba = tab_ptr<P>(tab, 0, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 0, 1)[mra * NQ + mk];
+        const double Bb = tab_ptr<P>(tab, 0, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 0, 1)[mrb * NQ + mk];
+        aS0[0] = mrow_ok ? Ba * Bb : 0.0;
+        aS0[1] = mrow_ok ? Da * Bb : 0.0;
+        aS0[2] = mrow_ok ? Ba * Db : 0.0;
+        aS0[3] = mrow_ok ? Da * Db : 0.0;
+      }
+      {
+        const double Ba = tab_ptr<P>(tab, 2, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 2, 1)[mra * NQ + mk];
+        const double Bb = tab_ptr<P>(tab, 2, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 2, 1)[mrb * NQ + mk];
+        aS2[0] = mrow_ok ? Ba * Bb : 0.0;
+        aS2[1] = mrow_ok ? Da * Bb : 0.0;
+        aS2[2] = mrow_ok ? Ba * Db : 0.0;
+        aS2[3] = mrow_ok ? Da * Db : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int q1 = 0; q1 < NQ; ++q1) {
+          const unsigned long long vb = __double_as_longlong(tab_ptr<P>(tab, 1, 0)[a * NQ + q1]);
+          const unsigned long long vd = __double_as_longlong(tab_ptr<P>(tab, 1, 1)[a * NQ + q1]);
+          const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)vb), bhi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
+          const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)vd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(vd >> 32));
+          uB1[a][q1] = __longlong_as_double(((unsigned long long)bhi << 32) | blo);
+          uD1[a][q1] = __longlong_as_double(((unsigned long long)dhi << 32) | dlo);
+        }
+    }
+    {
       double ah[9];
-      // ---- read window ---------------------------------------------------------------------------
-      if (j == 0) {   // (branch-free in the step loop: before the first element the tables read as zeros)
-        const double* tab = lds + L::off_tab + (es & 1) * 6 * NB * NQ;
-        {
-          const double Ba = tab_ptr<P>(tab, 0, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 0, 1)[mra * NQ + mk];
-          const double Bb = tab_ptr<P>(tab, 0, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 0, 1)[mrb * NQ + mk];
-          aS0[0] = mrow_ok ? Ba * Bb : 0.0;
-          aS0[1] = mrow_ok ? Da * Bb : 0.0;
-          aS0[2] = mrow_ok ? Ba * Db : 0.0;
-          aS0[3] = mrow_ok ? Da * Db : 0.0;
-        }
-        {
-          const double Ba = tab_ptr<P>(tab, 2, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 2, 1)[mra * NQ + mk];
-          const double Bb = tab_ptr<P>(tab, 2, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 2, 1)[mrb * NQ + mk];
-          aS2[0] = mrow_ok ? Ba * Bb : 0.0;
-          aS2[1] = mrow_ok ? Da * Bb : 0.0;
-          aS2[2] = mrow_ok ? Ba * Db : 0.0;
-          aS2[3] = mrow_ok ? Da * Db : 0.0;
-        }
-#pragma unroll
-        for (int a = 0; a < NB; ++a)
-#pragma unroll
-          for (int q1 = 0; q1 < NQ; ++q1) {
-            const unsigned long long vb = __double_as_longlong(tab_ptr<P>(tab, 1, 0)[a * NQ + q1]);
-            const unsigned long long vd = __double_as_longlong(tab_ptr<P>(tab, 1, 1)[a * NQ + q1]);
-            const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)vb), bhi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
-            const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)vd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(vd >> 32));
-            uB1[a][q1] = __longlong_as_double(((unsigned long long)bhi << 32) | blo);
-            uD1[a][q1] = __longlong_as_double(((unsigned long long)dhi << 32) | dlo);
-          }
-      }
-#pragma unroll
-      for (int m = 0; m < 3; ++m)
-#pragma unroll
-        for (int n = 0; n < 3; ++n) ah[m * 3 + n] = AH[((m * 3 + j) * 3 + n) * NQ3 + lane];
+      load_slice(0, ah);
+      wgs_contract_block<0>(lc, ah, aS0, aS2, uB1, uD1, C[0], ST, 0, ST, 0);
+    }
+    {
+      double ah[9];
+      load_slice(1, ah);
+      wgs_contract_block<0>(lc, ah, aS0, aS2, uB1, uD1, C[1], ST, 1, ST, 1);
+    }
+    // ---- lock step: column component j = 2 while X rewrites the rows for the next element ----------------------
+    {
+      double ah[9];
+      load_slice(2, ah);
       wgs_barrier();
-      // ---- compute window (branch-free: steps outside the column run on zeros / stale operands) -------
-      wgs_contract_block<0>(lc, ah, aS0, aS2, uB1, uD1, C[j], ST, j, ST, j);
-      if (j == 2 && valid) {
-        __builtin_amdgcn_wave_barrier();
-        double* S = p.scratch_k + ((eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * es)) * 3 + I) * (int64_t)NK;
-        wgs_flush_final(lane, ST, S);
-        __builtin_amdgcn_wave_barrier();
-        if (es + 1 >= n_seq) {
-          // the carried rows of the last element have no successor: store them as well
-#pragma unroll
-          for (int jj = 0; jj < 3; ++jj) wgs_stage_carry<0>(lc, C[jj], ST, jj, ST, jj);
-          __builtin_amdgcn_wave_barrier();
-          wgs_flush_carry(lane, ST, S);
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
+      wgs_contract_block<0>(lc, ah, aS0, aS2, uB1, uD1, C[2], ST, 2, ST, 2);
+      // this wave's piece of the element is complete: buffer -> scratch
+      __builtin_amdgcn_wave_barrier();
+      wgs_flush_final(lane, ST, piece_of(it));
+      __builtin_amdgcn_wave_barrier();
       wgs_barrier();
     }
+  }
+  // the carried rows of the last element have no successor: straight from the registers into the third part of the piece
+  {
+    double* Sc = piece_of(n_seq - 1) + WgsLds::n_final;
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) wgs_stage_carry<0>(lc, C[jj], Sc, jj, Sc, jj);
   }
 }
 
 #ifdef WGS_EXP_SKIP_Y
 template<int I>
 MH_DEV void wgs_y_skip(const TensorArgs& p) {
-  for (int it = 0; it < 6 * (p.box_n[2] + 1); ++it) wgs_barrier();
+  for (int it = 0; it < 2 * p.box_n[2] + 1; ++it) wgs_barrier();
 }
 #define wgs_y_loop wgs_y_skip
 #define WGS_Y_ARGS p
@@ -821,7 +833,7 @@ __global__ __launch_bounds__(256, 2) void tensor_wgs_kernel(TensorArgs p) {
   if (role == 0) {
     int status = 0;
 #ifdef WGS_EXP_SKIP_X
-    for (int it = 0; it < 6 * (p.box_n[2] + 1); ++it) wgs_barrier();
+    for (int it = 0; it < 2 * p.box_n[2] + 1; ++it) wgs_barrier();
 #else
     wgs_x_loop<KIND>(p, smem_wgs, eu, ev, status);
 #endif
