@@ -1,14 +1,14 @@
 // Phase 1 of the two-phase tangent assembly as a ROLE-SPECIALISED workgroup (p = 2, 3-D).
 //
-// Why: the single-wave phase-1 kernel (kernels_tensor_2phase.hpp) needs the whole register file
-// of a SIMD (constitutive stage + contraction tiles + prefetch live together) and 31 KB of LDS,
-// so one wave runs alone per SIMD and every LDS / matrix-pipe / memory latency is exposed
-// (profiles/r01_*: ~46 k cycles per (element, i) for ~20 k cycles of issued work).  Here the work
-// of one element column is split over four waves of one workgroup so that each wave fits in half
-// a register file and two workgroups (8 waves) share a CU:
+// Why: a single wave doing everything for an (element column, row i) -- the first phase-1 kernel of this path --
+// needs the whole register file of a SIMD (constitutive stage + contraction tiles + prefetch live together) and
+// 31 KB of LDS, so it runs alone per SIMD and every LDS / matrix-pipe / memory latency is exposed (measured:
+// ~46 k cycles per (element, i) for ~20 k cycles of issued work).  Here the work of one element column is
+// split over four waves of one workgroup so that each wave fits in half a register file and two workgroups
+// (8 waves) share a CU:
 //
 //   wave 0  "X"   quadrature-point stage: gathers u, evaluates F and the material ONCE per point
-//                 (the single-wave kernel repeats this for every row i), then per row i the
+//                 (the single-wave kernel repeated this for every row i), then per row i the
 //                 residual piece (sum factorisation) and the pulled-back tangent row
 //                 Ahat_i[m][j][n] -> LDS (lane = quadrature point, private slots).
 //   wave 1+i "Y_i" contraction of row i:  S1 (matrix pipe, q2) -> S2 (vector pipe, q1, wave-uniform
