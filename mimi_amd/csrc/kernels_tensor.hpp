@@ -57,7 +57,7 @@ struct TensorArgs {
   unsigned long long* prof;  // diagnostic build only (MH_PROFILE): per-stage cycle sums
   double* scratch_k;         // two-phase path: [n_el][3][27*81] element row pieces
   double* scratch_r;         // two-phase path: [n_el][3][27] element residual pieces
-  double* scratch_pt;        // two-phase path, J2: [n_el][41][n_q] material results per quadrature point
+  double* scratch_pt;        // two-phase path, J2: [n_el][24][n_q] material results per quadrature point
   const int64_t* perm;       // two-phase path: lexicographic -> caller's node id (nullptr = identity)
   const unsigned char* nbr_pos;  // two-phase path, permuted numbering: [n_nodes][125] positions inside a CSR row
 };

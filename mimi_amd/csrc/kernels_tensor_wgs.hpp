@@ -73,38 +73,49 @@ MH_DEV void swap32_f64(double c, double o, double& c_hi_in_lo, double& o_lo_in_h
 // the single point wave and bound the whole kernel.  Here every wave of the chip takes one element
 // (lane = quadrature point) and leaves the PointResult in scratch_pt[element][field][point].
 // ------------------------------------------------------------------------------------------------
-constexpr int WGS_PT_FIELDS = 41;  // P 9, Finv 9, detF, sigma 9, s_trial 9, q, delta, hprime, plastic
+// record of a point: Finv 9, detF, sigma (symmetric: 6), trial deviator (symmetric: 6), beta, gamma of the algorithmic
+// tangent (materials.hpp tangent_row_of) -- P = J sigma F^-T is recomputed by the reader
+constexpr int WGS_PT_FIELDS = 24;
 
-MH_DEV void wgs_point_store(double* rec, int lane, const PointResult<3>& w) {
+MH_DEV void wgs_point_store(double* rec, int lane, const mimi_hip_material& m, const PointResult<3>& w) {
   constexpr int NQ3 = 64;
+  constexpr int sym_i[6] = {0, 1, 2, 1, 2, 2}, sym_j[6] = {0, 0, 0, 1, 1, 2};
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    rec[(0 + k) * NQ3 + lane] = w.P[k];
-    rec[(9 + k) * NQ3 + lane] = w.Finv[k];
-    rec[(19 + k) * NQ3 + lane] = w.sigma[k];
-    rec[(28 + k) * NQ3 + lane] = w.s_trial[k];
+  for (int k = 0; k < 9; ++k) rec[k * NQ3 + lane] = w.Finv[k];
+  rec[9 * NQ3 + lane] = w.detF;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    rec[(10 + k) * NQ3 + lane] = w.sigma[sym_i[k] + 3 * sym_j[k]];
+    rec[(16 + k) * NQ3 + lane] = w.s_trial[sym_i[k] + 3 * sym_j[k]];
   }
-  rec[18 * NQ3 + lane] = w.detF;
-  rec[37 * NQ3 + lane] = w.q;
-  rec[38 * NQ3 + lane] = w.delta;
-  rec[39 * NQ3 + lane] = w.hprime;
-  rec[40 * NQ3 + lane] = w.plastic ? 1.0 : 0.0;
+  double beta = 1.0, gamma = 0.0;
+  if (w.plastic) {
+    const double q = w.q, G = m.G;
+    beta = 1.0 - 3.0 * G * w.delta / q;
+    gamma = 3.0 * G * (1.5 / q) * (1.0 / ((3.0 * G + w.hprime) * q) - w.delta / (q * q));
+  }
+  rec[22 * NQ3 + lane] = beta;
+  rec[23 * NQ3 + lane] = gamma;
 }
 
-MH_DEV void wgs_point_load(const double* rec, int lane, PointResult<3>& w) {
+// w gets Finv, detF, sigma, s_trial and (recomputed as the material does, pk1_from_cauchy) P
+MH_DEV void wgs_point_load(const double* rec, int lane, PointResult<3>& w, double& beta, double& gamma) {
   constexpr int NQ3 = 64;
+  constexpr int sym_i[6] = {0, 1, 2, 1, 2, 2}, sym_j[6] = {0, 0, 0, 1, 1, 2};
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    w.P[k] = rec[(0 + k) * NQ3 + lane];
-    w.Finv[k] = rec[(9 + k) * NQ3 + lane];
-    w.sigma[k] = rec[(19 + k) * NQ3 + lane];
-    w.s_trial[k] = rec[(28 + k) * NQ3 + lane];
+  for (int k = 0; k < 9; ++k) w.Finv[k] = rec[k * NQ3 + lane];
+  w.detF = rec[9 * NQ3 + lane];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double sg = rec[(10 + k) * NQ3 + lane], st = rec[(16 + k) * NQ3 + lane];
+    w.sigma[sym_i[k] + 3 * sym_j[k]] = sg;
+    w.sigma[sym_j[k] + 3 * sym_i[k]] = sg;
+    w.s_trial[sym_i[k] + 3 * sym_j[k]] = st;
+    w.s_trial[sym_j[k] + 3 * sym_i[k]] = st;
   }
-  w.detF = rec[18 * NQ3 + lane];
-  w.q = rec[37 * NQ3 + lane];
-  w.delta = rec[38 * NQ3 + lane];
-  w.hprime = rec[39 * NQ3 + lane];
-  w.plastic = rec[40 * NQ3 + lane] != 0.0;
+  beta = rec[22 * NQ3 + lane];
+  gamma = rec[23 * NQ3 + lane];
+  pk1_from_cauchy<3>(w);
 }
 
 __global__ __launch_bounds__(256) void tensor_point_kernel(TensorArgs p, int n_el) {
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(256) void tensor_point_kernel(TensorArgs p, int n_e
     }
   PointResult<3> w;
   const int status = evaluate_pk1<3>(p.mat, p.dt, p.state, e * NQ3 + lane, F, w);
-  wgs_point_store(p.scratch_pt + e * (int64_t)(WGS_PT_FIELDS * NQ3), lane, w);
+  wgs_point_store(p.scratch_pt + e * (int64_t)(WGS_PT_FIELDS * NQ3), lane, p.mat.m, w);
   if (status) atomicOr(p.status, status);
 }
 
@@ -195,14 +206,8 @@ struct WgsPoint<MIMI_HIP_MAT_J2> {
 };
 
 // fills WgsPoint<J2> from the PointResult of the material pre-pass
-MH_DEV void wgs_j2_point(const mimi_hip_material& m, const PointResult<3>& w, const double* Ji, double wd,
-                         WgsPoint<MIMI_HIP_MAT_J2>& s) {
-  double beta = 1.0, gamma = 0.0;
-  if (w.plastic) {
-    const double q = w.q, G = m.G;
-    beta = 1.0 - 3.0 * G * w.delta / q;
-    gamma = 3.0 * G * (1.5 / q) * (1.0 / ((3.0 * G + w.hprime) * q) - w.delta / (q * q));
-  }
+MH_DEV void wgs_j2_point(const mimi_hip_material& m, const PointResult<3>& w, double beta, double gamma, const double* Ji,
+                         double wd, WgsPoint<MIMI_HIP_MAT_J2>& s) {
   const double G2 = 2.0 * m.G;
   s.wdJ = wd * w.detF;
   s.Kc = m.K - beta * G2 / 3.0;
@@ -297,7 +302,13 @@ MH_DEV int wgs_x_point(const TensorArgs& p, int64_t pt, const double* F, const d
     mat.m.kind = KIND;
     PointResult<3> w;
     const int status = evaluate_pk1<3>(mat, p.dt, p.state, pt, F, w);
-    wgs_j2_point(p.mat.m, w, Ji, wd, s);
+    double beta = 1.0, gamma = 0.0;
+    if (w.plastic) {
+      const double q = w.q, G = p.mat.m.G;
+      beta = 1.0 - 3.0 * G * w.delta / q;
+      gamma = 3.0 * G * (1.5 / q) * (1.0 / ((3.0 * G + w.hprime) * q) - w.delta / (q * q));
+    }
+    wgs_j2_point(p.mat.m, w, beta, gamma, Ji, wd, s);
     return status;
   }
 }
@@ -516,8 +527,9 @@ MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& st
     } else {
       // J2: the material was evaluated by tensor_point_kernel
       PointResult<3> w;
-      wgs_point_load(p.scratch_pt + e * (int64_t)(WGS_PT_FIELDS * NQ3), lane, w);
-      wgs_j2_point(p.mat.m, w, Ji, wd, s);
+      double beta, gamma;
+      wgs_point_load(p.scratch_pt + e * (int64_t)(WGS_PT_FIELDS * NQ3), lane, w, beta, gamma);
+      wgs_j2_point(p.mat.m, w, beta, gamma, Ji, wd, s);
     }
     __builtin_amdgcn_wave_barrier();
   };
