@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -38,6 +40,22 @@ struct Error : std::runtime_error {
       ::mimi_hip::fail("HIP error %s at %s:%d: %s", hipGetErrorName(e_), __FILE__, __LINE__, \
                        hipGetErrorString(e_));                                             \
   } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device) instead of once per launch (it costs microseconds,
+// which the small meshes of the reference's examples notice)
+inline void ensure_dynamic_lds(const void* kernel, int bytes) {
+  static std::mutex guard;
+  static std::map<std::pair<const void*, int>, int> granted;
+  int device = 0;
+  MH_HIP(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(guard);
+  int& have = granted[std::make_pair(kernel, device)];
+  if (bytes > have) {
+    MH_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have = bytes;
+  }
+}
+
 
 void set_last_error(const std::string& s);
 

@@ -208,7 +208,7 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a)
   if (lds > 160 * 1024) fail("element too large for LDS (%zu bytes)", lds);
   auto go = [&](auto kernel, int threads = 256) {
     if (lds > 64 * 1024)
-      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
     hipLaunchKernelGGL(kernel, dim3(h->n_el), dim3(threads), lds, h->stream, a);
     MH_HIP(hipGetLastError());
   };

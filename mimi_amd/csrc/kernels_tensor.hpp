@@ -767,7 +767,7 @@ inline void launch_tensor_p(mimi_hip_domain_s* h, int grad, TensorArgs a) {
   const size_t lds = TensorLds<P>::total * sizeof(double);
   auto kernel = grad ? tensor_domain_kernel<P, 1> : tensor_domain_kernel<P, 0>;
   if (lds > 64 * 1024)
-    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
   const int nu = a.box_n[a.u_axis], nv = a.box_n[a.v_axis];
   for (int cv = 0; cv < P + 1; ++cv)
     for (int cu = 0; cu < P + 1; ++cu) {

@@ -875,7 +875,7 @@ inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a) {
     MH_HIP(hipGetLastError());
   }
   auto kernel = h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN ? tensor_wgs_kernel<MIMI_HIP_MAT_NEOHOOKEAN> : tensor_wgs_kernel<MIMI_HIP_MAT_J2>;
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
   hipLaunchKernelGGL(kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
   MH_HIP(hipGetLastError());
   launch_tensor_p2(h, a);

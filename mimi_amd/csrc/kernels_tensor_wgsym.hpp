@@ -366,7 +366,7 @@ inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a) {
   a.n_units_v = a.box_n[1];
   const size_t lds = WgsymLds::total * sizeof(double);
   auto kernel = tensor_wgsym_kernel<MIMI_HIP_MAT_NEOHOOKEAN>;
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
   hipLaunchKernelGGL(kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
   MH_HIP(hipGetLastError());
   launch_tensor_p2(h, a);
