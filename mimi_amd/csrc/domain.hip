@@ -105,6 +105,52 @@ static void init_state(mimi_hip_domain_s* h) {
   MH_HIP(hipStreamSynchronize(h->stream));
 }
 
+// pair_pos[e][a][b]: offset of column dofs[b] * dim inside row dofs[a] * dim (what the general and colour kernels scatter
+// through); col = the CSR columns, host or device
+static void build_pair_pos(mimi_hip_domain_s* h, const int32_t* col) {
+  DeviceBuffer<int32_t> col_tmp;
+  const int32_t* col_dev = col;
+  if (!is_device_pointer(col)) {
+    col_tmp.assign(col, h->nnz, h->stream);
+    col_dev = col_tmp.ptr;
+  }
+  const int64_t total = (int64_t)h->n_el * h->n_dof * h->n_dof;
+  h->pair_pos.resize(total);
+  const int threads = 256;
+  const int64_t blocks = (total + threads - 1) / threads;
+  hipLaunchKernelGGL(pair_pos_kernel, dim3((unsigned)blocks), dim3(threads), 0, h->stream, h->n_el, h->n_dof,
+                     h->dim, h->dofs.ptr, h->rowptr, col_dev, h->pair_pos.ptr, h->status_dev);
+  MH_HIP(hipGetLastError());
+  check_status(h);
+}
+
+// Handles whose CSR is the (possibly permuted) structured pattern do not build pair_pos at create time: the two-phase
+// kernels never use it.  The fallback kernels get it here, from columns regenerated out of the pattern's closed form.
+static void ensure_pair_pos(mimi_hip_domain_s* h) {
+  if (h->pair_pos.ptr) return;
+  if (!(h->structured_csr || h->structured_perm)) fail("pair positions were not built for this handle");
+  SparsityDev S{};
+  S.dim = h->dim;
+  for (int d = 0; d < 3; ++d) {
+    S.n[d] = d < h->dim ? h->n_ctrl[d] : 1;
+    S.p[d] = d < h->dim ? h->degree[d] : 0;
+    S.prefix[d] = nullptr;
+  }
+  DeviceBuffer<int32_t> col;
+  col.resize((size_t)h->nnz);
+  if (h->structured_csr) {
+    const int64_t n_rows = h->n_vdofs;
+    hipLaunchKernelGGL(structured_col_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, h->stream, S, n_rows, h->rowptr,
+                       col.ptr, 0, h->status_dev);
+  } else {
+    hipLaunchKernelGGL(permuted_col_kernel, dim3((unsigned)((h->n_nodes + 3) / 4)), dim3(256), 0, h->stream, S, (int64_t)h->n_nodes,
+                       h->node_ids.ptr, h->rowptr, h->nbr_pos.ptr, col.ptr);
+  }
+  MH_HIP(hipGetLastError());
+  build_pair_pos(h, col.ptr);
+  MH_HIP(hipStreamSynchronize(h->stream));
+}
+
 static void setup_csr(mimi_hip_domain_s* h, const int64_t* rowptr, const int32_t* col, bool need_pair_pos) {
   if (!rowptr || !col) fail("csr_rowptr / csr_col must be given");
   // rowptr: keep a device copy unless it already lives there
@@ -118,23 +164,8 @@ static void setup_csr(mimi_hip_domain_s* h, const int64_t* rowptr, const int32_t
   MH_HIP(hipMemcpyAsync(&nnz, h->rowptr + h->n_vdofs, sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
   MH_HIP(hipStreamSynchronize(h->stream));
   h->nnz = nnz;
-  if (!need_pair_pos) return;
-  DeviceBuffer<int32_t> col_tmp;
-  const int32_t* col_dev = col;
-  if (!is_device_pointer(col)) {
-    col_tmp.assign(col, nnz, h->stream);
-    col_dev = col_tmp.ptr;
-  }
-  const int64_t total = (int64_t)h->n_el * h->n_dof * h->n_dof;
-  h->pair_pos.resize(total);
-  const int threads = 256;
-  const int64_t blocks = (total + threads - 1) / threads;
-  hipLaunchKernelGGL(pair_pos_kernel, dim3((unsigned)blocks), dim3(threads), 0, h->stream, h->n_el, h->n_dof,
-                     h->dim, h->dofs.ptr, h->rowptr, col_dev, h->pair_pos.ptr, h->status_dev);
-  MH_HIP(hipGetLastError());
-  check_status(h);
+  if (need_pair_pos) build_pair_pos(h, col);
 }
-
 
 static PatchDev patch_dev(mimi_hip_domain_s* h, const double* ctrl) {
   PatchDev P{};
@@ -161,6 +192,7 @@ static PatchDev patch_dev(mimi_hip_domain_s* h, const double* ctrl) {
 
 // reference-layout tables (utils/precomputed.cpp:316-321) from the compact geometry, on demand
 static void ensure_general_tables(mimi_hip_domain_s* h) {
+  ensure_pair_pos(h);
   if (h->dN_dX.ptr) return;
   if (!h->geo.ptr) fail("no tables to integrate with");
   const int64_t npts = (int64_t)h->n_el * h->n_q;
@@ -416,7 +448,7 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
       MH_HIP(hipGetLastError());
       MH_HIP(hipStreamSynchronize(h->stream));
     }
-    setup_csr(h.get(), p->csr_rowptr, p->csr_col, true);
+    setup_csr(h.get(), p->csr_rowptr, p->csr_col, false);
     // lexicographic numbering + the closed-form pattern => CSR positions are arithmetic
     h->structured_csr = false;
     if (!p->node_ids && dim == 3 && !(getenv("MIMI_HIP_NO_STRUCTURED") && getenv("MIMI_HIP_NO_STRUCTURED")[0] == '1')) {
@@ -473,6 +505,8 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
       h->structured_perm = (*h->status_host == 0);
       MH_HIP(hipMemsetAsync(h->status_dev, 0, sizeof(int), h->stream));
     }
+    // pair positions now unless this handle will run the two-phase kernels (then on demand, ensure_pair_pos)
+    if (!(h->path == 1 && two_phase_supported(h.get()))) build_pair_pos(h.get(), p->csr_col);
     init_state(h.get());
     MH_HIP(hipStreamSynchronize(h->stream));
     *out = h.release();

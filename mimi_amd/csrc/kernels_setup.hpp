@@ -265,4 +265,30 @@ __global__ void permuted_window_kernel(SparsityDev S, int64_t n_nodes, const int
   }
 }
 
+// Columns of the permuted structured pattern from the window ranks (the inverse of permuted_window_kernel's check):
+// one wave per lexicographic node A, col[rowptr[perm[A] 3 + i] + 3 rank(t) + j] = perm[B_t] 3 + j.
+__global__ void permuted_col_kernel(SparsityDev S, int64_t n_nodes, const int64_t* __restrict__ perm,
+                                    const int64_t* __restrict__ rowptr, const unsigned char* __restrict__ nbr_pos,
+                                    int32_t* __restrict__ col) {
+  const int lane = threadIdx.x & 63;
+  const int64_t A = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (A >= n_nodes) return;
+  const int Am[3] = {(int)(A % S.n[0]), (int)((A / S.n[0]) % S.n[1]), (int)(A / ((int64_t)S.n[0] * S.n[1]))};
+  int lo[3], w[3];
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = Am[d] - S.p[d] < 0 ? 0 : Am[d] - S.p[d];
+    w[d] = width_1d(Am[d], S.n[d], S.p[d]);
+  }
+  const int nw = w[0] * w[1] * w[2];
+  const int64_t gA = perm[A];
+  for (int t = lane; t < nw; t += 64) {
+    const int t0 = t % w[0], t1 = (t / w[0]) % w[1], t2 = t / (w[0] * w[1]);
+    const int64_t B = (lo[0] + t0) + (int64_t)S.n[0] * ((lo[1] + t1) + (int64_t)S.n[1] * (lo[2] + t2));
+    const int64_t v = perm[B];
+    const int rank = nbr_pos[A * 125 + t];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) col[rowptr[gA * 3 + i] + 3 * rank + j] = (int32_t)(v * 3 + j);
+  }
+}
+
 }  // namespace mimi_hip

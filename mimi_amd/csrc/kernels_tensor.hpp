@@ -786,6 +786,7 @@ inline bool two_phase_supported(const mimi_hip_domain_s* h);                    
 inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a);               // kernels_tensor_wgs.hpp
 inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a);             // kernels_tensor_wgsym.hpp
 inline void launch_tensor_residual(mimi_hip_domain_s* h, TensorArgs a);          // kernels_tensor_residual.hpp
+static void ensure_pair_pos(mimi_hip_domain_s* h);                                // domain.hip
 
 inline void launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, double* r, double* A, double gf) {
   TensorArgs a = tensor_args(h, u, r, A, gf);
@@ -801,8 +802,13 @@ inline void launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, doubl
   }
   else if (!grad && !want_valu && two_phase_supported(h))
     launch_tensor_residual(h, a);
-  else
+  else {
+    if (grad) {
+      ensure_pair_pos(h);       // domain.hip: the colour kernel scatters the tangent through the pair-position table
+      a.pair_pos = h->pair_pos.ptr;
+    }
     launch_tensor_p<2>(h, grad, a);
+  }
 }
 
 inline void launch_tensor_post(mimi_hip_domain_s* h, const double* u) {
