@@ -59,6 +59,7 @@ struct TensorArgs {
   double* scratch_r;         // two-phase path: [n_el][3][27] element residual pieces
   double* scratch_pt;        // two-phase path, J2: [n_el][24][n_q] material results per quadrature point
   const int64_t* perm;       // two-phase path: lexicographic -> caller's node id (nullptr = identity)
+  int cols_per_wg;           // symmetric-half kernel: element columns a workgroup walks back to back
   const unsigned char* nbr_pos;  // two-phase path, permuted numbering: [n_nodes][125] positions inside a CSR row
 };
 

@@ -29,6 +29,11 @@
 
 namespace mimi_hip {
 
+#ifndef WGSYM_MAX_COLS
+#define WGSYM_MAX_COLS 4      // element columns per workgroup at most
+#define WGSYM_MIN_WGS 2048    // ... while at least this many workgroups remain (4 per resident slot)
+#endif
+
 #ifndef WGSYM_DIAG_MODE
 #define WGSYM_DIAG_MODE 2   // 2: contract only the a1 >= b1 chains of a diagonal block; 0: all nine
 #endif
@@ -118,20 +123,26 @@ MH_DEV void wgsym_x_rows(const TensorArgs& p, double* lds, int lane, int64_t e, 
 // wave X, two steps per element
 // ------------------------------------------------------------------------------------------------
 template<int KIND>
-MH_DEV void wgsym_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& status) {
+MH_DEV void wgsym_x_loop(const TensorArgs& p, double* lds, int col0, int n_cols, int& status) {
   using L = WgsymLds;
   constexpr int P = 2, NB = 3, NQ = 4, ND = 27, NQ3 = 64;
   constexpr int TROUNDS = 2;
   const int lane = threadIdx.x & 63;
   double* ue = lds + L::off_ue;
-  const int n_seq = p.box_n[2];
-  auto element_at = [&](int es) -> int64_t { return eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * es); };
-  auto table_src = [&](int es, int t) -> const double* {
+  // the workgroup walks n_cols element columns back to back: sequence index g = column-in-workgroup * nz + ez
+  const int nz = p.box_n[2];
+  const int n_seq = n_cols * nz;
+  auto element_at = [&](int g) -> int64_t {
+    const int col = col0 + g / nz;
+    return col % p.box_n[0] + (int64_t)p.box_n[0] * (col / p.box_n[0] + (int64_t)p.box_n[1] * (g % nz));
+  };
+  auto table_src = [&](int g, int t) -> const double* {
     const int dir = t / (2 * NB * NQ);
     const int rem = t % (2 * NB * NQ);
     const int isD = rem / (NB * NQ);
     const int k = rem % (NB * NQ);
-    const int span = (dir == 0 ? p.box_begin[0] + eu : dir == 1 ? p.box_begin[1] + ev : p.box_begin[2] + es);
+    const int col = col0 + g / nz;
+    const int span = (dir == 0 ? p.box_begin[0] + col % p.box_n[0] : dir == 1 ? p.box_begin[1] + col / p.box_n[0] : p.box_begin[2] + g % nz);
     return (isD ? (dir == 0 ? p.tabD[0] : dir == 1 ? p.tabD[1] : p.tabD[2])
                 : (dir == 0 ? p.tabB[0] : dir == 1 ? p.tabB[1] : p.tabB[2])) + (int64_t)span * NB * NQ + k;
   };
@@ -244,20 +255,24 @@ MH_DEV void wgsym_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& 
 // wave Y_W: diagonal block (W, W) in step D, off-diagonal block (I1, J1) in step O; flushes piece W
 // ------------------------------------------------------------------------------------------------
 template<int W>
-MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
+MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols) {
   using L = WgsymLds;
   constexpr int P = 2, NB = 3, NQ = 4, NB2 = 9, ND = 27, NQ3 = 64, NROW = 81, NK = ND * NROW;
   // step O blocks: Y0 (1,0), Y1 (2,0), Y2 (2,1)
   constexpr int I1 = W == 0 ? 1 : 2, J1 = W == 2 ? 1 : 0;
   const WgsLane lc = wgs_lane_constants();
   const int lane = lc.lane;
-  const int n_seq = p.box_n[2];
+  const int nz = p.box_n[2];
+  const int n_seq = n_cols * nz;   // sequence index g = column-in-workgroup * nz + ez
   const double* AH0 = lds + L::off_ah + L::ah_block(W, W) * NQ3;
   const double* AH1 = lds + L::off_ah + L::ah_block(I1, J1) * NQ3;
   auto st_of = [&](int piece) -> double* { return lds + L::off_st + piece * WgsLds::st_size; };
-  auto piece_of = [&](int es) -> double* {
-    return p.scratch_k + ((eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * es)) * 3 + W) * (int64_t)NK;
+  auto piece_i = [&](int g, int i) -> double* {
+    const int col = col0 + g / nz;
+    const int64_t e = col % p.box_n[0] + (int64_t)p.box_n[0] * (col / p.box_n[0] + (int64_t)p.box_n[1] * (g % nz));
+    return p.scratch_k + (e * 3 + i) * (int64_t)NK;
   };
+  auto piece_of = [&](int g) -> double* { return piece_i(g, W); };
   const int mrow = lane & 15, mk = lane >> 4;
   const bool mrow_ok = mrow < NB2;
   const int mra = mrow_ok ? mrow / NB : 0, mrb = mrow_ok ? mrow % NB : 0;
@@ -318,40 +333,43 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
       wgs_barrier();
       wgs_contract_block<1>(lc, ah, aS0, aS2, uB1, uD1, C1, st_of(I1), J1, st_of(J1), I1);
       wgs_barrier();
+      if (it % nz == nz - 1) {
+        // last element of a column: the carried rows have no successor -- straight from the registers into the third
+        // part of the pieces (no LDS, no lock step) -- and the next column starts with an empty carry
+        wgs_stage_carry<WGSYM_DIAG_MODE>(lc, C0, piece_i(it, W) + WgsLds::n_final, W, piece_i(it, W) + WgsLds::n_final, W);
+        wgs_stage_carry<1>(lc, C1, piece_i(it, I1) + WgsLds::n_final, J1, piece_i(it, J1) + WgsLds::n_final, I1);
+#pragma unroll
+        for (int k = 0; k < NB2; ++k) C0[k] = C1[k] = 0.0;
+      }
     }
   }
-  // ---- after the last element (no more lock steps): its pieces from the buffers, and the carried rows, which
-  // have no successor, straight from the registers into the third part of the pieces ------------------------------
+  // ---- after the last element (no more lock steps): its pieces from the buffers ------------------------------------
   wgs_flush_final(lane, st_of(W), piece_of(n_seq - 1));
-  auto piece_i = [&](int i) -> double* {
-    return p.scratch_k + ((eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * (n_seq - 1))) * 3 + i) * (int64_t)NK + WgsLds::n_final;
-  };
-  wgs_stage_carry<WGSYM_DIAG_MODE>(lc, C0, piece_i(W), W, piece_i(W), W);
-  wgs_stage_carry<1>(lc, C1, piece_i(I1), J1, piece_i(J1), I1);
 }
 
 template<int KIND>
 __global__ __launch_bounds__(256, 2) void tensor_wgsym_kernel(TensorArgs p) {
   extern __shared__ __align__(16) double smem_wgsym[];
   const int role = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) + WGS_ROT(blockIdx.x)) & 3);
-  const int unit = blockIdx.x;
-  const int eu = unit % p.box_n[0], ev = unit / p.box_n[0];
+  const int n_cols_all = p.box_n[0] * p.box_n[1];
+  const int col0 = blockIdx.x * p.cols_per_wg;
+  const int n_cols = n_cols_all - col0 < p.cols_per_wg ? n_cols_all - col0 : p.cols_per_wg;
   // (WGSYM_EXP_SKIP_X / _Y: timing experiments only — the skipped role just keeps the barrier count)
   if (role == 0) {
     int status = 0;
 #ifdef WGSYM_EXP_SKIP_X
-    for (int k = 0; k < 2 * p.box_n[2] + 1; ++k) wgs_barrier();
+    for (int k = 0; k < 2 * n_cols * p.box_n[2] + 1; ++k) wgs_barrier();
 #else
-    wgsym_x_loop<KIND>(p, smem_wgsym, eu, ev, status);
+    wgsym_x_loop<KIND>(p, smem_wgsym, col0, n_cols, status);
 #endif
     if (status) atomicOr(p.status, status);
   } else {
 #ifdef WGSYM_EXP_SKIP_Y
-    for (int k = 0; k < 2 * p.box_n[2] + 1; ++k) wgs_barrier();
+    for (int k = 0; k < 2 * n_cols * p.box_n[2] + 1; ++k) wgs_barrier();
 #else
-    if (role == 1) wgsym_y_loop<0>(p, smem_wgsym, eu, ev);
-    else if (role == 2) wgsym_y_loop<1>(p, smem_wgsym, eu, ev);
-    else wgsym_y_loop<2>(p, smem_wgsym, eu, ev);
+    if (role == 1) wgsym_y_loop<0>(p, smem_wgsym, col0, n_cols);
+    else if (role == 2) wgsym_y_loop<1>(p, smem_wgsym, col0, n_cols);
+    else wgsym_y_loop<2>(p, smem_wgsym, col0, n_cols);
 #endif
   }
 }
@@ -367,7 +385,11 @@ inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a) {
   const size_t lds = WgsymLds::total * sizeof(double);
   auto kernel = tensor_wgsym_kernel<MIMI_HIP_MAT_NEOHOOKEAN>;
   ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
-  hipLaunchKernelGGL(kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
+  // several columns per workgroup (the pipeline of the four waves then runs through the column boundaries: one
+  // prologue per workgroup instead of one per column) as long as the grid still fills the chip several times over
+  const int n_cols_all = a.box_n[0] * a.box_n[1];
+  a.cols_per_wg = n_cols_all / WGSYM_MIN_WGS < 1 ? 1 : (n_cols_all / WGSYM_MIN_WGS > WGSYM_MAX_COLS ? WGSYM_MAX_COLS : n_cols_all / WGSYM_MIN_WGS);
+  hipLaunchKernelGGL(kernel, dim3((n_cols_all + a.cols_per_wg - 1) / a.cols_per_wg), dim3(256), lds, h->stream, a);
   MH_HIP(hipGetLastError());
   launch_tensor_p2(h, a);
 }

@@ -247,6 +247,20 @@ def test_medium_block_parity(matname):
     assert relmax(A_g, A_o) < 1e-11
 
 
+def test_many_columns_per_workgroup():
+    """65 x 65 columns of 2 elements: the symmetric kernel walks two columns per workgroup here (4225 columns, so the
+    last workgroup has only one) -- the column boundary inside a workgroup (carry stored and reset), against the oracle."""
+    P, D, G = make_pair((65, 65, 2), 2, [4.0, 4.0, 1.0], "neohook", "bspline")
+    from oracle import ref_path as rp
+    u = synthetic_u(P, scale=0.005)   # elements are 0.06 wide: larger random displacements nearly invert some of them
+    r_o, A_o = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    r_g, A_g = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    D.add_domain_residual_and_grad(u, 1.0, r_o, A_o, rp.TANGENT_EXACT)
+    G.AddDomainResidualAndGrad(u, 1.0, r_g, A_g)
+    assert relmax(r_g, r_o) < 1e-12
+    assert relmax(A_g, A_o) < 1e-11
+
+
 @pytest.mark.parametrize("n_el", [(1, 1, 1), (2, 1, 3), (1, 3, 1), (1, 1, 4), (3, 1, 2)], ids=lambda n: "x".join(map(str, n)))
 def test_tiny_blocks(n_el):
     """Degenerate sizes of the two-phase kernels: single columns, single elements per column, windows cut on
