@@ -32,7 +32,7 @@
 #define MAXD 3
 #define MAX_TDOF 192 /* 3-D p=3 */
 
-enum { MAT_NEOHOOKEAN = 0, MAT_J2 = 1 };
+enum { MAT_NEOHOOKEAN = 0, MAT_J2 = 1, MAT_STVK = 2, MAT_J2LINEAR = 3, MAT_J2SIMO = 4, MAT_J2LOG = 5 };
 enum { HARD_POWERLAW = 0, HARD_VOCE = 1, HARD_JC = 2, HARD_JC_RATE = 3, HARD_JC_TEMP_RATE = 4,
        HARD_JC_CONST_TEMP = 5 };
 enum { TANGENT_FD = 0, TANGENT_EXACT = 1 };
@@ -50,6 +50,8 @@ typedef struct {
   double A, B, C, eps0_dot;                /* JohnsonCook (+rate) */
   double reference_temperature, m;         /* + temperature */
   double const_temperature_contribution;   /* JohnsonCookConstantTemperature */
+  /* J2Linear (materials.hpp:149-151) */
+  double lin_isotropic_hardening, lin_kinematic_hardening, lin_sigma_y;
 } oracle_material;
 
 typedef struct {
@@ -65,6 +67,9 @@ typedef struct {
   double* eqps;           /* [n_el][n_q] accumulated plastic strain */
   double* temperature;    /* [n_el][n_q] */
   double dt;              /* material_->dt_ (nonlinear_solid.cpp:154,167) */
+  /* the other materials' first state matrix lives in plastic_strain (J2Linear: plastic strain; J2Simo: be_old;
+   * J2Log: Fp_inv), their second one here (J2Linear: beta, J2Simo: F_old)  (materials.hpp:153-161,428-437,576-584) */
+  double* state2;         /* [n_el][n_q][dim*dim] or NULL */
 } oracle_domain;
 
 /* ---- utils/n_thread_exe.hpp:12-26 ---------------------------------------- */
@@ -195,6 +200,7 @@ static double sigma_y_of(const oracle_material* m) {
 typedef struct {
   const oracle_material* m;
   double eqps_old, q, thermo, dt;
+  double slope;   /* 3G (J2, J2Log: materials.hpp:345,622) or G tr(be) (J2Simo: materials.hpp:495) */
 } rm_ctx;
 
 static dual rm_residual(const rm_ctx* c, dual delta) {
@@ -202,8 +208,8 @@ static dual rm_residual(const rm_ctx* c, dual delta) {
   dual H = hardening_evaluate(c->m, e);
   const double fac = rate_contribution(c->m, delta.v / c->dt) * c->thermo;
   dual r;
-  r.v = c->q - 3.0 * c->m->G * delta.v - H.v * fac;
-  r.d = -3.0 * c->m->G * delta.d - H.d * fac;
+  r.v = c->q - c->slope * delta.v - H.v * fac;
+  r.d = -c->slope * delta.d - H.d * fac;
   return r;
 }
 
@@ -332,6 +338,7 @@ static int j2_plastic_stress(const oracle_material* m, int dim, double dt, int a
   c.q = q;
   c.thermo = thermo_contribution(m, *temperature);
   c.dt = dt;
+  c.slope = 3.0 * m->G;
   const double tolerance = sigma_y_of(m) * 1.e-10;
   dual zero = {0.0, 0.0};
   int status = 0;
@@ -373,6 +380,329 @@ static int j2_plastic_stress(const oracle_material* m, int dim, double dt, int a
       }
   }
   return status;
+}
+
+
+/* ---- the other materials ------------------------------------------------------ */
+/* symmetric eigen-decomposition (the reference calls mfem::DenseMatrix::CalcEigenvalues = LAPACK dsyev,
+ * material_utils.hpp:104; materials.hpp:665): cyclic Jacobi, Q columns = eigenvectors */
+static void sym_eig(const double* A, int dim, double* lam, double* Q) {
+  double a[9];
+  for (int i = 0; i < dim * dim; ++i) a[i] = A[i];
+  for (int i = 0; i < dim; ++i)
+    for (int j = 0; j < dim; ++j) M(Q, i, j) = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0, diag = 0;
+    for (int i = 0; i < dim; ++i)
+      for (int j = 0; j < dim; ++j) {
+        if (i != j) off += M(a, i, j) * M(a, i, j);
+        else diag += M(a, i, i) * M(a, i, i);
+      }
+    if (off <= 1e-34 * diag || off == 0.0) break;
+    for (int p = 0; p < dim - 1; ++p)
+      for (int q = p + 1; q < dim; ++q) {
+        const double apq = M(a, p, q);
+        if (apq == 0.0) continue;
+        const double theta = (M(a, q, q) - M(a, p, p)) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < dim; ++k) {   /* a <- a G */
+          const double akp = M(a, k, p), akq = M(a, k, q);
+          M(a, k, p) = c * akp - sn * akq;
+          M(a, k, q) = sn * akp + c * akq;
+        }
+        for (int k = 0; k < dim; ++k) {   /* a <- G^T a */
+          const double apk = M(a, p, k), aqk = M(a, q, k);
+          M(a, p, k) = c * apk - sn * aqk;
+          M(a, q, k) = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < dim; ++k) {
+          const double qkp = M(Q, k, p), qkq = M(Q, k, q);
+          M(Q, k, p) = c * qkp - sn * qkq;
+          M(Q, k, q) = sn * qkp + c * qkq;
+        }
+      }
+  }
+  for (int i = 0; i < dim; ++i) lam[i] = M(a, i, i);
+}
+
+/* out = Q diag(f(lam)) Q^T (mfem::MultADAt), f = log (is_exp 0) or exp (1) */
+static void sym_fun(const double* A, int dim, int is_exp, double* out) {
+  double lam[3], Q[9];
+  sym_eig(A, dim, lam, Q);
+  for (int i = 0; i < dim; ++i) lam[i] = is_exp ? exp(lam[i]) : log(lam[i]);
+  for (int i = 0; i < dim; ++i)
+    for (int j = 0; j < dim; ++j) {
+      double t = 0;
+      for (int k = 0; k < dim; ++k) t += M(Q, i, k) * lam[k] * M(Q, j, k);
+      M(out, i, j) = t;
+    }
+}
+
+static void mat_mul(const double* A, const double* B, int dim, double* C_) { /* C = A B */
+  for (int i = 0; i < dim; ++i)
+    for (int j = 0; j < dim; ++j) {
+      double t = 0;
+      for (int k = 0; k < dim; ++k) t += M(A, i, k) * M(B, k, j);
+      M(C_, i, j) = t;
+    }
+}
+
+static void mat_mul_abt(const double* A, const double* B, int dim, double* C_) { /* C = A B^T */
+  for (int i = 0; i < dim; ++i)
+    for (int j = 0; j < dim; ++j) {
+      double t = 0;
+      for (int k = 0; k < dim; ++k) t += M(A, i, k) * M(B, j, k);
+      M(C_, i, j) = t;
+    }
+}
+
+/* material_utils.hpp:22-56 Dev(A, dim, factor): the trace is divided by dim */
+static void dev_d(const double* A, int dim, double factor, double* out) {
+  double tr = 0;
+  for (int i = 0; i < dim; ++i) tr += M(A, i, i);
+  const double tr_over_dim = tr / (double)dim;
+  for (int i = 0; i < dim * dim; ++i) out[i] = A[i] * factor;
+  for (int i = 0; i < dim; ++i) M(out, i, i) = (M(A, i, i) - tr_over_dim) * factor;
+}
+
+static double norm_d(const double* A, int dim) {
+  double a = 0;
+  for (int i = 0; i < dim * dim; ++i) a += A[i] * A[i];
+  return sqrt(a);
+}
+
+/* polish != 0 (only for the oracle's difference-quotient tangent, never for the restated path): plain Newton steps on
+ * top of ScalarSolve's answer, so that the stress is a smooth function of F to rounding */
+static double polish_root(const rm_ctx* c, double x, double lower, double upper) {
+  for (int it = 0; it < 6; ++it) {
+    dual xx = {x, 1.0};
+    dual R = rm_residual(c, xx);
+    if (R.d == 0.0) break;
+    double xn = x - R.v / R.d;
+    if (xn < lower) xn = lower;
+    if (xn > upper) xn = upper;
+    if (xn == x) break;
+    x = xn;
+  }
+  return x;
+}
+
+/* materials.cpp:72-94 StVenantKirchhoff::EvaluatePK1: S = lambda tr(E) I + 2 mu E, P = F S */
+static void stvk_pk1(const oracle_material* m, int dim, point_work* w) {
+  double C_[9], E[9], S[9];
+  for (int i = 0; i < dim; ++i)
+    for (int j = 0; j < dim; ++j) {
+      double t = 0;
+      for (int k = 0; k < dim; ++k) t += M(w->F, k, i) * M(w->F, k, j);
+      M(C_, i, j) = t;
+    }
+  double tr = 0;
+  for (int i = 0; i < dim; ++i)
+    for (int j = 0; j < dim; ++j) M(E, i, j) = 0.5 * M(C_, i, j) - (i == j ? 0.5 : 0.0);
+  for (int i = 0; i < dim; ++i) tr += M(E, i, i);
+  for (int i = 0; i < dim; ++i)
+    for (int j = 0; j < dim; ++j) M(S, i, j) = 2 * m->mu * M(E, i, j) + (i == j ? m->lambda * tr : 0.0);
+  mat_mul(w->F, S, dim, w->P);
+}
+
+static void pk1_from_sigma(int dim, const double* sigma, point_work* w) {
+  /* materials.cpp:60-71: P = det(F) * sigma * F^-T */
+  for (int i = 0; i < dim; ++i)
+    for (int J = 0; J < dim; ++J) {
+      double t = 0;
+      for (int k = 0; k < dim; ++k) t += M(sigma, i, k) * M(w->Finv, J, k);
+      M(w->P, i, J) = t * w->detF;
+    }
+}
+
+/* materials.hpp:185-236  J2Linear::PlasticStress<accumulate>, then base EvaluatePK1 */
+static int j2linear_stress(const oracle_material* m, int dim, int accumulate, double* plastic_strain, double* beta,
+                           double* eqps, point_work* w) {
+  double eps[9], s[9], eta[9];
+  const int dd = dim * dim;
+  for (int i = 0; i < dim; ++i)
+    for (int j = 0; j < dim; ++j) M(eps, i, j) = 0.5 * (M(w->F, i, j) + M(w->F, j, i));
+  for (int i = 0; i < dim; ++i) M(eps, i, i) -= 1.;
+  for (int i = 0; i < dd; ++i) eps[i] -= plastic_strain[i];
+  double tr = 0;
+  for (int i = 0; i < dim; ++i) tr += M(eps, i, i);
+  const double p = m->K * tr;
+  dev_d(eps, dim, 2.0 * m->G, s);
+  for (int i = 0; i < dd; ++i) eta[i] = s[i] - beta[i];
+  const double eta_norm = norm_d(eta, dim);
+  const double q = sqrt(3.0 / 2.0) * eta_norm;
+  const double phi = q - (m->lin_sigma_y + m->lin_isotropic_hardening * *eqps);
+  if (phi > 0.) {
+    const double inc = phi / (3. * m->G + m->lin_kinematic_hardening + m->lin_isotropic_hardening);
+    for (int i = 0; i < dd; ++i) eta[i] *= 1. / eta_norm;
+    if (!accumulate) {
+      for (int i = 0; i < dd; ++i) s[i] += -sqrt(6.0) * m->G * inc * eta[i];
+    } else {
+      *eqps += inc;
+      for (int i = 0; i < dd; ++i) plastic_strain[i] += sqrt(3.0 / 2.0) * inc * eta[i];
+      for (int i = 0; i < dd; ++i) beta[i] += sqrt(2.0 / 3.0) * m->lin_kinematic_hardening * inc * eta[i];
+    }
+  }
+  if (!accumulate) {
+    double sigma[9];
+    for (int i = 0; i < dd; ++i) sigma[i] = s[i];
+    for (int i = 0; i < dim; ++i) M(sigma, i, i) += p;
+    pk1_from_sigma(dim, sigma, w);
+  }
+  return 0;
+}
+
+/* materials.hpp:452-545  J2Simo::PlasticStress<accumulate> (EvaluatePK1 is overridden: P straight from here) */
+static int j2simo_stress(const oracle_material* m, int dim, double dt, int accumulate, int polish, double* be_old,
+                         double* F_old, double* eqps, double* temperature, point_work* w) {
+  double f_inv[9] = {0}, f_bar[9] = {0}, be[9], fbbo[9], s[9], Np[9];
+  const int dd = dim * dim;
+  int status = 0;
+  mat_mul(F_old, w->Finv, dim, f_inv);
+  inv_d(f_inv, dim, f_bar);
+  {
+    /* materials.hpp:466-469: f_bar *= cbrt(det f_bar) -- multiplied, as written there */
+    const double c = cbrt(det_d(f_bar, dim));
+    for (int i = 0; i < dd; ++i) f_bar[i] *= c;
+  }
+  mat_mul(f_bar, be_old, dim, fbbo);
+  mat_mul_abt(fbbo, f_bar, dim, be);
+  dev_d(be, dim, m->G, s);
+  const double s_norm = norm_d(s, dim);
+  if (fabs(s_norm) < 2.220446049250313e-16) {
+    for (int i = 0; i < dd; ++i) Np[i] = 0.0;
+    for (int i = 0; i < dim; ++i) M(Np, i, i) = sqrt(1. / 2.);
+  } else {
+    for (int i = 0; i < dd; ++i) Np[i] = sqrt(3. / 2.) / s_norm * s[i];
+  }
+  double s_effective = 0;
+  for (int i = 0; i < dd; ++i) s_effective += Np[i] * s[i];
+  double be_trace = 0;
+  for (int i = 0; i < dim; ++i) be_trace += M(be, i, i);
+
+  rm_ctx c;
+  c.m = m;
+  c.eqps_old = *eqps;
+  c.q = s_effective;
+  c.thermo = thermo_contribution(m, *temperature);
+  c.dt = dt;
+  c.slope = m->G * be_trace;
+  const double tolerance = sigma_y_of(m) * 1.e-10;
+  dual zero = {0.0, 0.0};
+  if (rm_residual(&c, zero).v > tolerance) {
+    dual e0 = {c.eqps_old, 0.0};
+    const double upper = (s_effective - hardening_evaluate(m, e0).v * c.thermo) / (m->G * be_trace);
+    double delta = scalar_solve(&c, 0.0, 0.0, upper, 1.e-10, tolerance, 100, &status);
+    if (polish) delta = polish_root(&c, delta, 0.0, upper);
+    for (int i = 0; i < dd; ++i) be[i] += -2. / 3. * delta * be_trace * Np[i];
+    dev_d(be, dim, m->G, s);
+    if (accumulate) {
+      *eqps += delta;
+      if (m->hard_kind == HARD_JC_TEMP_RATE)
+        *temperature += m->heat_fraction * s_effective * delta / (m->density * m->specific_heat);
+    }
+  }
+  if (!accumulate) {
+    double tau[9];
+    for (int i = 0; i < dd; ++i) tau[i] = s[i];
+    for (int i = 0; i < dim; ++i) M(tau, i, i) += m->K * (w->detF * w->detF - 1.) * .5;
+    mat_mul_abt(tau, w->Finv, dim, w->P);
+  } else {
+    memcpy(F_old, w->F, sizeof(double) * dd);
+    memcpy(be_old, be, sizeof(double) * dd);
+  }
+  return status;
+}
+
+/* materials.hpp:592-713  J2Log::PlasticStress<accumulate> under the base EvaluatePK1 (materials.cpp:60-71), which
+ * takes alternative_stress_ = s + (p / det F) I as the Cauchy stress and overwrites what PlasticStress left in
+ * tmp.stress_:  P = det F (s + p/det F I) F^-T.  (The golden series j2_log_h1_p2 is reproduced by exactly this.) */
+static int j2log_stress(const oracle_material* m, int dim, double dt, int accumulate, int polish, double* Fp_inv,
+                        double* eqps, double* temperature, point_work* w) {
+  double F_e[9], C_e[9], E_e[9], s[9], Np[9];
+  const int dd = dim * dim;
+  int status = 0;
+  mat_mul(w->F, Fp_inv, dim, F_e);
+  for (int i = 0; i < dim; ++i)
+    for (int j = 0; j < dim; ++j) {
+      double t = 0;
+      for (int k = 0; k < dim; ++k) t += M(F_e, k, i) * M(F_e, k, j);
+      M(C_e, i, j) = t;
+    }
+  sym_fun(C_e, dim, 0, E_e);   /* material_utils.hpp:91-114 LogarithmicStrain */
+  for (int i = 0; i < dd; ++i) E_e[i] *= 0.5;
+  double tr = 0;
+  for (int i = 0; i < dim; ++i) tr += M(E_e, i, i);
+  const double p = m->K * tr;
+  dev_d(E_e, dim, 2.0 * m->G, s);
+  const double q = sqrt(1.5) * norm_d(s, dim);
+
+  rm_ctx c;
+  c.m = m;
+  c.eqps_old = *eqps;
+  c.q = q;
+  c.thermo = thermo_contribution(m, *temperature);
+  c.dt = dt;
+  c.slope = 3.0 * m->G;
+  const double tolerance = sigma_y_of(m) * 1.e-10;
+  dual zero = {0.0, 0.0};
+  if (rm_residual(&c, zero).v > tolerance) {
+    dual e0 = {c.eqps_old, 0.0};
+    const double upper = (q - hardening_evaluate(m, e0).v * c.thermo) / (3.0 * m->G);
+    double delta = scalar_solve(&c, 0.0, 0.0, upper, 1.e-10, tolerance, 100, &status);
+    if (polish) delta = polish_root(&c, delta, 0.0, upper);
+    for (int i = 0; i < dd; ++i) Np[i] = 1.5 / q * s[i];
+    for (int i = 0; i < dd; ++i) s[i] += -2.0 * m->G * delta * Np[i];
+    if (accumulate) {
+      double inc[9], ex[9], old[9];
+      for (int i = 0; i < dd; ++i) inc[i] = -delta * Np[i];
+      sym_fun(inc, dim, 1, ex);
+      *eqps += delta;
+      memcpy(old, Fp_inv, sizeof(double) * dd);
+      mat_mul(old, ex, dim, Fp_inv);
+    }
+  }
+  if (!accumulate) {
+    double alt[9];
+    for (int i = 0; i < dd; ++i) alt[i] = s[i];
+    for (int i = 0; i < dim; ++i) M(alt, i, i) += p / w->detF;
+    pk1_from_sigma(dim, alt, w);
+  }
+  return status;
+}
+
+/* one dispatcher for the stateful extras; state pointers address ONE quadrature point */
+static int other_material_stress(const oracle_material* m, int dim, double dt, int accumulate, int polish,
+                                 double* mat1, double* mat2, double* eqps, double* temperature, point_work* w) {
+  switch (m->kind) {
+  case MAT_STVK: if (!accumulate) stvk_pk1(m, dim, w); return 0;
+  case MAT_J2LINEAR: return j2linear_stress(m, dim, accumulate, mat1, mat2, eqps, w);
+  case MAT_J2SIMO: return j2simo_stress(m, dim, dt, accumulate, polish, mat1, mat2, eqps, temperature, w);
+  default: return j2log_stress(m, dim, dt, accumulate, polish, mat1, eqps, temperature, w);
+  }
+}
+
+/* tangent of those materials for the oracle's TANGENT_EXACT mode: central difference quotient of P(F) at the POINT
+ * (step 1e-6, polished return map) -- about 1e-10 relative; not in the reference */
+static void difference_tangent(const oracle_material* m, int dim, double dt, double* mat1, double* mat2, double* eqps,
+                               double* temperature, const point_work* w0, double* A) {
+  const double h = 1.0e-6;
+  for (int j = 0; j < dim; ++j)
+    for (int L = 0; L < dim; ++L) {
+      point_work wp = *w0, wm = *w0;
+      M(wp.F, j, L) += h;
+      M(wm.F, j, L) -= h;
+      wp.detF = det_d(wp.F, dim);
+      inv_d(wp.F, dim, wp.Finv);
+      wm.detF = det_d(wm.F, dim);
+      inv_d(wm.F, dim, wm.Finv);
+      other_material_stress(m, dim, dt, 0, 1, mat1, mat2, eqps, temperature, &wp);
+      other_material_stress(m, dim, dt, 0, 1, mat1, mat2, eqps, temperature, &wm);
+      for (int i = 0; i < dim; ++i)
+        for (int Jx = 0; Jx < dim; ++Jx)
+          A[((i * dim + Jx) * dim + j) * dim + L] = (M(wp.P, i, Jx) - M(wm.P, i, Jx)) / (2.0 * h);
+    }
 }
 
 /* dP_iJ/dF_jL, exact, stored A[((i*dim+J)*dim+j)*dim+L]  (not in the reference: the
@@ -441,8 +771,22 @@ static int evaluate_pk1(const oracle_domain* D, int e, int q, point_work* w) {
     return 0;
   }
   const long pt = (long)e * D->n_q + q;
+  const int dd = D->dim * D->dim;
+  if (D->mat.kind != MAT_J2)
+    return other_material_stress(&D->mat, D->dim, D->dt, 0, 0, D->plastic_strain + pt * dd,
+                                 D->state2 ? D->state2 + pt * dd : NULL, D->eqps + pt, D->temperature + pt, w);
   return j2_plastic_stress(&D->mat, D->dim, D->dt, 0, D->plastic_strain + pt * D->dim * D->dim,
                            D->eqps + pt, D->temperature + pt, w);
+}
+
+static void point_tangent(const oracle_domain* D, long pt, const point_work* w, double* A) {
+  const int dd = D->dim * D->dim;
+  if (D->mat.kind == MAT_NEOHOOKEAN || D->mat.kind == MAT_J2) {
+    exact_tangent(&D->mat, D->dim, w, A);
+    return;
+  }
+  difference_tangent(&D->mat, D->dim, D->dt, D->plastic_strain + pt * dd, D->state2 ? D->state2 + pt * dd : NULL,
+                     D->eqps + pt, D->temperature + pt, w, A);
 }
 
 /* nonlinear_solid.hpp:65-87  ElementResidual<false>:
@@ -501,7 +845,7 @@ static int element_residual_and_grad_exact(const oracle_domain* D, int e, const 
     double A[81];
     compute_F(dim, n_dof, x_e, dNdX, &w);
     status |= evaluate_pk1(D, e, q, &w);
-    exact_tangent(&D->mat, dim, &w, A);
+    point_tangent(D, pt, &w, A);
     const double wd = D->weight[pt] * D->det[pt];
     for (int i = 0; i < dim; ++i)
       for (int J = 0; J < dim; ++J) {
@@ -637,7 +981,7 @@ int oracle_add_domain_residual_and_grad(const oracle_domain* D, const double* u,
 /* nonlinear_solid.cpp:179-199 DomainPostTimeAdvance -> ElementResidual<true> ->
  * J2::Accumulate (materials.hpp:399-402) */
 int oracle_domain_post_time_advance(const oracle_domain* D, const double* u, int n_threads) {
-  if (D->mat.kind != MAT_J2) return 0;
+  if (D->mat.kind == MAT_NEOHOOKEAN || D->mat.kind == MAT_STVK) return 0;
   const int dim = D->dim, n_dof = D->n_dof, n_tdof = n_dof * dim;
   if (n_threads < 1) n_threads = 1;
   if (n_threads > D->n_el) n_threads = D->n_el;
@@ -654,8 +998,13 @@ int oracle_domain_post_time_advance(const oracle_domain* D, const double* u, int
         const long pt = e * D->n_q + q;
         point_work w;
         compute_F(dim, n_dof, x_e, D->dN_dX + pt * n_dof * dim, &w);
-        status |= j2_plastic_stress(&D->mat, dim, D->dt, 1, D->plastic_strain + pt * dim * dim,
-                                    D->eqps + pt, D->temperature + pt, &w);
+        if (D->mat.kind == MAT_J2)
+          status |= j2_plastic_stress(&D->mat, dim, D->dt, 1, D->plastic_strain + pt * dim * dim,
+                                      D->eqps + pt, D->temperature + pt, &w);
+        else
+          status |= other_material_stress(&D->mat, dim, D->dt, 1, 0, D->plastic_strain + pt * dim * dim,
+                                          D->state2 ? D->state2 + pt * dim * dim : NULL, D->eqps + pt,
+                                          D->temperature + pt, &w);
       }
     }
   }
@@ -665,7 +1014,7 @@ int oracle_domain_post_time_advance(const oracle_domain* D, const double* u, int
 /* point-level entry for tests: F (column-major dim x dim) -> P and exact dP/dF */
 int oracle_point_pk1(const oracle_material* m, int dim, double dt, const double* F,
                      const double* plastic_strain, double eqps, double temperature, double* P,
-                     double* A) {
+                     double* A, const double* state2) {
   point_work w;
   memcpy(w.F, F, sizeof(double) * dim * dim);
   w.detF = det_d(w.F, dim);
@@ -673,6 +1022,14 @@ int oracle_point_pk1(const oracle_material* m, int dim, double dt, const double*
   int status = 0;
   if (m->kind == MAT_NEOHOOKEAN) {
     neo_hookean_pk1(m, dim, &w);
+  } else if (m->kind != MAT_J2) {
+    double m1[9] = {0}, m2[9] = {0};
+    if (plastic_strain) memcpy(m1, plastic_strain, sizeof(double) * dim * dim);
+    if (state2) memcpy(m2, state2, sizeof(double) * dim * dim);
+    status = other_material_stress(m, dim, dt, 0, 0, m1, m2, &eqps, &temperature, &w);
+    memcpy(P, w.P, sizeof(double) * dim * dim);
+    if (A) difference_tangent(m, dim, dt, m1, m2, &eqps, &temperature, &w, A);
+    return status;
   } else {
     double ps[9];
     memcpy(ps, plastic_strain, sizeof(double) * dim * dim);

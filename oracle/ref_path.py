@@ -15,7 +15,8 @@ from . import iga
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "_build", "liboracle_ref.so")
 
-MAT_NEOHOOKEAN, MAT_J2 = 0, 1
+MAT_NEOHOOKEAN, MAT_J2, MAT_STVK, MAT_J2LINEAR, MAT_J2SIMO, MAT_J2LOG = 0, 1, 2, 3, 4, 5
+MAT_KINDS = dict(neohookean=0, j2=1, stvk=2, j2linear=3, j2simo=4, j2log=5)
 HARD = dict(PowerLaw=0, Voce=1, JohnsonCook=2, JohnsonCookRate=3, JohnsonCookTempRate=4,
             JohnsonCookConstTemp=5)
 TANGENT_FD, TANGENT_EXACT = 0, 1
@@ -43,7 +44,9 @@ class _Material(C.Structure):
                 ("sigma_sat", C.c_double), ("strain_constant", C.c_double),
                 ("A", C.c_double), ("B", C.c_double), ("C", C.c_double), ("eps0_dot", C.c_double),
                 ("reference_temperature", C.c_double), ("m", C.c_double),
-                ("const_temperature_contribution", C.c_double)]
+                ("const_temperature_contribution", C.c_double),
+                ("lin_isotropic_hardening", C.c_double), ("lin_kinematic_hardening", C.c_double),
+                ("lin_sigma_y", C.c_double)]
 
 
 class _Domain(C.Structure):
@@ -53,7 +56,7 @@ class _Domain(C.Structure):
                 ("weight", C.c_void_p), ("det", C.c_void_p),
                 ("mat", _Material),
                 ("plastic_strain", C.c_void_p), ("eqps", C.c_void_p), ("temperature", C.c_void_p),
-                ("dt", C.c_double)]
+                ("dt", C.c_double), ("state2", C.c_void_p)]
 
 
 class _Contact(C.Structure):
@@ -88,11 +91,14 @@ def lame(young, poisson):
 
 
 def make_material(kind, young, poisson, density=1.0, hardening=None, heat_fraction=0.9,
-                  specific_heat=450.0, initial_temperature=20.0, melting_temperature=1500.0):
-    """kind: 'neohookean' | 'j2'.  hardening: dict(kind=..., A=..., ...)."""
+                  specific_heat=450.0, initial_temperature=20.0, melting_temperature=1500.0,
+                  isotropic_hardening=0.0, kinematic_hardening=0.0, sigma_y=0.0):
+    """kind: 'neohookean' | 'j2' | 'stvk' | 'j2linear' | 'j2simo' | 'j2log'.  hardening: dict(kind=..., A=..., ...);
+    isotropic_hardening / kinematic_hardening / sigma_y: J2Linear only."""
     m = _Material()
     lam, mu, K, G = lame(young, poisson)
-    m.kind = MAT_NEOHOOKEAN if kind == "neohookean" else MAT_J2
+    m.kind = MAT_KINDS[kind]
+    m.lin_isotropic_hardening, m.lin_kinematic_hardening, m.lin_sigma_y = isotropic_hardening, kinematic_hardening, sigma_y
     m.density, m.lambda_, m.mu, m.K, m.G = density, lam, mu, K, G
     m.heat_fraction, m.specific_heat = heat_fraction, specific_heat
     m.initial_temperature, m.melting_temperature = initial_temperature, melting_temperature
@@ -143,6 +149,13 @@ class DomainOracle:
         ne, nq = self.weight.shape
         dim = patch.dim
         self.plastic_strain = np.zeros((ne, nq, dim * dim))
+        self.state2 = np.zeros((ne, nq, dim * dim))
+        eye = np.eye(dim).ravel()
+        if material.kind == MAT_J2SIMO:      # materials.cpp:199-200: be_old = F_old = I
+            self.plastic_strain[:] = eye
+            self.state2[:] = eye
+        elif material.kind == MAT_J2LOG:     # materials.cpp:244: Fp_inv = I
+            self.plastic_strain[:] = eye
         self.eqps = np.zeros((ne, nq))
         self.temperature = np.full((ne, nq), material.initial_temperature)
         d = _Domain()
@@ -152,9 +165,10 @@ class DomainOracle:
         d.mat = material
         d.plastic_strain, d.eqps, d.temperature = map(_ptr, (self.plastic_strain, self.eqps, self.temperature))
         d.dt = 0.0
+        d.state2 = _ptr(self.state2)
         self.d = d
         self.material = material
-        self.has_states = material.kind == MAT_J2
+        self.has_states = material.kind not in (MAT_NEOHOOKEAN, MAT_STVK)
 
     def set_dt(self, dt):
         self.d.dt = float(dt)
@@ -191,15 +205,17 @@ class DomainOracle:
         return R, K.reshape(nt, nt).T.copy()   # K[r, c]
 
 
-def point_pk1(material, F, dt=1.0, plastic_strain=None, eqps=0.0, temperature=20.0):
-    """(P, A) at one point; F, P row-major [i, J]; A[i, J, j, L] = dP_iJ/dF_jL."""
+def point_pk1(material, F, dt=1.0, plastic_strain=None, eqps=0.0, temperature=20.0, state2=None):
+    """(P, A) at one point; F, P row-major [i, J]; A[i, J, j, L] = dP_iJ/dF_jL.  plastic_strain / state2: the
+    material's first / second state matrix (row-major), see oracle_domain in ref_path.c."""
     dim = F.shape[0]
     Fc = np.ascontiguousarray(F.T)            # column-major storage
     ps = np.zeros(dim * dim) if plastic_strain is None else np.ascontiguousarray(plastic_strain.T).ravel()
+    s2 = np.zeros(dim * dim) if state2 is None else np.ascontiguousarray(state2.T).ravel()
     P = np.zeros(dim * dim)
     A = np.zeros(dim ** 4)
     st = lib().oracle_point_pk1(C.byref(material), dim, C.c_double(dt), _ptr(Fc), _ptr(ps),
-                                C.c_double(eqps), C.c_double(temperature), _ptr(P), _ptr(A))
+                                C.c_double(eqps), C.c_double(temperature), _ptr(P), _ptr(A), _ptr(s2))
     if st:
         raise RuntimeError("ScalarSolve failed")
     return P.reshape(dim, dim).T.copy(), A.reshape(dim, dim, dim, dim)

@@ -10,7 +10,13 @@ def oracle_material(name):
     from oracle import ref_path as rp
     if name == "neohook":
         return rp.make_material("neohookean", 2100, 0.3, density=1.0)
-    return rp.make_material("j2", 2100, 0.3, density=1.0, hardening=JC_TEST, heat_fraction=0.9,
+    if name == "stvk":
+        return rp.make_material("stvk", 2100, 0.3, density=1.0)
+    if name == "j2linear":
+        return rp.make_material("j2linear", 2100, 0.3, density=1.0, isotropic_hardening=40.0, kinematic_hardening=25.0,
+                                sigma_y=70.0)
+    kind = {"j2": "j2", "j2simo": "j2simo", "j2log": "j2log"}[name]
+    return rp.make_material(kind, 2100, 0.3, density=1.0, hardening=JC_TEST, heat_fraction=0.9,
                             specific_heat=450, initial_temperature=20, melting_temperature=1500)
 
 
