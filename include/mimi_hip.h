@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MIMI_HIP_ABI_VERSION 1
+#define MIMI_HIP_ABI_VERSION 2
 
 /* ---- errors ---------------------------------------------------------------- */
 const char* mimi_hip_last_error(void);
@@ -44,7 +44,11 @@ int mimi_hip_device_count(void);
 /* ---- materials (materials/materials.hpp, materials/material_hardening.hpp) -- */
 enum mimi_hip_material_kind {
   MIMI_HIP_MAT_NEOHOOKEAN = 0, /* CompressibleOgdenNeoHookean  materials.hpp:118-140, materials.cpp:96-118 */
-  MIMI_HIP_MAT_J2 = 1          /* J2 (small strain, nonlinear isotropic hardening) materials.hpp:259-403 */
+  MIMI_HIP_MAT_J2 = 1,         /* J2 (small strain, nonlinear isotropic hardening) materials.hpp:259-403 */
+  MIMI_HIP_MAT_STVK = 2,       /* StVenantKirchhoff  materials.hpp:88-111, materials.cpp:72-94 */
+  MIMI_HIP_MAT_J2LINEAR = 3,   /* J2Linear (linear isotropic + kinematic hardening)  materials.hpp:142-249 */
+  MIMI_HIP_MAT_J2SIMO = 4,     /* J2Simo (finite strain, be / F_old state)  materials.hpp:406-557 */
+  MIMI_HIP_MAT_J2LOG = 5       /* J2Log (logarithmic strain, Fp_inv state)  materials.hpp:559-753 */
 };
 
 enum mimi_hip_hardening_kind {
@@ -68,6 +72,8 @@ typedef struct mimi_hip_material {
   double sigma_sat, strain_constant;        /* Voce */
   double A, B, C, eps0_dot;                 /* JohnsonCook: A + B eqps^n, rate term 1 + C ln(rate/eps0_dot) */
   double reference_temperature, m;          /* thermal softening exponent m */
+  /* J2Linear (materials.hpp:149-151); its yield stress sigma_y_ is the field sigma_y above */
+  double lin_isotropic_hardening, lin_kinematic_hardening;
 } mimi_hip_material;
 
 /* MaterialBase::SetYoungPoisson (materials.cpp:7-14) */

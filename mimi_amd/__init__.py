@@ -2,7 +2,7 @@
 solids.  The compute path is libmimi_hip.so (hand-written HIP for gfx950, C ABI in
 include/mimi_hip.h); this package is the host-side mirror of the reference's operator
 surface.  There is no CPU fallback."""
-from .materials import (CompressibleOgdenNeoHookean, J2, Material, HardeningBase, PowerLawHardening,
+from .materials import (CompressibleOgdenNeoHookean, J2, StVenantKirchhoff, J2Linear, J2Simo, J2Log, Material, HardeningBase, PowerLawHardening,
                         VoceHardening, JohnsonCookHardening, JohnsonCookRateDependentHardening,
                         JohnsonCookTemperatureAndRateDependentHardening,
                         JohnsonCookConstantTemperatureHardening)

@@ -20,7 +20,8 @@ class Material(C.Structure):
                 ("sigma_y", C.c_double), ("n", C.c_double), ("eps0", C.c_double),
                 ("sigma_sat", C.c_double), ("strain_constant", C.c_double),
                 ("A", C.c_double), ("B", C.c_double), ("C", C.c_double), ("eps0_dot", C.c_double),
-                ("reference_temperature", C.c_double), ("m", C.c_double)]
+                ("reference_temperature", C.c_double), ("m", C.c_double),
+                ("lin_isotropic_hardening", C.c_double), ("lin_kinematic_hardening", C.c_double)]
 
 
 class DomainTables(C.Structure):

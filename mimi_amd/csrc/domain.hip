@@ -27,9 +27,9 @@ MaterialDev make_material_dev(const mimi_hip_material& m) {
   MaterialDev d{};
   d.m = m;
   d.const_temperature_contribution = 1.0;
-  if (m.kind == MIMI_HIP_MAT_J2) {
+  if (m.kind == MIMI_HIP_MAT_J2 || m.kind == MIMI_HIP_MAT_J2SIMO || m.kind == MIMI_HIP_MAT_J2LOG) {
     if (m.hardening < MIMI_HIP_HARD_POWERLAW || m.hardening > MIMI_HIP_HARD_JC_CONST_TEMP)
-      fail("hardening missing for J2");  // materials.cpp:139-148
+      fail("hardening missing for J2 / J2Simo / J2Log");  // materials.cpp:139-148,177-183,217-223
     d.sigma_y_ref = (m.hardening == MIMI_HIP_HARD_POWERLAW || m.hardening == MIMI_HIP_HARD_VOCE) ? m.sigma_y : m.A;
     if (m.hardening >= MIMI_HIP_HARD_JC_TEMP_RATE && m.reference_temperature > m.melting_temperature)
       fail("reference temperature, %g ,can't be bigger than melting temperature, %g .",
@@ -41,7 +41,9 @@ MaterialDev make_material_dev(const mimi_hip_material& m) {
       if (d.const_temperature_contribution <= 0.0)
         fail("Invalid temperature contribution %g", d.const_temperature_contribution);
     }
-  } else if (m.kind != MIMI_HIP_MAT_NEOHOOKEAN) {
+  } else if (m.kind == MIMI_HIP_MAT_J2LINEAR) {
+    d.sigma_y_ref = m.sigma_y;
+  } else if (m.kind != MIMI_HIP_MAT_NEOHOOKEAN && m.kind != MIMI_HIP_MAT_STVK) {
     fail("unknown material kind %d", m.kind);
   }
   return d;
@@ -91,17 +93,39 @@ static void init_common(mimi_hip_domain_s* h, int device, const mimi_hip_materia
   *h->status_host = 0;
 }
 
+static bool material_has_state(int kind) { return kind != MIMI_HIP_MAT_NEOHOOKEAN && kind != MIMI_HIP_MAT_STVK; }
+// the tensor-product kernels carry closed-form tangents of the two benchmarked materials only
+static bool material_on_tensor_path(int kind) { return kind == MIMI_HIP_MAT_NEOHOOKEAN || kind == MIMI_HIP_MAT_J2; }
+
 static void init_state(mimi_hip_domain_s* h) {
   h->n_pts = (int64_t)h->n_el * h->n_q;
-  if (h->mat.m.kind != MIMI_HIP_MAT_J2) return;
-  // J2::CreateState (materials.cpp:151-166): zero plastic strain / eqps, T = initial
+  const int kind = h->mat.m.kind;
+  if (!material_has_state(kind)) return;
+  // CreateState (materials.cpp:120-133 J2Linear, 151-166 J2, 185-208 J2Simo, 225-252 J2Log): zero matrices / eqps,
+  // T = initial; J2Simo: be_old = F_old = I; J2Log: Fp_inv = I
+  const int dd = h->dim * h->dim;
   h->eqps.resize(h->n_pts);
   h->temperature.resize(h->n_pts);
-  h->plastic_strain.resize(h->n_pts * h->dim * h->dim);
+  h->plastic_strain.resize(h->n_pts * dd);
   MH_HIP(hipMemsetAsync(h->eqps.ptr, 0, h->n_pts * sizeof(double), h->stream));
-  MH_HIP(hipMemsetAsync(h->plastic_strain.ptr, 0, h->n_pts * h->dim * h->dim * sizeof(double), h->stream));
-  std::vector<double> T(h->n_pts, h->mat.m.initial_temperature);
+  MH_HIP(hipMemsetAsync(h->plastic_strain.ptr, 0, h->n_pts * dd * sizeof(double), h->stream));
+  const bool two = kind == MIMI_HIP_MAT_J2LINEAR || kind == MIMI_HIP_MAT_J2SIMO;
+  if (two) {
+    h->state2.resize(h->n_pts * dd);
+    MH_HIP(hipMemsetAsync(h->state2.ptr, 0, h->n_pts * dd * sizeof(double), h->stream));
+  }
+  std::vector<double> T(h->n_pts, kind == MIMI_HIP_MAT_J2LINEAR ? 0.0 : h->mat.m.initial_temperature);
   MH_HIP(hipMemcpyAsync(h->temperature.ptr, T.data(), h->n_pts * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (kind == MIMI_HIP_MAT_J2SIMO || kind == MIMI_HIP_MAT_J2LOG) {
+    std::vector<double> ones(h->n_pts, 1.0);
+    for (int i = 0; i < h->dim; ++i) {
+      const size_t c = (size_t)i * (h->dim + 1);   // diagonal component of the SoA [component][point] layout
+      MH_HIP(hipMemcpyAsync(h->plastic_strain.ptr + c * h->n_pts, ones.data(), h->n_pts * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      if (kind == MIMI_HIP_MAT_J2SIMO)
+        MH_HIP(hipMemcpyAsync(h->state2.ptr + c * h->n_pts, ones.data(), h->n_pts * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    MH_HIP(hipStreamSynchronize(h->stream));
+  }
   MH_HIP(hipStreamSynchronize(h->stream));
 }
 
@@ -225,7 +249,7 @@ static GeneralArgs general_args(mimi_hip_domain_s* h, const double* u, double* r
   a.grad_factor = gf;
   a.dt = h->dt;
   a.mat = h->mat;
-  a.state = StateView{h->eqps.ptr, h->temperature.ptr, h->plastic_strain.ptr, h->n_pts};
+  a.state = StateView{h->eqps.ptr, h->temperature.ptr, h->plastic_strain.ptr, h->n_pts, h->state2.ptr};
   a.status = h->status_dev;
   return a;
 }
@@ -244,6 +268,14 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a)
     hipLaunchKernelGGL(kernel, dim3(h->n_el), dim3(threads), lds, h->stream, a);
     MH_HIP(hipGetLastError());
   };
+  if (!material_on_tensor_path(h->mat.m.kind)) {
+    // the other materials: same kernel, stress and tangent from materials_other.hpp
+    if (grad == 0) go(domain_general_kernel<DIM, 0, 3, 256, 1>);
+    else if (grad == 1 && h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, GEN_BIG_PP, GEN_BIG_THREADS, 1>, GEN_BIG_THREADS);
+    else if (grad == 1) go(domain_general_kernel<DIM, 1, 3, 256, 1>);
+    else go(domain_general_kernel<DIM, 2, 3, 256, 1>);
+    return;
+  }
   if (grad == 0) go(domain_general_kernel<DIM, 0>);
   else if (grad == 1 && h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, GEN_BIG_PP, GEN_BIG_THREADS>, GEN_BIG_THREADS);
   else if (grad == 1) go(domain_general_kernel<DIM, 1, 3>);
@@ -416,7 +448,7 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
     const char* keep_env = getenv("MIMI_HIP_KEEP_GENERAL");
     const char* path_env = getenv("MIMI_HIP_FORCE_GENERAL");
     const bool force_general = path_env && path_env[0] == '1';
-    const bool tensor_ok = tensor_supported(dim, h->degree, nq);
+    const bool tensor_ok = tensor_supported(dim, h->degree, nq) && material_on_tensor_path(h->mat.m.kind);
     const bool keep_general = force_general || !tensor_ok || (keep_env && keep_env[0] == '1');
     h->path = (tensor_ok && !force_general) ? 1 : 0;
     h->dofs.resize((size_t)h->n_el * h->n_dof);
@@ -572,7 +604,7 @@ int mimi_hip_domain_add_residual_and_grad(mimi_hip_domain_t h, const double* u, 
 int mimi_hip_domain_post_time_advance(mimi_hip_domain_t h, const double* u) {
   return guarded([&] {
     if (!h) fail("null handle");
-    if (h->mat.m.kind != MIMI_HIP_MAT_J2) return;  // has_states_ == false (nonlinear_solid.cpp:182-183)
+    if (!material_has_state(h->mat.m.kind)) return;  // has_states_ == false (nonlinear_solid.cpp:182-183)
     MH_HIP(hipSetDevice(h->device));
     Mirror<double> mu = Mirror<double>::in(u, h->n_vdofs, h->stage_u, h->stream);
     if (h->path == 1) {
@@ -581,10 +613,11 @@ int mimi_hip_domain_post_time_advance(mimi_hip_domain_t h, const double* u) {
       ensure_general_tables(h);
       GeneralArgs a = general_args(h, mu.dev, nullptr, nullptr, 0.0);
       const size_t lds = (size_t)h->n_dof * h->dim * sizeof(double);
-      if (h->dim == 2)
-        hipLaunchKernelGGL(post_time_advance_general_kernel<2>, dim3(h->n_el), dim3(256), lds, h->stream, a);
-      else
-        hipLaunchKernelGGL(post_time_advance_general_kernel<3>, dim3(h->n_el), dim3(256), lds, h->stream, a);
+      const bool other = !material_on_tensor_path(h->mat.m.kind);
+      void (*kernel)(GeneralArgs) =
+          h->dim == 2 ? (other ? post_time_advance_general_kernel<2, 1> : post_time_advance_general_kernel<2, 0>)
+                      : (other ? post_time_advance_general_kernel<3, 1> : post_time_advance_general_kernel<3, 0>);
+      hipLaunchKernelGGL(kernel, dim3(h->n_el), dim3(256), lds, h->stream, a);
       MH_HIP(hipGetLastError());
     }
     if (mu.host) check_status(h);
@@ -595,18 +628,19 @@ int mimi_hip_domain_get_state(mimi_hip_domain_t h, int what, double* out, int64_
   return guarded([&] {
     if (!h || !out) fail("null argument");
     MH_HIP(hipSetDevice(h->device));
-    if (h->mat.m.kind != MIMI_HIP_MAT_J2) fail("material has no state");
+    if (!material_has_state(h->mat.m.kind)) fail("material has no state");
     const int dd = h->dim * h->dim;
-    const int64_t need = what == 2 ? h->n_pts * dd : h->n_pts;
+    const int64_t need = (what == 2 || what == 3) ? h->n_pts * dd : h->n_pts;
     if (capacity < need) fail("state buffer too small (%lld < %lld)", (long long)capacity, (long long)need);
     MH_HIP(hipStreamSynchronize(h->stream));
     if (what == 0) {
       MH_HIP(hipMemcpy(out, h->eqps.ptr, need * sizeof(double), hipMemcpyDeviceToHost));
     } else if (what == 1) {
       MH_HIP(hipMemcpy(out, h->temperature.ptr, need * sizeof(double), hipMemcpyDeviceToHost));
-    } else if (what == 2) {
+    } else if (what == 2 || what == 3) {
+      if (what == 3 && !h->state2.ptr) fail("material has no second state matrix");
       std::vector<double> soa(need);
-      MH_HIP(hipMemcpy(soa.data(), h->plastic_strain.ptr, need * sizeof(double), hipMemcpyDeviceToHost));
+      MH_HIP(hipMemcpy(soa.data(), what == 2 ? h->plastic_strain.ptr : h->state2.ptr, need * sizeof(double), hipMemcpyDeviceToHost));
       for (int64_t pt = 0; pt < h->n_pts; ++pt)
         for (int c = 0; c < dd; ++c) out[pt * dd + c] = soa[(int64_t)c * h->n_pts + pt];
     } else {

@@ -39,7 +39,7 @@ struct mimi_hip_domain_s {
   mimi_hip::DeviceBuffer<double> scratch_k, scratch_r, scratch_pt;  // two-phase tangent path
 
   // J2 state, SoA over points
-  mimi_hip::DeviceBuffer<double> eqps, temperature, plastic_strain;
+  mimi_hip::DeviceBuffer<double> eqps, temperature, plastic_strain, state2;
 
   // status word raised by kernels (ScalarSolve failures, bad pattern)
   int* status_dev = nullptr;

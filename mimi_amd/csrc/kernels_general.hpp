@@ -20,6 +20,7 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include "materials.hpp"
+#include "materials_other.hpp"
 
 namespace mimi_hip {
 
@@ -95,7 +96,8 @@ MH_DEV void compute_F_general(int n_dof, const double* __restrict__ g /* [DIM][n
 // PP: node pairs per lane and pass of the node-pair phase (3 covers up to 768 pairs = p <= 2 in 3-D; 8 halves the
 // passes of larger elements)
 // THREADS: workgroup size (256; 512 for elements with more than 768 node pairs: one pass of the node-pair phase for p = 3)
-template<int DIM, int GRAD, int PP = 3, int THREADS = 256>
+// FAMILY: 0 neo-Hookean / J2 (closed-form tangents, materials.hpp); 1 the other materials (materials_other.hpp)
+template<int DIM, int GRAD, int PP = 3, int THREADS = 256, int FAMILY = 0>
 __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domain_general_kernel(GeneralArgs p) {
   constexpr int DD = DIM * DIM;
   constexpr int D4 = DD * DD;
@@ -126,9 +128,16 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
   for (int q = tid; q < n_q; q += blockDim.x) {
     double F[DD];
     compute_F_general<DIM>(n_dof, gE + (int64_t)q * n_tdof, u_e, F);
+    const double wd = wE[q];
+    if constexpr (FAMILY == 1) {
+      double P[DD];
+      status |= evaluate_other<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F, P, GRAD == 1 ? Aw + q * D4 : nullptr, wd);
+#pragma unroll
+      for (int k = 0; k < DD; ++k) Pw[q * DD + k] = wd * P[k];
+      continue;
+    }
     PointResult<DIM> w;
     status |= evaluate_pk1<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F, w);
-    const double wd = wE[q];
 #pragma unroll
     for (int k = 0; k < DD; ++k) Pw[q * DD + k] = wd * w.P[k];
     if constexpr (GRAD == 1) {
@@ -265,11 +274,18 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
       for (int q = tid; q < n_q; q += blockDim.x) {
         double F[DD];
         compute_F_general<DIM>(n_dof, gE + (int64_t)q * n_tdof, u_e, F);
-        PointResult<DIM> w;
-        status |= evaluate_pk1<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F, w);
         const double wd = wE[q];
+        if constexpr (FAMILY == 1) {
+          double P[DD];
+          status |= evaluate_other<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F, P, nullptr, wd);
 #pragma unroll
-        for (int k = 0; k < DD; ++k) Pw[q * DD + k] = wd * w.P[k];
+          for (int k = 0; k < DD; ++k) Pw[q * DD + k] = wd * P[k];
+        } else {
+          PointResult<DIM> w;
+          status |= evaluate_pk1<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F, w);
+#pragma unroll
+          for (int k = 0; k < DD; ++k) Pw[q * DD + k] = wd * w.P[k];
+        }
       }
       __syncthreads();
       if (tid == 0) u_e[c] = orig;
@@ -293,7 +309,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
 }
 
 // DomainPostTimeAdvance (nonlinear_solid.cpp:179-199): one lane per quadrature point
-template<int DIM>
+template<int DIM, int FAMILY = 0>
 __global__ __launch_bounds__(256) void post_time_advance_general_kernel(GeneralArgs p) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const int e = blockIdx.x;
@@ -309,7 +325,8 @@ __global__ __launch_bounds__(256) void post_time_advance_general_kernel(GeneralA
   for (int q = tid; q < n_q; q += blockDim.x) {
     double F[DIM * DIM];
     compute_F_general<DIM>(n_dof, p.dN_dX + ((int64_t)e * n_q + q) * n_tdof, u_e, F);
-    status |= accumulate_state<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F);
+    if constexpr (FAMILY == 1) status |= accumulate_other<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F);
+    else status |= accumulate_state<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F);
   }
   if (status) atomicOr(p.status, status);
 }

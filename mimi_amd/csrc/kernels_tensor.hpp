@@ -755,7 +755,7 @@ inline TensorArgs tensor_args(mimi_hip_domain_s* h, const double* u, double* r, 
   a.grad_factor = gf;
   a.dt = h->dt;
   a.mat = h->mat;
-  a.state = StateView{h->eqps.ptr, h->temperature.ptr, h->plastic_strain.ptr, h->n_pts};
+  a.state = StateView{h->eqps.ptr, h->temperature.ptr, h->plastic_strain.ptr, h->n_pts, nullptr};
   a.status = h->status_dev;
   a.prof = h->prof_dev;
   a.perm = h->structured_perm ? h->node_ids.ptr : nullptr;

@@ -21,7 +21,9 @@
 
 namespace mimi_hip {
 
+#ifndef MH_DEV
 #define MH_DEV __device__ __forceinline__
+#endif
 
 template<int DIM>
 MH_DEV double det_of(const double* F) {
@@ -116,13 +118,14 @@ MH_DEV Dual hardening_evaluate(const mimi_hip_material& m, Dual eqps) {
 
 struct ReturnMapCtx {
   double eqps_old, q, thermo, dt;
+  double slope;   // 3G (J2, J2Log: materials.hpp:345,622) or G tr(be) (J2Simo: materials.hpp:495)
 };
 
 // materials.hpp:343-349
 MH_DEV Dual rm_residual(const mimi_hip_material& m, const ReturnMapCtx& c, Dual delta) {
   const Dual H = hardening_evaluate(m, Dual{c.eqps_old + delta.v, delta.d});
   const double fac = rate_contribution(m, delta.v / c.dt) * c.thermo;
-  return Dual{c.q - 3.0 * m.G * delta.v - H.v * fac, -3.0 * m.G * delta.d - H.d * fac};
+  return Dual{c.q - c.slope * delta.v - H.v * fac, -c.slope * delta.d - H.d * fac};
 }
 
 // solvers/newton.hpp:53-169; status bit 1 = root not bracketed, bit 2 = not converged
@@ -180,8 +183,9 @@ MH_DEV double scalar_solve(const mimi_hip_material& m, const ReturnMapCtx& c, do
 struct StateView {
   double* eqps;
   double* temperature;
-  double* plastic_strain;
+  double* plastic_strain;   // first state matrix (J2, J2Linear: plastic strain; J2Simo: be_old; J2Log: Fp_inv)
   int64_t n_pts;
+  double* state2;           // second state matrix (J2Linear: beta; J2Simo: F_old), same SoA layout
 };
 
 template<int DIM>
@@ -267,7 +271,7 @@ MH_DEV int j2_stress(const MaterialDev& md, double dt, const double* F, double* 
   w.delta = 0;
   w.hprime = 0;
 
-  ReturnMapCtx c{eqps, q, thermo_contribution(md, temperature), dt};
+  ReturnMapCtx c{eqps, q, thermo_contribution(md, temperature), dt, 3.0 * m.G};
   const double tolerance = md.sigma_y_ref * 1.e-10;
   int status = 0;
   if (rm_residual(m, c, Dual{0.0, 0.0}).v > tolerance) {

@@ -175,10 +175,12 @@ class NonlinearSolid(NonlinearBase):
 
     # -- material state (MaterialState, materials.hpp:278-286) --------------------------
     def State(self, what):
-        ids = {"accumulated_plastic_strain": 0, "temperature": 1, "plastic_strain": 2}
+        # "plastic_strain" = the material's first state matrix (J2 / J2Linear: plastic strain, J2Simo: be_old, J2Log:
+        # Fp_inv); "state2" = its second one (J2Linear: beta, J2Simo: F_old)
+        ids = {"accumulated_plastic_strain": 0, "temperature": 1, "plastic_strain": 2, "state2": 3}
         n = self.n_elements_ * self.n_quad_
         dim = self.patch_.dim if self.patch_ is not None else self.tables_["dim"]
-        shape = (self.n_elements_, self.n_quad_, dim * dim) if what == "plastic_strain" else (self.n_elements_, self.n_quad_)
+        shape = (self.n_elements_, self.n_quad_, dim * dim) if ids[what] >= 2 else (self.n_elements_, self.n_quad_)
         out = np.empty(shape)
         check(_capi.lib().mimi_hip_domain_get_state(self._handle(), ids[what], ptr(out), out.size))
         return out

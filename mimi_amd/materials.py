@@ -122,3 +122,33 @@ class J2(Material):
                 continue
             setattr(m, f, float(v))
         return m
+
+
+class StVenantKirchhoff(Material):
+    """materials/materials.hpp:88-111"""
+    _kind = 2
+
+
+class J2Linear(Material):
+    """materials/materials.hpp:142-249 (attribute names of py/py_material.cpp:47-53)"""
+    _kind = 3
+    isotropic_hardening = 0.0
+    kinematic_hardening = 0.0
+    sigma_y = 0.0
+
+    def _c_struct(self):
+        m = super()._c_struct()
+        m.sigma_y = float(self.sigma_y)
+        m.lin_isotropic_hardening = float(self.isotropic_hardening)
+        m.lin_kinematic_hardening = float(self.kinematic_hardening)
+        return m
+
+
+class J2Simo(J2):
+    """materials/materials.hpp:406-557"""
+    _kind = 4
+
+
+class J2Log(J2):
+    """materials/materials.hpp:559-753"""
+    _kind = 5

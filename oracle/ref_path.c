@@ -479,13 +479,22 @@ static double polish_root(const rm_ctx* c, double x, double lower, double upper)
     dual xx = {x, 1.0};
     dual R = rm_residual(c, xx);
     if (R.d == 0.0) break;
-    double xn = x - R.v / R.d;
-    if (xn < lower) xn = lower;
-    if (xn > upper) xn = upper;
-    if (xn == x) break;
+    const double xn = x - R.v / R.d;
+    if (!(xn > lower && xn < upper) || xn == x) break;
+    dual xt = {xn, 0.0};
+    if (!(fabs(rm_residual(c, xt).v) < fabs(R.v))) break;   /* only steps that improve (first yield: H' unbounded) */
     x = xn;
   }
   return x;
+}
+
+/* -d residual / d delta at delta, including the rate term the reference's own Newton leaves out
+ * (material_hardening.hpp:69-71) -- for the oracle tangent */
+static double return_map_slope(const rm_ctx* c, double delta) {
+  dual e1 = {c->eqps_old + delta, 1.0};
+  dual H = hardening_evaluate(c->m, e1);
+  const double rc = rate_contribution(c->m, delta / c->dt);
+  return c->slope + H.d * rc * c->thermo + H.v * rate_contribution_derivative(c->m, delta / c->dt) / c->dt * c->thermo;
 }
 
 /* materials.cpp:72-94 StVenantKirchhoff::EvaluatePK1: S = lambda tr(E) I + 2 mu E, P = F S */
@@ -554,8 +563,11 @@ static int j2linear_stress(const oracle_material* m, int dim, int accumulate, do
 }
 
 /* materials.hpp:452-545  J2Simo::PlasticStress<accumulate> (EvaluatePK1 is overridden: P straight from here) */
+/* delta_fixed / r_out (oracle tangent only): take the plastic branch with the given increment instead of solving, and
+ * report the return-map residual at it */
 static int j2simo_stress(const oracle_material* m, int dim, double dt, int accumulate, int polish, double* be_old,
-                         double* F_old, double* eqps, double* temperature, point_work* w) {
+                         double* F_old, double* eqps, double* temperature, point_work* w, const double* delta_fixed,
+                         double* r_out) {
   double f_inv[9] = {0}, f_bar[9] = {0}, be[9], fbbo[9], s[9], Np[9];
   const int dd = dim * dim;
   int status = 0;
@@ -590,11 +602,22 @@ static int j2simo_stress(const oracle_material* m, int dim, double dt, int accum
   c.slope = m->G * be_trace;
   const double tolerance = sigma_y_of(m) * 1.e-10;
   dual zero = {0.0, 0.0};
-  if (rm_residual(&c, zero).v > tolerance) {
+  w->plastic = 0;
+  if (delta_fixed || rm_residual(&c, zero).v > tolerance) {
     dual e0 = {c.eqps_old, 0.0};
     const double upper = (s_effective - hardening_evaluate(m, e0).v * c.thermo) / (m->G * be_trace);
-    double delta = scalar_solve(&c, 0.0, 0.0, upper, 1.e-10, tolerance, 100, &status);
-    if (polish) delta = polish_root(&c, delta, 0.0, upper);
+    double delta;
+    if (delta_fixed) {
+      dual df = {*delta_fixed, 0.0};
+      delta = *delta_fixed;
+      *r_out = rm_residual(&c, df).v;
+    } else {
+      delta = scalar_solve(&c, 0.0, 0.0, upper, 1.e-10, tolerance, 100, &status);
+      if (polish) delta = polish_root(&c, delta, 0.0, upper);
+    }
+    w->plastic = 1;
+    w->delta = delta;
+    w->hprime = return_map_slope(&c, delta);
     for (int i = 0; i < dd; ++i) be[i] += -2. / 3. * delta * be_trace * Np[i];
     dev_d(be, dim, m->G, s);
     if (accumulate) {
@@ -619,7 +642,7 @@ static int j2simo_stress(const oracle_material* m, int dim, double dt, int accum
  * takes alternative_stress_ = s + (p / det F) I as the Cauchy stress and overwrites what PlasticStress left in
  * tmp.stress_:  P = det F (s + p/det F I) F^-T.  (The golden series j2_log_h1_p2 is reproduced by exactly this.) */
 static int j2log_stress(const oracle_material* m, int dim, double dt, int accumulate, int polish, double* Fp_inv,
-                        double* eqps, double* temperature, point_work* w) {
+                        double* eqps, double* temperature, point_work* w, const double* delta_fixed, double* r_out) {
   double F_e[9], C_e[9], E_e[9], s[9], Np[9];
   const int dd = dim * dim;
   int status = 0;
@@ -647,11 +670,22 @@ static int j2log_stress(const oracle_material* m, int dim, double dt, int accumu
   c.slope = 3.0 * m->G;
   const double tolerance = sigma_y_of(m) * 1.e-10;
   dual zero = {0.0, 0.0};
-  if (rm_residual(&c, zero).v > tolerance) {
+  w->plastic = 0;
+  if (delta_fixed || rm_residual(&c, zero).v > tolerance) {
     dual e0 = {c.eqps_old, 0.0};
     const double upper = (q - hardening_evaluate(m, e0).v * c.thermo) / (3.0 * m->G);
-    double delta = scalar_solve(&c, 0.0, 0.0, upper, 1.e-10, tolerance, 100, &status);
-    if (polish) delta = polish_root(&c, delta, 0.0, upper);
+    double delta;
+    if (delta_fixed) {
+      dual df = {*delta_fixed, 0.0};
+      delta = *delta_fixed;
+      *r_out = rm_residual(&c, df).v;
+    } else {
+      delta = scalar_solve(&c, 0.0, 0.0, upper, 1.e-10, tolerance, 100, &status);
+      if (polish) delta = polish_root(&c, delta, 0.0, upper);
+    }
+    w->plastic = 1;
+    w->delta = delta;
+    w->hprime = return_map_slope(&c, delta);
     for (int i = 0; i < dd; ++i) Np[i] = 1.5 / q * s[i];
     for (int i = 0; i < dd; ++i) s[i] += -2.0 * m->G * delta * Np[i];
     if (accumulate) {
@@ -673,35 +707,63 @@ static int j2log_stress(const oracle_material* m, int dim, double dt, int accumu
 }
 
 /* one dispatcher for the stateful extras; state pointers address ONE quadrature point */
-static int other_material_stress(const oracle_material* m, int dim, double dt, int accumulate, int polish,
-                                 double* mat1, double* mat2, double* eqps, double* temperature, point_work* w) {
+static int other_material_stress_x(const oracle_material* m, int dim, double dt, int accumulate, int polish,
+                                   double* mat1, double* mat2, double* eqps, double* temperature, point_work* w,
+                                   const double* delta_fixed, double* r_out) {
+  w->plastic = 0;
   switch (m->kind) {
   case MAT_STVK: if (!accumulate) stvk_pk1(m, dim, w); return 0;
   case MAT_J2LINEAR: return j2linear_stress(m, dim, accumulate, mat1, mat2, eqps, w);
-  case MAT_J2SIMO: return j2simo_stress(m, dim, dt, accumulate, polish, mat1, mat2, eqps, temperature, w);
-  default: return j2log_stress(m, dim, dt, accumulate, polish, mat1, eqps, temperature, w);
+  case MAT_J2SIMO:
+    return j2simo_stress(m, dim, dt, accumulate, polish, mat1, mat2, eqps, temperature, w, delta_fixed, r_out);
+  default: return j2log_stress(m, dim, dt, accumulate, polish, mat1, eqps, temperature, w, delta_fixed, r_out);
   }
 }
 
-/* tangent of those materials for the oracle's TANGENT_EXACT mode: central difference quotient of P(F) at the POINT
- * (step 1e-6, polished return map) -- about 1e-10 relative; not in the reference */
+static int other_material_stress(const oracle_material* m, int dim, double dt, int accumulate, int polish,
+                                 double* mat1, double* mat2, double* eqps, double* temperature, point_work* w) {
+  return other_material_stress_x(m, dim, dt, accumulate, polish, mat1, mat2, eqps, temperature, w, NULL, NULL);
+}
+
+/* tangent of those materials for the oracle's TANGENT_EXACT mode (not in the reference): central difference quotients
+ * of P(F) at the POINT, step 1e-6.  At a yielding point of J2Simo / J2Log the increment delta is NOT re-solved under
+ * the perturbation (with power-law hardening delta(F) has an unbounded second derivative at first yield, which a
+ * difference quotient cannot resolve); instead  dP = dP|delta + (dP/d delta) d delta,  d delta = -(dr|delta) / (dr/d delta)
+ * with the return-map residual r: every quotient is then taken of a smooth function.  About 1e-9 relative. */
 static void difference_tangent(const oracle_material* m, int dim, double dt, double* mat1, double* mat2, double* eqps,
                                double* temperature, const point_work* w0, double* A) {
   const double h = 1.0e-6;
+  point_work wc = *w0;
+  double r_unused = 0;
+  other_material_stress_x(m, dim, dt, 0, 1, mat1, mat2, eqps, temperature, &wc, NULL, NULL);
+  const int frozen = wc.plastic && (m->kind == MAT_J2SIMO || m->kind == MAT_J2LOG);
+  const double delta0 = wc.delta, slope = wc.hprime;
+  double dP_ddelta[9] = {0};
+  if (frozen) {
+    const double k = 1.0e-4 * (fabs(delta0) + 1.0e-3);
+    point_work wp = *w0, wm = *w0;
+    const double dp = delta0 + k, dm = delta0 - k;
+    other_material_stress_x(m, dim, dt, 0, 1, mat1, mat2, eqps, temperature, &wp, &dp, &r_unused);
+    other_material_stress_x(m, dim, dt, 0, 1, mat1, mat2, eqps, temperature, &wm, &dm, &r_unused);
+    for (int i = 0; i < dim * dim; ++i) dP_ddelta[i] = (wp.P[i] - wm.P[i]) / (2.0 * k);
+  }
   for (int j = 0; j < dim; ++j)
     for (int L = 0; L < dim; ++L) {
       point_work wp = *w0, wm = *w0;
+      double rp = 0, rm = 0;
       M(wp.F, j, L) += h;
       M(wm.F, j, L) -= h;
       wp.detF = det_d(wp.F, dim);
       inv_d(wp.F, dim, wp.Finv);
       wm.detF = det_d(wm.F, dim);
       inv_d(wm.F, dim, wm.Finv);
-      other_material_stress(m, dim, dt, 0, 1, mat1, mat2, eqps, temperature, &wp);
-      other_material_stress(m, dim, dt, 0, 1, mat1, mat2, eqps, temperature, &wm);
+      other_material_stress_x(m, dim, dt, 0, 1, mat1, mat2, eqps, temperature, &wp, frozen ? &delta0 : NULL, &rp);
+      other_material_stress_x(m, dim, dt, 0, 1, mat1, mat2, eqps, temperature, &wm, frozen ? &delta0 : NULL, &rm);
+      const double ddelta = frozen ? ((rp - rm) / (2.0 * h)) / slope : 0.0;
       for (int i = 0; i < dim; ++i)
         for (int Jx = 0; Jx < dim; ++Jx)
-          A[((i * dim + Jx) * dim + j) * dim + L] = (M(wp.P, i, Jx) - M(wm.P, i, Jx)) / (2.0 * h);
+          A[((i * dim + Jx) * dim + j) * dim + L] =
+              (M(wp.P, i, Jx) - M(wm.P, i, Jx)) / (2.0 * h) + M(dP_ddelta, i, Jx) * ddelta;
     }
 }
 

@@ -23,7 +23,18 @@ def product_material(name):
         m.density = 1.0
         m.set_young_poisson(2100, 0.3)
         return m
-    m = mimi_amd.J2()
+    if name == "stvk":
+        m = mimi_amd.StVenantKirchhoff()
+        m.density = 1.0
+        m.set_young_poisson(2100, 0.3)
+        return m
+    if name == "j2linear":
+        m = mimi_amd.J2Linear()
+        m.density = 1.0
+        m.set_young_poisson(2100, 0.3)
+        m.isotropic_hardening, m.kinematic_hardening, m.sigma_y = 40.0, 25.0, 70.0
+        return m
+    m = {"j2": mimi_amd.J2, "j2simo": mimi_amd.J2Simo, "j2log": mimi_amd.J2Log}[name]()
     m.density = 1.0
     m.set_young_poisson(2100, 0.3)
     m.heat_fraction, m.specific_heat = 0.9, 450

@@ -1,0 +1,92 @@
+"""The device constitutive routines (mimi_amd/csrc/materials.hpp, materials_other.hpp) compiled for the host
+(tests/host_materials.hip, hipcc) against the oracle, point by point: PK1 stress <= 1e-12, tangent <= 1e-11 for the
+closed forms (neo-Hookean, J2) and <= 1e-6 for the dual-number tangents of the other materials (the oracle's
+difference-quotient tangent and the return map's own tolerance bound that comparison, not the device code)."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from _cases import oracle_material
+from test_domain_gpu import product_material
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def host_lib():
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    out = os.path.join(HERE, "_build", "libhost_materials.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared",
+                           "-I", os.path.join(ROOT, "include"), "-o", out, os.path.join(HERE, "host_materials.hip")])
+    return C.CDLL(out)
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def sym(a):
+    return 0.5 * (a + a.T)
+
+
+def random_state(name, dim, rng, fresh):
+    """(first matrix, second matrix, eqps): the material's initial state or a plausible advanced one"""
+    eye = np.eye(dim)
+    if fresh:
+        m1 = eye.copy() if name in ("j2simo", "j2log") else np.zeros((dim, dim))
+        m2 = eye.copy() if name == "j2simo" else np.zeros((dim, dim))
+        return m1, m2, 0.0
+    if name in ("j2", "j2linear"):
+        ep = sym(0.01 * rng.standard_normal((dim, dim)))
+        ep -= np.trace(ep) / dim * eye
+        beta = sym(0.5 * rng.standard_normal((dim, dim))) if name == "j2linear" else np.zeros((dim, dim))
+        return ep, beta, 0.02
+    if name == "j2simo":
+        g = eye + 0.02 * rng.standard_normal((dim, dim))
+        return g @ g.T, eye + 0.02 * rng.standard_normal((dim, dim)), 0.02
+    if name == "j2log":
+        return eye + 0.02 * rng.standard_normal((dim, dim)), np.zeros((dim, dim)), 0.02
+    return np.zeros((dim, dim)), np.zeros((dim, dim)), 0.0
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("name", ["neohook", "j2", "stvk", "j2linear", "j2simo", "j2log"])
+def test_device_materials_on_host_vs_oracle(host_lib, name, dim):
+    from oracle import ref_path as rp
+    mo = oracle_material(name)
+    mp = product_material(name)._c_struct()
+    sigma_y_ref = 70.0
+    rng = np.random.default_rng(7 + dim)
+    tol_A = 1e-11 if name in ("neohook", "j2") else 1e-6
+    n_plastic = 0
+    for trial in range(120):
+        scale = 10 ** rng.uniform(-2.5, -0.9)
+        F = np.eye(dim) + scale * rng.standard_normal((dim, dim))
+        m1, m2, eqps = random_state(name, dim, rng, fresh=trial % 2 == 0)
+        Po, Ao = rp.point_pk1(mo, F, dt=0.5, plastic_strain=m1, eqps=eqps, temperature=20.0, state2=m2)
+        Fc = np.ascontiguousarray(F.T).ravel()
+        P, A = np.zeros(dim * dim), np.zeros(dim ** 4)
+        a1, a2 = np.ascontiguousarray(m1.T).ravel().copy(), np.ascontiguousarray(m2.T).ravel().copy()
+        st = host_lib.host_point(C.byref(mp), C.c_double(sigma_y_ref), dim, C.c_double(0.5), ptr(Fc), ptr(a1), ptr(a2),
+                                 C.c_double(eqps), C.c_double(20.0), ptr(P), ptr(A))
+        assert st == 0
+        Pg, Ag = P.reshape(dim, dim).T, A.reshape(dim, dim, dim, dim)
+        assert np.abs(Pg - Po).max() <= 1e-12 * max(np.abs(Po).max(), 1.0), (trial, scale)
+        assert np.abs(Ag - Ao).max() <= tol_A * np.abs(Ao).max(), (trial, scale, np.abs(Ag - Ao).max() / np.abs(Ao).max())
+        # the committed state: DomainPostTimeAdvance at this point
+        if name in ("neohook", "stvk"):
+            continue
+        e, T = C.c_double(eqps), C.c_double(20.0)
+        st = host_lib.host_accumulate(C.byref(mp), C.c_double(sigma_y_ref), dim, C.c_double(0.5), ptr(Fc), ptr(a1), ptr(a2),
+                                      C.byref(e), C.byref(T))
+        assert st == 0
+        n_plastic += e.value > eqps
+    if name not in ("neohook", "stvk"):
+        assert n_plastic > 20      # the plastic branch was exercised

@@ -120,6 +120,27 @@ def test_nonlinear_solid_j2(golden_dir, tangent_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tangent_mode", [0, 1], ids=["analytic", "referenceFD"])
+@pytest.mark.parametrize("matname,refdir", [("J2Simo", "j2_simo_h1_p2"), ("J2Log", "j2_log_h1_p2")])
+def test_nonlinear_solid_j2_simo_and_log(golden_dir, matname, refdir, tangent_mode):
+    """reference tests/test_nonlinear_solid.py:100-114: the finite-strain plasticity series through the HIP integrators"""
+    import mimi_amd as mimi
+    from oracle import harness as hz
+    nl = balken_plasticity(1, 2, getattr(mimi, matname)())
+    nl.tangent_mode = tangent_mode
+    nl.setup(1)
+    nl.configure_newton("nonlinear_solid", 1e-12, 1e-8, 10, False)
+    nl.time_step_size = 0.5
+    u = nl.solution_view("displacement", "x").ravel()
+    for i in range(10):
+        nl.step_time2()
+        ref = hz.golden_to_lexicographic(np.genfromtxt(os.path.join(golden_dir, "ref", refdir, f"x_{i}.txt")))
+        assert np.allclose(u, ref)
+        assert np.abs(u - ref).max() < 1e-8, (i, np.abs(u - ref).max())
+    assert nl.domain_.State("accumulated_plastic_strain").max() > 0.05
+
+
+@pytest.mark.gpu
 def test_3d_cantilever_runs_through_tensor_kernels():
     """cfg1-like plumbing: 3-D p=2 block from cube-nurbs.mesh, one implicit step converges and
     agrees with the same step taken with the reference-FD tangent."""
