@@ -32,6 +32,11 @@ WORKLOADS = {
     "northstar": ((128, 128, 16), 2, "neohookean"),
     "cfg3": ((128, 128, 16), 3, "j2"),
     "northstar_j2": ((128, 128, 16), 2, "j2"),
+    # the reference's other materials (general kernels, dual-number tangents): measured for DESIGN.md only
+    "cfg2_stvk": ((64, 64, 8), 2, "stvk"),
+    "cfg2_j2linear": ((64, 64, 8), 2, "j2linear"),
+    "cfg2_j2simo": ((64, 64, 8), 2, "j2simo"),
+    "cfg2_j2log": ((64, 64, 8), 2, "j2log"),
     "cfg5": ((256, 256, 32), 2, "neohookean"),
     # orientation experiments (same block, short axis first)
     "northstar_zfirst": ((16, 128, 128), 2, "neohookean"),
@@ -70,7 +75,18 @@ def make_material(kind):
         m.density = 1.0
         m.set_young_poisson(2100, 0.3)
         return m
-    m = mimi_amd.J2()
+    if kind == "stvk":
+        m = mimi_amd.StVenantKirchhoff()
+        m.density = 1.0
+        m.set_young_poisson(2100, 0.3)
+        return m
+    if kind == "j2linear":
+        m = mimi_amd.J2Linear()
+        m.density = 1.0
+        m.set_young_poisson(2100, 0.3)
+        m.isotropic_hardening, m.kinematic_hardening, m.sigma_y = 40.0, 25.0, 70.0
+        return m
+    m = {"j2": mimi_amd.J2, "j2simo": mimi_amd.J2Simo, "j2log": mimi_amd.J2Log}[kind]()
     m.density = 1.0
     m.set_young_poisson(2100, 0.3)
     m.heat_fraction, m.specific_heat = 0.9, 450
@@ -96,10 +112,12 @@ def cpu_baseline(p, material, seconds_hint=12.0):
     n_el = (32, 32, 8)
     threads = min(os.cpu_count() or 1, 32)
     P = iga.Patch.block(n_el, p)
-    if material == "neohookean":
-        mat = rp.make_material("neohookean", 2100, 0.3)
+    if material in ("neohookean", "stvk"):
+        mat = rp.make_material(material, 2100, 0.3)
+    elif material == "j2linear":
+        mat = rp.make_material("j2linear", 2100, 0.3, isotropic_hardening=40.0, kinematic_hardening=25.0, sigma_y=70.0)
     else:
-        mat = rp.make_material("j2", 2100, 0.3, hardening=dict(kind="JohnsonCookTempRate", A=70, B=140, n=0.2835,
+        mat = rp.make_material(material, 2100, 0.3, hardening=dict(kind="JohnsonCookTempRate", A=70, B=140, n=0.2835,
                                m=1.3558, eps0_dot=0.004, reference_temperature=20),
                                specific_heat=450, initial_temperature=20, melting_temperature=1500)
     D = rp.DomainOracle(P, mat, n_threads=threads)

@@ -94,8 +94,9 @@ static void init_common(mimi_hip_domain_s* h, int device, const mimi_hip_materia
 }
 
 static bool material_has_state(int kind) { return kind != MIMI_HIP_MAT_NEOHOOKEAN && kind != MIMI_HIP_MAT_STVK; }
-// the tensor-product kernels carry closed-form tangents of the two benchmarked materials only
-static bool material_on_tensor_path(int kind) { return kind == MIMI_HIP_MAT_NEOHOOKEAN || kind == MIMI_HIP_MAT_J2; }
+// closed-form tangents inside the kernels (every kernel family) vs the other materials (materials_other.hpp: general
+// kernels, and the two-phase tensor kernels through the tangent record of the material pre-pass)
+static bool material_closed_form(int kind) { return kind == MIMI_HIP_MAT_NEOHOOKEAN || kind == MIMI_HIP_MAT_J2; }
 
 static void init_state(mimi_hip_domain_s* h) {
   h->n_pts = (int64_t)h->n_el * h->n_q;
@@ -268,7 +269,7 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a)
     hipLaunchKernelGGL(kernel, dim3(h->n_el), dim3(threads), lds, h->stream, a);
     MH_HIP(hipGetLastError());
   };
-  if (!material_on_tensor_path(h->mat.m.kind)) {
+  if (!material_closed_form(h->mat.m.kind)) {
     // the other materials: same kernel, stress and tangent from materials_other.hpp
     if (grad == 0) go(domain_general_kernel<DIM, 0, 3, 256, 1>);
     else if (grad == 1 && h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, GEN_BIG_PP, GEN_BIG_THREADS, 1>, GEN_BIG_THREADS);
@@ -290,7 +291,9 @@ static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double*
   Mirror<double> mA;
   if (with_grad) mA = Mirror<double>::inout(A, h->nnz, h->stage_A, h->stream);
   const int grad = !with_grad ? 0 : (h->tangent_mode == MIMI_HIP_TANGENT_REFERENCE_FD ? 2 : 1);
-  if (h->path == 1 && grad != 2) {
+  // (the colour-partitioned tensor kernel, the fallback when the CSR is not the structured pattern, has closed-form
+  // materials only: the other materials then take the general kernels)
+  if (h->path == 1 && grad != 2 && (material_closed_form(h->mat.m.kind) || two_phase_supported(h))) {
     launch_tensor(h, grad, mu.dev, mr.dev, mA.dev, gf);
   } else {
     ensure_general_tables(h);
@@ -448,7 +451,7 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
     const char* keep_env = getenv("MIMI_HIP_KEEP_GENERAL");
     const char* path_env = getenv("MIMI_HIP_FORCE_GENERAL");
     const bool force_general = path_env && path_env[0] == '1';
-    const bool tensor_ok = tensor_supported(dim, h->degree, nq) && material_on_tensor_path(h->mat.m.kind);
+    const bool tensor_ok = tensor_supported(dim, h->degree, nq);
     const bool keep_general = force_general || !tensor_ok || (keep_env && keep_env[0] == '1');
     h->path = (tensor_ok && !force_general) ? 1 : 0;
     h->dofs.resize((size_t)h->n_el * h->n_dof);
@@ -613,7 +616,7 @@ int mimi_hip_domain_post_time_advance(mimi_hip_domain_t h, const double* u) {
       ensure_general_tables(h);
       GeneralArgs a = general_args(h, mu.dev, nullptr, nullptr, 0.0);
       const size_t lds = (size_t)h->n_dof * h->dim * sizeof(double);
-      const bool other = !material_on_tensor_path(h->mat.m.kind);
+      const bool other = !material_closed_form(h->mat.m.kind);
       void (*kernel)(GeneralArgs) =
           h->dim == 2 ? (other ? post_time_advance_general_kernel<2, 1> : post_time_advance_general_kernel<2, 0>)
                       : (other ? post_time_advance_general_kernel<3, 1> : post_time_advance_general_kernel<3, 0>);

@@ -29,6 +29,7 @@
 
 #include "domain.hpp"
 #include "materials.hpp"
+#include "materials_other.hpp"
 
 namespace mimi_hip {
 
@@ -713,7 +714,10 @@ __global__ __launch_bounds__(256) void tensor_post_kernel(TensorArgs p, int n_el
         for (int m = 0; m < 3; ++m) s += H[i * 3 + m] * g[(int64_t)(m * 3 + J) * NQ3];
         F[i + J * 3] = s;
       }
-    status |= accumulate_state<3>(p.mat, p.dt, p.state, e * NQ3 + q, F);
+    if (p.mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN || p.mat.m.kind == MIMI_HIP_MAT_J2)
+      status |= accumulate_state<3>(p.mat, p.dt, p.state, e * NQ3 + q, F);
+    else
+      status |= accumulate_other<3>(p.mat, p.dt, p.state, e * NQ3 + q, F);
   }
   if (status) atomicOr(p.status, status);
 }
@@ -755,7 +759,7 @@ inline TensorArgs tensor_args(mimi_hip_domain_s* h, const double* u, double* r, 
   a.grad_factor = gf;
   a.dt = h->dt;
   a.mat = h->mat;
-  a.state = StateView{h->eqps.ptr, h->temperature.ptr, h->plastic_strain.ptr, h->n_pts, nullptr};
+  a.state = StateView{h->eqps.ptr, h->temperature.ptr, h->plastic_strain.ptr, h->n_pts, h->state2.ptr};
   a.status = h->status_dev;
   a.prof = h->prof_dev;
   a.perm = h->structured_perm ? h->node_ids.ptr : nullptr;
@@ -795,7 +799,8 @@ inline void launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, doubl
   // symmetric-half kernel for hyperelastic materials; "wgs" forces the full nine-block kernel,
   // "valu" the colour-partitioned read-modify-write kernel
   static const char* variant = getenv("MIMI_HIP_TENSOR_VARIANT");
-  const bool want_valu = variant && variant[0] == 'v';
+  const bool closed_form = h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN || h->mat.m.kind == MIMI_HIP_MAT_J2;
+  const bool want_valu = variant && variant[0] == 'v' && closed_form;   // the colour kernel has the closed-form materials only
   if (grad && !want_valu && two_phase_supported(h)) {
     const bool want_full = variant && variant[0] == 'w';
     if (h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN && !want_full) launch_tensor_wgsym(h, a);

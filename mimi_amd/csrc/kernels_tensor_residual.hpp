@@ -103,9 +103,14 @@ __global__ __launch_bounds__(256) void tensor_residual_kernel(TensorArgs p, int 
       }
   }
   PointResult<3> w;
-  MaterialDev mat = p.mat;
-  mat.m.kind = KIND;
-  const int status = evaluate_pk1<3>(mat, p.dt, p.state, e * NQ3 + lane, F, w);
+  int status;
+  if constexpr (KIND == WGS_KIND_RECORD) {
+    status = evaluate_other<3>(p.mat, p.dt, p.state, e * NQ3 + lane, F, w.P, nullptr, 1.0);
+  } else {
+    MaterialDev mat = p.mat;
+    mat.m.kind = KIND;
+    status = evaluate_pk1<3>(mat, p.dt, p.state, e * NQ3 + lane, F, w);
+  }
   if (status) atomicOr(p.status, status);
   // element residual piece of every component by sum factorisation (as kernels_tensor_2phase.hpp, stage R)
   double* PH = RS;                   // [3 m][64]
@@ -200,7 +205,9 @@ inline void launch_tensor_residual(mimi_hip_domain_s* h, TensorArgs a) {
   h->scratch_r.resize((size_t)h->n_el * 3 * 27);
   a.scratch_r = h->scratch_r.ptr;
   const unsigned blocks = (unsigned)((h->n_el + 3) / 4);
-  if (h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN)
+  if (h->mat.m.kind != MIMI_HIP_MAT_NEOHOOKEAN && h->mat.m.kind != MIMI_HIP_MAT_J2)
+    hipLaunchKernelGGL(tensor_residual_kernel<WGS_KIND_RECORD>, dim3(blocks), dim3(256), 0, h->stream, a, (int)h->n_el);
+  else if (h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN)
     hipLaunchKernelGGL(tensor_residual_kernel<MIMI_HIP_MAT_NEOHOOKEAN>, dim3(blocks), dim3(256), 0, h->stream, a, (int)h->n_el);
   else
     hipLaunchKernelGGL(tensor_residual_kernel<MIMI_HIP_MAT_J2>, dim3(blocks), dim3(256), 0, h->stream, a, (int)h->n_el);

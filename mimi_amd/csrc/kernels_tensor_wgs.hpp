@@ -31,6 +31,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "materials_other.hpp"
+
 #include "kernels_tensor_2phase.hpp"
 
 namespace mimi_hip {
@@ -118,6 +120,16 @@ MH_DEV void wgs_point_load(const double* rec, int lane, PointResult<3>& w, doubl
   pk1_from_cauchy<3>(w);
 }
 
+// The other materials (materials_other.hpp): no closed form of the pulled-back tangent -- the pre-pass leaves the
+// tangent itself, pulled back to the reference element and weighted, in the record:
+//   field i*27 + (m*3 + j)*3 + n : Ahat_i[m][j][n] = wd sum_JL Jinv[m][J] dP_iJ/dF_jL Jinv[n][L]
+//   field 81 + i*3 + m           : Phat_i[m]       = wd sum_J  P_iJ Jinv[m][J]
+// (46 KB per element; wave X of the nine-block kernel then only copies its row into LDS).
+constexpr int WGS_REC_FIELDS = 90;
+constexpr int WGS_KIND_RECORD = 100;   // compile-time "material kind" of the kernels that read such records
+
+// FAMILY 0: J2 (24-field record, closed forms in wave X); 1: the other materials (90-field record)
+template<int FAMILY>
 __global__ __launch_bounds__(256) void tensor_point_kernel(TensorArgs p, int n_el) {
   constexpr int P = 2, NB = 3, NQ = 4, ND = 27, NQ3 = 64;
   __shared__ double ue_all[4][3 * ND];
@@ -170,10 +182,43 @@ __global__ __launch_bounds__(256) void tensor_point_kernel(TensorArgs p, int n_e
       for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * g[(int64_t)(m * 3 + J) * NQ3];
       F[i + J * 3] = sf;
     }
-  PointResult<3> w;
-  const int status = evaluate_pk1<3>(p.mat, p.dt, p.state, e * NQ3 + lane, F, w);
-  wgs_point_store(p.scratch_pt + e * (int64_t)(WGS_PT_FIELDS * NQ3), lane, p.mat.m, w);
-  if (status) atomicOr(p.status, status);
+  if constexpr (FAMILY == 1) {
+    double Pk[9], A[81];
+    const int status = evaluate_other<3>(p.mat, p.dt, p.state, e * NQ3 + lane, F, Pk, A, 1.0);
+    double* rec = p.scratch_pt + e * (int64_t)(WGS_REC_FIELDS * NQ3) + lane;
+    const double wd = g[(int64_t)9 * NQ3];
+    double Ji[9];
+    for (int k = 0; k < 9; ++k) Ji[k] = g[(int64_t)k * NQ3];
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) {
+        // B[m][L] = sum_J Jinv[m][J] A_iJjL, then Ahat[m][n] = wd sum_L B[m][L] Jinv[n][L]
+        double B[9];
+        for (int m = 0; m < 3; ++m)
+          for (int L = 0; L < 3; ++L) {
+            double t = 0.0;
+            for (int J = 0; J < 3; ++J) t += Ji[m * 3 + J] * A[((i * 3 + J) * 3 + j) * 3 + L];
+            B[m * 3 + L] = t;
+          }
+        for (int m = 0; m < 3; ++m)
+          for (int n = 0; n < 3; ++n) {
+            double t = 0.0;
+            for (int L = 0; L < 3; ++L) t += B[m * 3 + L] * Ji[n * 3 + L];
+            rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * NQ3] = wd * t;
+          }
+      }
+      for (int m = 0; m < 3; ++m) {
+        double t = 0.0;
+        for (int J = 0; J < 3; ++J) t += Pk[i + J * 3] * Ji[m * 3 + J];
+        rec[(int64_t)(81 + i * 3 + m) * NQ3] = wd * t;
+      }
+    }
+    if (status) atomicOr(p.status, status);
+  } else {
+    PointResult<3> w;
+    const int status = evaluate_pk1<3>(p.mat, p.dt, p.state, e * NQ3 + lane, F, w);
+    wgs_point_store(p.scratch_pt + e * (int64_t)(WGS_PT_FIELDS * NQ3), lane, p.mat.m, w);
+    if (status) atomicOr(p.status, status);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -203,6 +248,11 @@ template<>
 struct WgsPoint<MIMI_HIP_MAT_J2> {
   double G[9], Ji[9], N[9], Q[9], sig[9], st[9], Phat[9];
   double wdJ, Kc, hb, gg;   // wd J, K - beta 2G/3, beta G, 2G gamma
+};
+
+template<>
+struct WgsPoint<WGS_KIND_RECORD> {
+  const double* rec;   // this lane's column of the element's record
 };
 
 // fills WgsPoint<J2> from the PointResult of the material pre-pass
@@ -322,7 +372,15 @@ MH_DEV void wgs_x_row(const TensorArgs& p, double* lds, int lane, int64_t e, int
   double* AH = lds + L::off_ah + I * ND * NQ3;
   double* RS = lds + L::off_r;
   double Phat[3];
-  if constexpr (KIND == MIMI_HIP_MAT_NEOHOOKEAN) {
+  if constexpr (KIND == WGS_KIND_RECORD) {
+#pragma unroll
+    for (int m = 0; m < 3; ++m) Phat[m] = s.rec[(int64_t)(81 + I * 3 + m) * NQ3];
+    double v[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) v[k] = s.rec[(int64_t)(I * ND + k) * NQ3];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) AH[k * NQ3 + lane] = v[k];
+  } else if constexpr (KIND == MIMI_HIP_MAT_NEOHOOKEAN) {
 #pragma unroll
     for (int m = 0; m < 3; ++m) Phat[m] = s.Phat[I * 3 + m];
 #pragma unroll
@@ -524,6 +582,8 @@ MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& st
           }
       }
       status |= wgs_x_point<KIND>(p, e * NQ3 + lane, F, Ji, wd, s);
+    } else if constexpr (KIND == WGS_KIND_RECORD) {
+      s.rec = p.scratch_pt + e * (int64_t)(WGS_REC_FIELDS * NQ3) + lane;
     } else {
       // J2: the material was evaluated by tensor_point_kernel
       PointResult<3> w;
@@ -868,13 +928,17 @@ inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a) {
   a.n_units_u = a.box_n[0];
   a.n_units_v = a.box_n[1];
   const size_t lds = WgsLds::total * sizeof(double);
-  if (h->mat.m.kind != MIMI_HIP_MAT_NEOHOOKEAN) {
-    h->scratch_pt.resize((size_t)h->n_el * WGS_PT_FIELDS * 64);
+  const int kind = h->mat.m.kind;
+  const bool record = kind != MIMI_HIP_MAT_NEOHOOKEAN && kind != MIMI_HIP_MAT_J2;
+  if (kind != MIMI_HIP_MAT_NEOHOOKEAN) {
+    h->scratch_pt.resize((size_t)h->n_el * (record ? WGS_REC_FIELDS : WGS_PT_FIELDS) * 64);
     a.scratch_pt = h->scratch_pt.ptr;
-    hipLaunchKernelGGL(tensor_point_kernel, dim3((unsigned)((h->n_el + 3) / 4)), dim3(256), 0, h->stream, a, (int)h->n_el);
+    hipLaunchKernelGGL(record ? tensor_point_kernel<1> : tensor_point_kernel<0>, dim3((unsigned)((h->n_el + 3) / 4)), dim3(256), 0,
+                       h->stream, a, (int)h->n_el);
     MH_HIP(hipGetLastError());
   }
-  auto kernel = h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN ? tensor_wgs_kernel<MIMI_HIP_MAT_NEOHOOKEAN> : tensor_wgs_kernel<MIMI_HIP_MAT_J2>;
+  auto kernel = kind == MIMI_HIP_MAT_NEOHOOKEAN ? tensor_wgs_kernel<MIMI_HIP_MAT_NEOHOOKEAN>
+                : record ? tensor_wgs_kernel<WGS_KIND_RECORD> : tensor_wgs_kernel<MIMI_HIP_MAT_J2>;
   ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
   hipLaunchKernelGGL(kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
   MH_HIP(hipGetLastError());

@@ -542,8 +542,17 @@ static int j2linear_stress(const oracle_material* m, int dim, int accumulate, do
   const double eta_norm = norm_d(eta, dim);
   const double q = sqrt(3.0 / 2.0) * eta_norm;
   const double phi = q - (m->lin_sigma_y + m->lin_isotropic_hardening * *eqps);
+  /* by-products for the closed-form tangent (exact_tangent, J2 branch, with the relative stress eta in the place of the
+   * trial deviator and the constant hardening slope) */
+  memcpy(w->s_trial, eta, sizeof(eta));
+  w->q = q;
+  w->plastic = 0;
+  w->delta = 0;
+  w->hprime = m->lin_kinematic_hardening + m->lin_isotropic_hardening;
   if (phi > 0.) {
     const double inc = phi / (3. * m->G + m->lin_kinematic_hardening + m->lin_isotropic_hardening);
+    w->plastic = 1;
+    w->delta = inc;
     for (int i = 0; i < dd; ++i) eta[i] *= 1. / eta_norm;
     if (!accumulate) {
       for (int i = 0; i < dd; ++i) s[i] += -sqrt(6.0) * m->G * inc * eta[i];
@@ -557,6 +566,7 @@ static int j2linear_stress(const oracle_material* m, int dim, int accumulate, do
     double sigma[9];
     for (int i = 0; i < dd; ++i) sigma[i] = s[i];
     for (int i = 0; i < dim; ++i) M(sigma, i, i) += p;
+    memcpy(w->sigma, sigma, sizeof(sigma));
     pk1_from_sigma(dim, sigma, w);
   }
   return 0;
@@ -843,7 +853,7 @@ static int evaluate_pk1(const oracle_domain* D, int e, int q, point_work* w) {
 
 static void point_tangent(const oracle_domain* D, long pt, const point_work* w, double* A) {
   const int dd = D->dim * D->dim;
-  if (D->mat.kind == MAT_NEOHOOKEAN || D->mat.kind == MAT_J2) {
+  if (D->mat.kind == MAT_NEOHOOKEAN || D->mat.kind == MAT_J2 || D->mat.kind == MAT_J2LINEAR) {
     exact_tangent(&D->mat, D->dim, w, A);
     return;
   }
@@ -1090,7 +1100,8 @@ int oracle_point_pk1(const oracle_material* m, int dim, double dt, const double*
     if (state2) memcpy(m2, state2, sizeof(double) * dim * dim);
     status = other_material_stress(m, dim, dt, 0, 0, m1, m2, &eqps, &temperature, &w);
     memcpy(P, w.P, sizeof(double) * dim * dim);
-    if (A) difference_tangent(m, dim, dt, m1, m2, &eqps, &temperature, &w, A);
+    if (A && m->kind == MAT_J2LINEAR) exact_tangent(m, dim, &w, A);
+    else if (A) difference_tangent(m, dim, dt, m1, m2, &eqps, &temperature, &w, A);
     return status;
   } else {
     double ps[9];

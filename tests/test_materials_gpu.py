@@ -22,7 +22,8 @@ def test_other_materials_parity(matname, block):
     from oracle import ref_path as rp
     n_el, p, lengths = block
     P, D, G = make_pair(n_el, p, lengths, matname, "bspline")
-    assert G.path_ == 0                     # these materials run on the general kernels
+    # 3-D p = 2: the two-phase tensor kernels through the tangent record of the material pre-pass; else general kernels
+    assert G.path_ == (1 if (len(n_el) == 3 and p == 2) else 0)
     D.set_dt(0.5)
     G.dt_ = 0.5
     u = synthetic_u(P, scale=0.04)
@@ -51,6 +52,43 @@ def test_other_materials_parity(matname, block):
         if matname != "j2linear":
             assert np.abs(G.State("temperature") - D.temperature).max() < 1e-9
         u = 1.25 * u
+
+
+@pytest.mark.parametrize("matname", MATS)
+def test_other_materials_medium_block(matname):
+    """1536 elements, columns of 8, through the record path of the nine-block tensor kernel (every lane / carry /
+    gather case), then the same handle family on the general kernels (MIMI_HIP_FORCE_GENERAL is read at create time)."""
+    import os
+    from oracle import ref_path as rp
+    P, D, G = make_pair((16, 12, 8), 2, [4.0, 3.0, 2.0], matname, "bspline")
+    assert G.path_ == 1
+    D.set_dt(0.25)
+    G.dt_ = 0.25
+    u = synthetic_u(P, scale=0.01)
+    r_o, A_o = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    D.add_domain_residual_and_grad(u, 1.0, r_o, A_o, rp.TANGENT_EXACT)
+    os.environ["MIMI_HIP_FORCE_GENERAL"] = "1"
+    try:
+        _, _, G2 = make_pair((16, 12, 8), 2, [4.0, 3.0, 2.0], matname, "bspline")
+    finally:
+        del os.environ["MIMI_HIP_FORCE_GENERAL"]
+    assert G2.path_ == 0
+    G2.dt_ = 0.25
+    for g in (G, G2):
+        r_g, A_g = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+        g.AddDomainResidualAndGrad(u, 1.0, r_g, A_g)
+        assert relmax(r_g, r_o) < 1e-12
+        assert relmax(A_g, A_o) < 1e-6
+        r2 = np.zeros(P.n_vdofs)
+        g.AddDomainResidual(u, r2)
+        assert relmax(r2, r_o) < 1e-12
+    if matname != "stvk":
+        D.domain_post_time_advance(u)
+        for g in (G, G2):
+            g.DomainPostTimeAdvance(u)
+            assert np.abs(g.State("accumulated_plastic_strain") - D.eqps).max() < 1e-10
+            assert np.abs(g.State("plastic_strain") - D.plastic_strain).max() < 1e-10
+        assert D.eqps.max() > 1e-3
 
 
 @pytest.mark.parametrize("matname", ["j2simo", "j2log"])

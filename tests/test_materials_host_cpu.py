@@ -47,6 +47,7 @@ def random_state(name, dim, rng, fresh):
         ep = sym(0.01 * rng.standard_normal((dim, dim)))
         ep -= np.trace(ep) / dim * eye
         beta = sym(0.5 * rng.standard_normal((dim, dim))) if name == "j2linear" else np.zeros((dim, dim))
+        beta -= np.trace(beta) / dim * eye      # the back stress evolves along the (trace-free) relative stress
         return ep, beta, 0.02
     if name == "j2simo":
         g = eye + 0.02 * rng.standard_normal((dim, dim))
