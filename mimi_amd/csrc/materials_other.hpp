@@ -18,6 +18,8 @@
 // eigen-decomposition of the value part.
 #pragma once
 
+#include <type_traits>
+
 #include "materials.hpp"
 
 namespace mimi_hip {
@@ -214,26 +216,32 @@ MH_DEV void sym_exp(const double* A, double* out) {
   q_diag_qt<DIM>(Q, lam, out);
 }
 
+// What the value pass (T = double) of a point leaves for its derivative passes (T = Dual): the return-map increment
+// (solved once) and the eigen-decomposition of the logarithmic strain's argument.
+struct OtherCache {
+  double delta, hprime;
+  bool plastic;
+  double lam[3], Q[9];
+};
+
 // E = 1/2 log(C), C symmetric positive definite (material_utils.hpp:91-114 LogarithmicStrain)
 template<int DIM>
-MH_DEV void half_log_sym(const double* C, double* E) {
-  double lam[DIM], Q[DIM * DIM];
-  sym_eig<DIM>(C, lam, Q);
+MH_DEV void half_log_sym(const double* C, double* E, OtherCache& cc) {
+  double f[DIM];
+  sym_eig<DIM>(C, cc.lam, cc.Q);
 #pragma unroll
-  for (int i = 0; i < DIM; ++i) lam[i] = 0.5 * log(lam[i]);
-  q_diag_qt<DIM>(Q, lam, E);
+  for (int i = 0; i < DIM; ++i) f[i] = 0.5 * log(cc.lam[i]);
+  q_diag_qt<DIM>(cc.Q, f, E);
 }
 
 // ... and its directional derivative: dE = Q [ (Q^T dC Q) o Gamma ] Q^T, Gamma_ab = (f(la) - f(lb)) / (la - lb)
 template<int DIM>
-MH_DEV void half_log_sym(const Dual* C, Dual* E) {
-  double Cv[DIM * DIM], dC[DIM * DIM], lam[DIM], Q[DIM * DIM], B[DIM * DIM], W[DIM * DIM], f[DIM];
+MH_DEV void half_log_sym(const Dual* C, Dual* E, OtherCache& cc) {
+  double Cv[DIM * DIM], dC[DIM * DIM], B[DIM * DIM], W[DIM * DIM], f[DIM];
+  const double* lam = cc.lam;   // of the value part, from the value pass
+  const double* Q = cc.Q;
 #pragma unroll
-  for (int i = 0; i < DIM * DIM; ++i) {
-    Cv[i] = C[i].v;
-    dC[i] = C[i].d;
-  }
-  sym_eig<DIM>(Cv, lam, Q);
+  for (int i = 0; i < DIM * DIM; ++i) dC[i] = C[i].d;
   mat_mul_t<DIM, true, false>(Q, dC, W);   // Q^T dC
   mat_mul_t<DIM, false, false>(W, Q, B);   // Q^T dC Q
 #pragma unroll
@@ -262,8 +270,14 @@ MH_DEV Dual ad_implicit_delta(double delta, Dual a, Dual b, double hprime, doubl
 
 template<class T>
 MH_DEV T return_map_increment(const MaterialDev& md, double dt, double eqps_old, double temperature, T a, T b,
-                              bool& plastic, int& status) {
+                              bool& plastic, int& status, OtherCache& cc) {
   const mimi_hip_material& m = md.m;
+  if constexpr (!std::is_same<T, double>::value) {
+    // derivative pass: the increment of the value pass, differentiated implicitly
+    plastic = cc.plastic;
+    if (!plastic) return ad_from<T>(0.0);
+    return ad_implicit_delta(cc.delta, a, b, cc.hprime, 0.0, 0.0);
+  }
   ReturnMapCtx c{eqps_old, ad_v(a), thermo_contribution(md, temperature), dt, ad_v(b)};
   const double tolerance = md.sigma_y_ref * 1.e-10;
   plastic = false;
@@ -274,8 +288,12 @@ MH_DEV T return_map_increment(const MaterialDev& md, double dt, double eqps_old,
     const Dual H = hardening_evaluate(m, Dual{c.eqps_old + delta, 1.0});
     const double rc = rate_contribution(m, delta / dt);
     const double hprime = H.d * rc * c.thermo + H.v * rate_contribution_derivative(m, delta / dt) / dt * c.thermo;
+    cc.plastic = true;
+    cc.delta = delta;
+    cc.hprime = hprime;
     return ad_implicit_delta(delta, a, b, hprime, 0.0, 0.0);
   }
+  cc.plastic = false;
   return ad_from<T>(0.0);
 }
 
@@ -380,7 +398,7 @@ MH_DEV void j2linear_stress(const mimi_hip_material& m, const T* F, OtherState& 
 }
 
 template<int DIM, bool ACCUMULATE, class T>
-MH_DEV int j2simo_stress(const MaterialDev& md, double dt, const T* F, OtherState& st, T* P) {
+MH_DEV int j2simo_stress(const MaterialDev& md, double dt, const T* F, OtherState& st, T* P, OtherCache& cc) {
   const mimi_hip_material& m = md.m;
   constexpr int DD = DIM * DIM;
   int status = 0;
@@ -414,7 +432,7 @@ MH_DEV int j2simo_stress(const MaterialDev& md, double dt, const T* F, OtherStat
   for (int i = 1; i < DD; ++i) s_effective = s_effective + Np[i] * s[i];
   const T be_trace = trace_t<DIM>(be);
   bool plastic;
-  const T delta = return_map_increment<T>(md, dt, st.eqps, st.temperature, s_effective, be_trace * m.G, plastic, status);
+  const T delta = return_map_increment<T>(md, dt, st.eqps, st.temperature, s_effective, be_trace * m.G, plastic, status, cc);
   if (plastic) {
 #pragma unroll
     for (int i = 0; i < DD; ++i) be[i] = be[i] - Np[i] * (delta * be_trace * (2. / 3.));
@@ -441,19 +459,19 @@ MH_DEV int j2simo_stress(const MaterialDev& md, double dt, const T* F, OtherStat
 }
 
 template<int DIM, bool ACCUMULATE, class T>
-MH_DEV int j2log_stress(const MaterialDev& md, double dt, const T* F, OtherState& st, T* P) {
+MH_DEV int j2log_stress(const MaterialDev& md, double dt, const T* F, OtherState& st, T* P, OtherCache& cc) {
   const mimi_hip_material& m = md.m;
   constexpr int DD = DIM * DIM;
   int status = 0;
   T F_e[DD], C_e[DD], E_e[DD], s[DD];
   mat_mul_t<DIM, false, false>(F, st.m1, F_e);
   mat_mul_t<DIM, true, false>(F_e, F_e, C_e);
-  half_log_sym<DIM>(C_e, E_e);
+  half_log_sym<DIM>(C_e, E_e, cc);
   const T p = trace_t<DIM>(E_e) * m.K;
   dev_t<DIM>(E_e, 2.0 * m.G, s);
   const T q = norm_t<DIM>(s) * sqrt(1.5);
   bool plastic;
-  const T delta = return_map_increment<T>(md, dt, st.eqps, st.temperature, q, ad_from<T>(3.0 * m.G), plastic, status);
+  const T delta = return_map_increment<T>(md, dt, st.eqps, st.temperature, q, ad_from<T>(3.0 * m.G), plastic, status, cc);
   if (plastic) {
     // N_p = 1.5 / q s (trial);  s -= 2 G delta N_p
     if constexpr (ACCUMULATE) {
@@ -482,14 +500,14 @@ MH_DEV int j2log_stress(const MaterialDev& md, double dt, const T* F, OtherState
 }
 
 template<int DIM, bool ACCUMULATE, class T>
-MH_DEV int other_stress(const MaterialDev& md, double dt, const T* F, OtherState& st, T* P) {
+MH_DEV int other_stress(const MaterialDev& md, double dt, const T* F, OtherState& st, T* P, OtherCache& cc) {
   switch (md.m.kind) {
   case MIMI_HIP_MAT_STVK:
     if constexpr (!ACCUMULATE) stvk_stress<DIM>(md.m, F, P);
     return 0;
   case MIMI_HIP_MAT_J2LINEAR: j2linear_stress<DIM, ACCUMULATE>(md.m, F, st, P); return 0;
-  case MIMI_HIP_MAT_J2SIMO: return j2simo_stress<DIM, ACCUMULATE>(md, dt, F, st, P);
-  default: return j2log_stress<DIM, ACCUMULATE>(md, dt, F, st, P);
+  case MIMI_HIP_MAT_J2SIMO: return j2simo_stress<DIM, ACCUMULATE>(md, dt, F, st, P, cc);
+  default: return j2log_stress<DIM, ACCUMULATE>(md, dt, F, st, P, cc);
   }
 }
 
@@ -501,14 +519,15 @@ MH_DEV int evaluate_other(const MaterialDev& md, double dt, const StateView& sv,
   constexpr int DD = DIM * DIM;
   OtherState st;
   other_state_load<DIM>(md, sv, pt, st);
-  int status = other_stress<DIM, false>(md, dt, F, st, P);
+  OtherCache cc;
+  int status = other_stress<DIM, false>(md, dt, F, st, P, cc);
   if (A) {
     for (int jL = 0; jL < DD; ++jL) {   // F(j, L) is stored at j + L*DIM
       Dual Fd[DD], Pd[DD];
 #pragma unroll
       for (int k = 0; k < DD; ++k) Fd[k] = Dual{F[k], k == jL ? 1.0 : 0.0};
       int ignored = 0;
-      ignored |= other_stress<DIM, false>(md, dt, Fd, st, Pd);
+      ignored |= other_stress<DIM, false>(md, dt, Fd, st, Pd, cc);
       const int j = jL % DIM, L = jL / DIM;
 #pragma unroll
       for (int i = 0; i < DIM; ++i)
@@ -525,7 +544,8 @@ MH_DEV int accumulate_other(const MaterialDev& md, double dt, const StateView& s
   OtherState st;
   other_state_load<DIM>(md, sv, pt, st);
   double unused[DIM * DIM];
-  const int status = other_stress<DIM, true>(md, dt, F, st, unused);
+  OtherCache cc;
+  const int status = other_stress<DIM, true>(md, dt, F, st, unused, cc);
   other_state_store<DIM>(md, sv, pt, st);
   return status;
 }
