@@ -154,7 +154,9 @@ int mimi_hip_domain_post_time_advance(mimi_hip_domain_t h, const double* u);
 
 /* material state access (MaterialState of materials.hpp:278-286), for tests / output:
  * what = 0 accumulated plastic strain [n_el][n_q]; 1 temperature [n_el][n_q];
- *        2 plastic strain [n_el][n_q][dim*dim] (column-major per point) */
+ *        2 the material's first state matrix [n_el][n_q][dim*dim] (column-major per point): plastic strain (J2,
+ *          J2Linear), be_old (J2Simo), Fp_inv (J2Log);
+ *        3 its second one: beta (J2Linear, materials.hpp:158), F_old (J2Simo, materials.hpp:434) */
 int mimi_hip_domain_get_state(mimi_hip_domain_t h, int what, double* out, int64_t capacity);
 int mimi_hip_domain_reset_state(mimi_hip_domain_t h);
 /* sizes: what = 0 n_elements, 1 n_quad, 2 n_dof, 3 nnz, 4 n_vdofs, 5 path (0 general, 1 tensor) */
