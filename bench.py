@@ -274,6 +274,18 @@ def main():
                          "algorithmic_bytes_per_element": balg, "elements_per_launch": local_elements,
                          "avg_launch_ms": kernel_ms},
         }
+        if not args.residual_only and patch.dim == 3:
+            # second view of the same step (the tangent contraction is fp64-matrix-bound before it is HBM-bound):
+            # the ALGORITHMIC flops of the dense B^T A B form (no symmetry, no sum factorisation) over the step time.  The
+            # kernels execute several times fewer (sum factorisation; symmetric half for hyperelastic materials), so this
+            # ratio may exceed 1 -- it says how far the step is below the 9.7 ms the dense form needs at the matrix peak.
+            n_dof, n_q = (p + 1) ** 3, (p + 2) ** 3
+            f_alg = n_q * (4 * n_dof * 9 + 200 + 2 * (n_dof * 81 + (3 * n_dof) ** 2 * 3))
+            tf = f_alg * local_elements / (kernel_ms * 1e-3) / 1e12
+            out["roofline_fp64"] = {"bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
+                                    "algorithmic_flops_per_element": f_alg,
+                                    "note": "dense-form flops of SURVEY 8d over the same step time; the kernels execute fewer "
+                                            "(sum factorisation, symmetric half): see DESIGN.md 4.1 for the issued fp64 work"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, material)
         else:

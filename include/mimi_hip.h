@@ -217,6 +217,26 @@ int mimi_hip_contact_last_history(mimi_hip_contact_t h, double* out5);
 /* nodal average_pressure_ (mortar_contact.hpp:59), [n_marked]; returns n_marked via *n */
 int mimi_hip_contact_get_pressure(mimi_hip_contact_t h, double* out, int64_t capacity, int64_t* n);
 
+/* ---- the callers' steps around the assembly, device-resident ---------------------------
+ * One handle per CSR pattern (rowptr / col host or device; device arrays are used in place and must outlive the
+ * handle) and list of essential dofs (forms::Nonlinear's zero_dofs). */
+typedef struct mimi_hip_linear_s* mimi_hip_linear_t;
+int mimi_hip_linear_create(int64_t n, const int64_t* csr_rowptr, const int32_t* csr_col, const int64_t* ess_dofs,
+                           int64_t n_ess, int device, mimi_hip_linear_t* out);
+int mimi_hip_linear_destroy(mimi_hip_linear_t h);
+/* NULL = the handle's own stream */
+int mimi_hip_linear_set_stream(mimi_hip_linear_t h, void* hip_stream);
+/* forms::Nonlinear::AddMult / AddMultGrad tail (forms/nonlinear.hpp:76-80,112-115): r[ess] = 0 (r may be NULL);
+ * A.EliminateRowCol(ess, DIAG_ONE) on the CSR values (A_values may be NULL).  Host or device pointers. */
+int mimi_hip_linear_eliminate(mimi_hip_linear_t h, double* r, double* A_values);
+/* The reference's iterative linear solver (py/py_nonlinear_solid.cpp:329-339: mfem::GMRESSolver + mfem::DSmoother,
+ * rel 1e-8, abs 1e-12, 300 iterations; kdim <= 0 = mfem's default 50): x = 0 start, left-preconditioned restarted
+ * GMRES, modified Gram-Schmidt, stops when the preconditioned residual estimate <= max(rel_tol * ||M b||, abs_tol).
+ * use_jacobi = 0 runs it unpreconditioned.  A_values / b / x host or device. */
+int mimi_hip_linear_gmres(mimi_hip_linear_t h, const double* A_values, const double* b, double* x, double rel_tol,
+                          double abs_tol, int max_iter, int kdim, int use_jacobi, int32_t* iterations,
+                          double* final_norm, int32_t* converged);
+
 #ifdef __cplusplus
 }
 #endif

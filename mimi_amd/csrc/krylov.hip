@@ -1,0 +1,468 @@
+// Device-resident linear solve of the Newton step and the caller-side eliminations around it (SURVEY 8 rows a10,
+// f-4): what the reference does after the assembly returns.
+//
+//   forms::Nonlinear::AddMult / AddMultGrad  (forms/nonlinear.hpp:76-80,112-115): r[ess] = 0;
+//       grad.EliminateRowCol(ess, DIAG_ONE) -- serial loops over the essential dofs there, one kernel each here.
+//   PyNonlinearSolid::Setup, "use_iterative_solver" (py/py_nonlinear_solid.cpp:329-339): mfem::GMRESSolver with an
+//       mfem::DSmoother (Jacobi) preconditioner, rel 1e-8, abs 1e-12, 300 iterations.  MFEM is an absent, un-pinned
+//       submodule of the reference; what is restated here is its published algorithm (mfem linalg/solvers.cpp,
+//       GMRESSolver::Mult): left-preconditioned restarted GMRES(m = 50), modified Gram-Schmidt, Givens rotations,
+//       convergence on the preconditioned residual  |s_{i+1}| <= max(rel_tol * ||M r_0||, abs_tol).
+//
+// Everything vector-sized stays in HBM; per Arnoldi step the host sees one Hessenberg column.  Reductions are
+// deterministic: a fixed grid writes per-block partial sums, every consumer adds them in the same order.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mimi_hip.h"
+#include "common.hpp"
+
+namespace mimi_hip {
+
+constexpr int KR_BLOCKS = 512;    // reduction grid (two blocks per CU), also the number of partial sums per dot
+constexpr int KR_THREADS = 256;
+
+__device__ __forceinline__ double kr_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// sum over the block, result valid in thread 0
+__device__ __forceinline__ double kr_block_sum(double v, double* sh) {
+  v = kr_wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < KR_THREADS / 64; ++w) t += sh[w];
+  __syncthreads();
+  return t;
+}
+
+// the scalar behind KR_BLOCKS partial sums, same order for every reader (every thread gets it)
+__device__ __forceinline__ double kr_total(const double* partial, double* sh) {
+  double v = 0.0;
+  for (int k = threadIdx.x; k < KR_BLOCKS; k += KR_THREADS) v += partial[k];
+  v = kr_wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < KR_THREADS / 64; ++w) t += sh[w];
+  __syncthreads();
+  return t;
+}
+
+// y = Dinv (A x) (or A x when dinv == nullptr; y = Dinv (b - A x) when b != nullptr): one wave per row
+__global__ __launch_bounds__(256) void kr_spmv_kernel(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                      const double* __restrict__ val, const double* __restrict__ x,
+                                                      const double* __restrict__ b, const double* __restrict__ dinv,
+                                                      double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t beg = rowptr[row], end = rowptr[row + 1];
+  double s = 0.0;
+  for (int64_t k = beg + lane; k < end; k += 64) s += val[k] * x[col[k]];
+  s = kr_wave_sum(s);
+  if (lane == 0) {
+    if (b) s = b[row] - s;
+    y[row] = dinv ? dinv[row] * s : s;
+  }
+}
+
+// dinv[row] = 1 / A(row, row)   (mfem::DSmoother, type 0, scale 1)
+__global__ void kr_diag_kernel(int64_t n, const int64_t* __restrict__ rowptr, const int64_t* __restrict__ diag_pos,
+                               const double* __restrict__ val, double* __restrict__ dinv) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < n) dinv[row] = 1.0 / val[rowptr[row] + diag_pos[row]];
+}
+
+__global__ void kr_diag_pos_kernel(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                   int64_t* __restrict__ diag_pos, int* __restrict__ status) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  int64_t lo = rowptr[row], hi = rowptr[row + 1];
+  const int64_t base = lo;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (col[mid] < row) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= rowptr[row + 1] || col[lo] != row) {
+    atomicOr(status, 1);
+    diag_pos[row] = 0;
+    return;
+  }
+  diag_pos[row] = lo - base;
+}
+
+// one modified Gram-Schmidt stage: w -= h_prev * v_prev (h_prev = total of partial_prev; skipped when v_prev is null),
+// then partial_out[block] = sum_block w * v_next (v_next == w itself gives the squared norm)
+__global__ __launch_bounds__(KR_THREADS) void kr_mgs_kernel(int64_t n, double* __restrict__ w, const double* __restrict__ v_prev,
+                                                            const double* __restrict__ partial_prev, const double* v_next,
+                                                            double* __restrict__ partial_out) {
+  __shared__ double sh[KR_THREADS / 64];
+  double h = 0.0;
+  if (v_prev) h = kr_total(partial_prev, sh);
+  double acc = 0.0;
+  const bool self = (v_next == w);
+  for (int64_t i = (int64_t)blockIdx.x * KR_THREADS + threadIdx.x; i < n; i += (int64_t)KR_BLOCKS * KR_THREADS) {
+    double wi = w[i];
+    if (v_prev) {
+      wi -= h * v_prev[i];
+      w[i] = wi;
+    }
+    acc += wi * (self ? wi : v_next[i]);
+  }
+  const double t = kr_block_sum(acc, sh);
+  if (threadIdx.x == 0) partial_out[blockIdx.x] = t;
+}
+
+// v = w / sqrt(total(partial)); scalars[slot] for the host: the totals of n_cols partial arrays
+__global__ __launch_bounds__(KR_THREADS) void kr_normalize_kernel(int64_t n, const double* __restrict__ w,
+                                                                  const double* __restrict__ partial_norm2, double* __restrict__ v) {
+  __shared__ double sh[KR_THREADS / 64];
+  const double nrm = sqrt(kr_total(partial_norm2, sh));
+  const double inv = nrm > 0.0 ? 1.0 / nrm : 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * KR_THREADS + threadIdx.x; i < n; i += (int64_t)KR_BLOCKS * KR_THREADS) v[i] = w[i] * inv;
+}
+
+// totals[c] = total of partial array c, c < n_cols (one block per column; same order as kr_total)
+__global__ __launch_bounds__(KR_THREADS) void kr_totals_kernel(const double* __restrict__ partials, double* __restrict__ totals) {
+  __shared__ double sh[KR_THREADS / 64];
+  const double t = kr_total(partials + (int64_t)blockIdx.x * KR_BLOCKS, sh);
+  if (threadIdx.x == 0) totals[blockIdx.x] = t;
+}
+
+// x += sum_k y[k] V[k]
+__global__ __launch_bounds__(KR_THREADS) void kr_update_kernel(int64_t n, int k_count, const double* __restrict__ V, int64_t ldv,
+                                                               const double* __restrict__ y, double* __restrict__ x) {
+  for (int64_t i = (int64_t)blockIdx.x * KR_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * KR_THREADS) {
+    double s = x[i];
+    for (int k = 0; k < k_count; ++k) s += y[k] * V[(int64_t)k * ldv + i];
+    x[i] = s;
+  }
+}
+
+// forms/nonlinear.hpp:76-80: r[ess] = 0
+__global__ void kr_zero_entries_kernel(int64_t n_ess, const int64_t* __restrict__ ess, double* __restrict__ r) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n_ess) r[ess[k]] = 0.0;
+}
+
+// SparseMatrix::EliminateRowCol(rc, DIAG_ONE) for every essential dof (forms/nonlinear.hpp:112-115): one wave per row;
+// an entry goes when its row or its column is essential, the diagonal of an essential row becomes 1
+__global__ __launch_bounds__(256) void kr_eliminate_kernel(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                           const unsigned char* __restrict__ is_ess, double* __restrict__ val) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const bool row_ess = is_ess[row];
+  for (int64_t k = rowptr[row] + lane; k < rowptr[row + 1]; k += 64) {
+    const int32_t c = col[k];
+    if (row_ess) val[k] = (c == row) ? 1.0 : 0.0;
+    else if (is_ess[c]) val[k] = 0.0;
+  }
+}
+
+__global__ void kr_mark_kernel(int64_t n_ess, const int64_t* __restrict__ ess, unsigned char* __restrict__ is_ess) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n_ess) is_ess[ess[k]] = 1;
+}
+
+}  // namespace mimi_hip
+
+using namespace mimi_hip;
+
+struct mimi_hip_linear_s {
+  int device = 0;
+  int64_t n = 0, nnz = 0;
+  int kdim = 50;
+  hipStream_t stream = nullptr, own_stream = nullptr;
+  DeviceBuffer<int64_t> rowptr_own, diag_pos, ess;
+  DeviceBuffer<int32_t> col_own;
+  const int64_t* rowptr = nullptr;
+  const int32_t* col = nullptr;
+  DeviceBuffer<unsigned char> is_ess;
+  int64_t n_ess = 0;
+  DeviceBuffer<double> dinv, V, w, r, partials, totals, ycoef, stage_val, stage_b, stage_x;
+  int* status_dev = nullptr;
+  ~mimi_hip_linear_s() {
+    if (status_dev) (void)hipFree(status_dev);
+    if (own_stream) (void)hipStreamDestroy(own_stream);
+  }
+};
+
+namespace {
+
+template<typename F>
+int guarded_k(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return 1;
+  } catch (...) {
+    set_last_error("unknown error");
+    return 1;
+  }
+}
+
+void spmv(mimi_hip_linear_s* h, const double* val, const double* x, const double* b, const double* dinv, double* y) {
+  hipLaunchKernelGGL(kr_spmv_kernel, dim3((unsigned)((h->n + 3) / 4)), dim3(256), 0, h->stream, h->n, h->rowptr, h->col, val, x, b,
+                     dinv, y);
+  MH_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+extern "C" {
+
+int mimi_hip_linear_create(int64_t n, const int64_t* csr_rowptr, const int32_t* csr_col, const int64_t* ess_dofs,
+                           int64_t n_ess, int device, mimi_hip_linear_t* out) {
+  return guarded_k([&] {
+    if (!out || !csr_rowptr || !csr_col || n < 1) fail("null / empty argument");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+      fail("libmimi_hip: no HIP device visible -- this library has no CPU fallback");
+    if (device < 0 || device >= count) fail("device %d out of range (%d visible)", device, count);
+    auto h = std::make_unique<mimi_hip_linear_s>();
+    h->device = device;
+    h->n = n;
+    MH_HIP(hipSetDevice(device));
+    MH_HIP(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    if (is_device_pointer(csr_rowptr)) {
+      h->rowptr = csr_rowptr;
+    } else {
+      h->rowptr_own.assign(csr_rowptr, (size_t)n + 1, h->stream);
+      h->rowptr = h->rowptr_own.ptr;
+    }
+    int64_t nnz = 0;
+    MH_HIP(hipMemcpy(&nnz, h->rowptr + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+    h->nnz = nnz;
+    if (is_device_pointer(csr_col)) {
+      h->col = csr_col;
+    } else {
+      h->col_own.assign(csr_col, (size_t)nnz, h->stream);
+      h->col = h->col_own.ptr;
+    }
+    MH_HIP(hipMalloc(reinterpret_cast<void**>(&h->status_dev), sizeof(int)));
+    MH_HIP(hipMemsetAsync(h->status_dev, 0, sizeof(int), h->stream));
+    h->diag_pos.resize((size_t)n);
+    hipLaunchKernelGGL(kr_diag_pos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, n, h->rowptr, h->col,
+                       h->diag_pos.ptr, h->status_dev);
+    MH_HIP(hipGetLastError());
+    int status = 0;
+    MH_HIP(hipMemcpyAsync(&status, h->status_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    MH_HIP(hipStreamSynchronize(h->stream));
+    if (status) fail("CSR pattern has a row without a diagonal entry");
+    h->is_ess.resize((size_t)n);
+    MH_HIP(hipMemsetAsync(h->is_ess.ptr, 0, (size_t)n, h->stream));
+    h->n_ess = n_ess;
+    if (n_ess > 0) {
+      if (!ess_dofs) fail("null essential dof list");
+      h->ess.assign(ess_dofs, (size_t)n_ess, h->stream);
+      hipLaunchKernelGGL(kr_mark_kernel, dim3((unsigned)((n_ess + 255) / 256)), dim3(256), 0, h->stream, n_ess, h->ess.ptr,
+                         h->is_ess.ptr);
+      MH_HIP(hipGetLastError());
+    }
+    MH_HIP(hipStreamSynchronize(h->stream));
+    *out = h.release();
+  });
+}
+
+int mimi_hip_linear_destroy(mimi_hip_linear_t h) {
+  return guarded_k([&] {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    delete h;
+  });
+}
+
+int mimi_hip_linear_set_stream(mimi_hip_linear_t h, void* stream) {
+  return guarded_k([&] {
+    if (!h) fail("null handle");
+    h->stream = stream ? reinterpret_cast<hipStream_t>(stream) : h->own_stream;
+  });
+}
+
+int mimi_hip_linear_eliminate(mimi_hip_linear_t h, double* r, double* A_values) {
+  return guarded_k([&] {
+    if (!h) fail("null handle");
+    MH_HIP(hipSetDevice(h->device));
+    if (h->n_ess == 0) return;
+    if (r) {
+      Mirror<double> mr = Mirror<double>::inout(r, (size_t)h->n, h->stage_b, h->stream);
+      hipLaunchKernelGGL(kr_zero_entries_kernel, dim3((unsigned)((h->n_ess + 255) / 256)), dim3(256), 0, h->stream, h->n_ess,
+                         h->ess.ptr, mr.dev);
+      MH_HIP(hipGetLastError());
+      mr.finish(h->stream);
+      if (mr.host) MH_HIP(hipStreamSynchronize(h->stream));
+    }
+    if (A_values) {
+      Mirror<double> mA = Mirror<double>::inout(A_values, (size_t)h->nnz, h->stage_val, h->stream);
+      hipLaunchKernelGGL(kr_eliminate_kernel, dim3((unsigned)((h->n + 3) / 4)), dim3(256), 0, h->stream, h->n, h->rowptr, h->col,
+                         h->is_ess.ptr, mA.dev);
+      MH_HIP(hipGetLastError());
+      mA.finish(h->stream);
+      if (mA.host) MH_HIP(hipStreamSynchronize(h->stream));
+    }
+  });
+}
+
+int mimi_hip_linear_gmres(mimi_hip_linear_t h, const double* A_values, const double* b, double* x, double rel_tol, double abs_tol,
+                          int max_iter, int kdim, int use_jacobi, int32_t* iterations, double* final_norm, int32_t* converged) {
+  return guarded_k([&] {
+    if (!h || !A_values || !b || !x) fail("null argument");
+    if (kdim < 1) kdim = 50;   // mfem::GMRESSolver default m
+    MH_HIP(hipSetDevice(h->device));
+    const int64_t n = h->n;
+    hipStream_t s = h->stream;
+    Mirror<double> mA = Mirror<double>::in(A_values, (size_t)h->nnz, h->stage_val, s);
+    Mirror<double> mb = Mirror<double>::in(b, (size_t)n, h->stage_b, s);
+    Mirror<double> mx = Mirror<double>::inout(x, (size_t)n, h->stage_x, s);   // overwritten: iterative_mode == false
+    h->V.resize((size_t)(kdim + 1) * n);
+    h->w.resize((size_t)n);
+    h->r.resize((size_t)n);
+    h->partials.resize((size_t)(kdim + 2) * KR_BLOCKS);
+    h->totals.resize((size_t)(kdim + 2));
+    h->ycoef.resize((size_t)kdim);
+    const double* dinv = nullptr;
+    if (use_jacobi) {
+      h->dinv.resize((size_t)n);
+      hipLaunchKernelGGL(kr_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, h->rowptr, h->diag_pos.ptr, mA.dev,
+                         h->dinv.ptr);
+      MH_HIP(hipGetLastError());
+      dinv = h->dinv.ptr;
+    }
+    double* V = h->V.ptr;
+    double* w = h->w.ptr;
+    double* r = h->r.ptr;
+    double* part = h->partials.ptr;
+    std::vector<double> H((size_t)(kdim + 1) * kdim, 0.0), sv(kdim + 1, 0.0), cs(kdim + 1, 0.0), sn(kdim + 1, 0.0), col(kdim + 2),
+        y(kdim);
+    auto Hat = [&](int i, int j) -> double& { return H[(size_t)i + (size_t)j * (kdim + 1)]; };
+    auto norm_of = [&](const double* vec) -> double {   // vec also goes to `part[0..)` as its squared norm
+      hipLaunchKernelGGL(kr_mgs_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, const_cast<double*>(vec), (const double*)nullptr,
+                         (const double*)nullptr, vec, part);
+      hipLaunchKernelGGL(kr_totals_kernel, dim3(1), dim3(KR_THREADS), 0, s, part, h->totals.ptr);
+      MH_HIP(hipGetLastError());
+      double t = 0.0;
+      MH_HIP(hipMemcpyAsync(&t, h->totals.ptr, sizeof(double), hipMemcpyDeviceToHost, s));
+      MH_HIP(hipStreamSynchronize(s));
+      return std::sqrt(t);
+    };
+    auto update = [&](int k_count) {   // GMRESSolver: Update(x, k, H, s, v)
+      for (int i = k_count - 1; i >= 0; --i) {
+        double t = sv[i];
+        for (int j = i + 1; j < k_count; ++j) t -= Hat(i, j) * y[j];
+        y[i] = t / Hat(i, i);
+      }
+      MH_HIP(hipMemcpyAsync(h->ycoef.ptr, y.data(), sizeof(double) * k_count, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(kr_update_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, k_count, V, n, h->ycoef.ptr, mx.dev);
+      MH_HIP(hipGetLastError());
+      MH_HIP(hipStreamSynchronize(s));   // y is host memory reused by the next cycle
+    };
+    auto finish = [&](int it, double nrm, bool conv) {
+      if (iterations) *iterations = it;
+      if (final_norm) *final_norm = nrm;
+      if (converged) *converged = conv ? 1 : 0;
+      mx.finish(s);
+      MH_HIP(hipStreamSynchronize(s));
+    };
+
+    // x = 0; r = M b
+    MH_HIP(hipMemsetAsync(mx.dev, 0, sizeof(double) * n, s));
+    {
+      // r = M (b - A x) with x = 0
+      spmv(h, mA.dev, mx.dev, mb.dev, dinv, r);
+    }
+    double beta = norm_of(r);
+    double goal = std::fmax(rel_tol * beta, abs_tol);
+    if (beta <= goal) {
+      finish(0, beta, true);
+      return;
+    }
+    int j = 1;
+    while (j <= max_iter) {
+      // v_0 = r / beta (partials of ||r||^2 are in part[0..))
+      hipLaunchKernelGGL(kr_normalize_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, r, part, V);
+      std::fill(sv.begin(), sv.end(), 0.0);
+      sv[0] = beta;
+      int i = 0;
+      for (; i < kdim && j <= max_iter; ++i, ++j) {
+        // w = M A v_i
+        spmv(h, mA.dev, V + (int64_t)i * n, nullptr, dinv, w);
+        // modified Gram-Schmidt: stage k subtracts h_{k-1} v_{k-1} and forms h_k = w . v_k; the last stage forms ||w||^2
+        for (int k = 0; k <= i + 1; ++k) {
+          const double* v_prev = k > 0 ? V + (int64_t)(k - 1) * n : nullptr;
+          const double* p_prev = k > 0 ? part + (int64_t)(k - 1) * KR_BLOCKS : nullptr;
+          const double* v_next = k <= i ? V + (int64_t)k * n : w;
+          hipLaunchKernelGGL(kr_mgs_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, w, v_prev, p_prev, v_next,
+                             part + (int64_t)k * KR_BLOCKS);
+        }
+        hipLaunchKernelGGL(kr_normalize_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, w, part + (int64_t)(i + 1) * KR_BLOCKS,
+                           V + (int64_t)(i + 1) * n);
+        hipLaunchKernelGGL(kr_totals_kernel, dim3(i + 2), dim3(KR_THREADS), 0, s, part, h->totals.ptr);
+        MH_HIP(hipGetLastError());
+        MH_HIP(hipMemcpyAsync(col.data(), h->totals.ptr, sizeof(double) * (i + 2), hipMemcpyDeviceToHost, s));
+        MH_HIP(hipStreamSynchronize(s));
+        for (int k = 0; k <= i; ++k) Hat(k, i) = col[k];
+        Hat(i + 1, i) = std::sqrt(col[i + 1]);
+        // Givens rotations (GMRESSolver: ApplyPlaneRotation / GeneratePlaneRotation)
+        for (int k = 0; k < i; ++k) {
+          const double t = cs[k] * Hat(k, i) + sn[k] * Hat(k + 1, i);
+          Hat(k + 1, i) = -sn[k] * Hat(k, i) + cs[k] * Hat(k + 1, i);
+          Hat(k, i) = t;
+        }
+        {
+          const double dx = Hat(i, i), dy = Hat(i + 1, i);
+          if (dy == 0.0) {
+            cs[i] = 1.0;
+            sn[i] = 0.0;
+          } else if (std::fabs(dy) > std::fabs(dx)) {
+            const double t = dx / dy;
+            sn[i] = 1.0 / std::sqrt(1.0 + t * t);
+            cs[i] = t * sn[i];
+          } else {
+            const double t = dy / dx;
+            cs[i] = 1.0 / std::sqrt(1.0 + t * t);
+            sn[i] = t * cs[i];
+          }
+          Hat(i, i) = cs[i] * dx + sn[i] * dy;
+          Hat(i + 1, i) = 0.0;
+          sv[i + 1] = -sn[i] * sv[i];
+          sv[i] = cs[i] * sv[i];
+        }
+        const double resid = std::fabs(sv[i + 1]);
+        if (resid <= goal) {
+          update(i + 1);
+          finish(j, resid, true);
+          return;
+        }
+      }
+      update(i);
+      // r = M (b - A x)
+      spmv(h, mA.dev, mx.dev, mb.dev, dinv, r);
+      beta = norm_of(r);
+      if (beta <= goal) {
+        finish(j - 1, beta, true);
+        return;
+      }
+    }
+    finish(max_iter, beta, false);
+  });
+}
+
+}  // extern "C"

@@ -28,6 +28,7 @@ import scipy.sparse.linalg as spla
 
 from . import splines
 from .integrators import CSRPattern, MortarContact, NonlinearSolid as NonlinearSolidIntegrator
+from .linear import LinearSolver
 from .splines import BSplinePatch
 
 
@@ -297,6 +298,10 @@ class NonlinearSolid(Solid):
         self._fac = (0.5 - beta / am, af, af * (1.0 - gamma / am), beta * af / am, gamma * af / am, am)  # ode.cpp:5-14
         self._nstate = 0
         self._jac = np.zeros_like(self.mass_)
+        # linear solver (py_nonlinear_solid.cpp:327-343): "use_iterative_solver" -> GMRES + Jacobi on the device
+        # (mimi_amd/linear.py); else a sparse direct solve on the host (UMFPack in the reference, SuperLU here)
+        self.linear_ = LinearSolver(self.pattern_, self.dirichlet_, device=self.device)
+        self.use_iterative_solver_ = bool(rc.get_int("use_iterative_solver", 0))
 
     def configure_newton(self, name, rel_tol, abs_tol, max_iter, iterative_mode):   # py_solid.cpp:334-346
         self._newton = dict(rel_tol=rel_tol, abs_tol=abs_tol, max_iter=int(max_iter), iterative_mode=bool(iterative_mode))
@@ -335,8 +340,7 @@ class NonlinearSolid(Solid):
         self.domain_.AddDomainResidualAndGrad(xt, self._fac0, y, self._jac)
         for c in self.contacts_:
             c.AddBoundaryResidualAndGrad(xt, self._fac0, y, self._jac)
-        y[self.dirichlet_] = 0.0
-        _eliminate_row_col(self.pattern_.rowptr, self.pattern_.col, self._jac, self.dirichlet_)
+        self.linear_.Eliminate(y, self._jac)          # forms/nonlinear.hpp:76-80,112-115
         y -= self.rhs_
         y[self.dirichlet_] = 0.0
         return y, self._jac
@@ -361,7 +365,10 @@ class NonlinearSolid(Solid):
             if not any(improved):
                 x = best_x.copy()
                 break
-            c = spla.splu(self._csr(J).tocsc()).solve(r)
+            if self.use_iterative_solver_:
+                c = self.linear_.Mult(J, r, np.zeros_like(r))
+            else:
+                c = spla.splu(self._csr(J).tocsc()).solve(r)
             q1 = norm
             q3 = np.linalg.norm(self._mult(x - c))
             q2 = np.linalg.norm(self._mult(x - 0.5 * c))

@@ -141,6 +141,38 @@ def test_nonlinear_solid_j2_simo_and_log(golden_dir, matname, refdir, tangent_mo
 
 
 @pytest.mark.gpu
+def test_nonlinear_solid_neohook_iterative_solver(golden_dir):
+    """the reference's "use_iterative_solver" route (py_nonlinear_solid.cpp:329-339): GMRES + Jacobi, here on the device;
+    the golden series is reached through inexact Newton steps as well"""
+    import mimi_amd as mimi
+    from oracle import harness as hz
+    nl = balken(1, 2)
+    mat = mimi.CompressibleOgdenNeoHookean()
+    mat.density = 1
+    mat.viscosity = -1
+    mat.set_young_poisson(2100, 0.3)
+    nl.set_material(mat)
+    rc = mimi.RuntimeCommunication()
+    rc.set_real("ode_coefficient", 0.5)
+    rc.set_int("use_iterative_solver", 1)
+    nl.runtime_communication = rc
+    bc = mimi.BoundaryConditions()
+    bc.initial.dirichlet(2, 0).dirichlet(2, 1)
+    bc.initial.body_force(1, -5)
+    nl.boundary_condition = bc
+    nl.setup(1)
+    assert nl.use_iterative_solver_
+    nl.configure_newton("nonlinear_solid", 1e-12, 1e-8, 10, False)
+    nl.time_step_size = 0.05
+    u = nl.solution_view("displacement", "x").ravel()
+    for i in range(10):
+        nl.step_time2()
+        ref = hz.golden_to_lexicographic(np.genfromtxt(os.path.join(golden_dir, "ref", "neohook_h1_p2", f"x_{i}.txt")))
+        assert np.allclose(u, ref)
+    assert nl.linear_.final_iter_ > 1
+
+
+@pytest.mark.gpu
 def test_3d_cantilever_runs_through_tensor_kernels():
     """cfg1-like plumbing: 3-D p=2 block from cube-nurbs.mesh, one implicit step converges and
     agrees with the same step taken with the reference-FD tangent."""
