@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MIMI_HIP_ABI_VERSION 2
+#define MIMI_HIP_ABI_VERSION 3
 
 /* ---- errors ---------------------------------------------------------------- */
 const char* mimi_hip_last_error(void);
@@ -110,7 +110,7 @@ typedef struct mimi_hip_domain_tables {
 int mimi_hip_domain_create(const mimi_hip_domain_tables* tables, const mimi_hip_material* material,
                            int device, mimi_hip_domain_t* out);
 
-/* Tensor-product B-spline patch description (weights all 1): the library builds the
+/* Tensor-product B-spline / NURBS patch description: the library builds the
  * 1-D basis tables, per-point inverse geometry Jacobians and weights itself
  * (replaces PrepareElementData + PrecomputeElementQuadData, precomputed.cpp:39-149,264-330)
  * and integrates by sum factorisation.  Lexicographic conventions: node
@@ -127,6 +127,11 @@ typedef struct mimi_hip_bspline_patch {
   int32_t element_end[3];        /* (element sharding across GPUs); all zeros = whole patch       */
   const int64_t* csr_rowptr;     /* [n_vdofs+1] host or device */
   const int32_t* csr_col;        /* [nnz]       host or device */
+  const double* weights;         /* host, [n_nodes] lexicographic NURBS weights, or NULL (all 1).  They must be a tensor
+                                    product w[a0,a1,a2] = w0[a0] w1[a1] w2[a2] (arcs, cylinders, annuli, extrusions and
+                                    revolutions are): the rational basis is then a tensor product too and every kernel
+                                    family applies.  Other weights are refused here: hand such a patch to
+                                    mimi_hip_domain_create as flat tables. */
 } mimi_hip_bspline_patch;
 
 int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* patch, const mimi_hip_material* material,

@@ -38,7 +38,7 @@ class BSplinePatch(C.Structure):
                 ("knots", C.c_void_p * 3), ("control_points", C.c_void_p), ("node_ids", C.c_void_p),
                 ("quadrature_order", C.c_int32),
                 ("element_begin", C.c_int32 * 3), ("element_end", C.c_int32 * 3),
-                ("csr_rowptr", C.c_void_p), ("csr_col", C.c_void_p)]
+                ("csr_rowptr", C.c_void_p), ("csr_col", C.c_void_p), ("weights", C.c_void_p)]
 
 
 class ContactTables(C.Structure):

@@ -106,7 +106,10 @@ struct Tables1D {
   std::vector<double> w;      // [nq]
 };
 
-inline Tables1D make_tables_1d(const double* knots, int n_knots, int p, int nq) {
+// w1d (or nullptr): the 1-D weights of a patch whose NURBS weights are a tensor product w[a0,a1,a2] = w0[a0] w1[a1] w2[a2]
+// -- the rational basis is then the tensor product of the 1-D rational bases R_a = w_a N_a / sum_b w_b N_b, and the
+// tables hold R_a and dR_a/dxi.
+inline Tables1D make_tables_1d(const double* knots, int n_knots, int p, int nq, const double* w1d = nullptr) {
   Tables1D t;
   t.p = p;
   t.nq = nq;
@@ -127,6 +130,19 @@ inline Tables1D make_tables_1d(const double* knots, int n_knots, int p, int nq) 
     std::vector<double> N(p + 1), dN(p + 1);
     for (int q = 0; q < nq; ++q) {
       bspline_basis(knots, p, s, knots[s] + x[q] * h, N.data(), dN.data());
+      if (w1d) {
+        double W = 0.0, dW = 0.0;
+        for (int a = 0; a <= p; ++a) {
+          W += w1d[s - p + a] * N[a];
+          dW += w1d[s - p + a] * dN[a];
+        }
+        for (int a = 0; a <= p; ++a) {
+          const double wa = w1d[s - p + a];
+          const double Ra = wa * N[a] / W;
+          dN[a] = wa * (dN[a] * W - N[a] * dW) / (W * W);
+          N[a] = Ra;
+        }
+      }
       for (int a = 0; a <= p; ++a) {
         t.B[base + (size_t)a * nq + q] = N[a];
         t.D[base + (size_t)a * nq + q] = dN[a] * h;

@@ -384,9 +384,34 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
     int64_t n_nodes = 1;
     h->n_dof = 1;
     h->n_q = 1;
+    // NURBS weights: accepted when they are a tensor product of 1-D weights (then the rational basis factorises)
+    std::vector<double> w1d[3];
+    if (p->weights) {
+      int64_t nc[3] = {1, 1, 1}, stride[3] = {1, 1, 1};
+      for (int d = 0; d < dim; ++d) nc[d] = p->n_knots[d] - p->degree[d] - 1;
+      stride[1] = nc[0];
+      stride[2] = nc[0] * nc[1];
+      const double c = p->weights[0];
+      if (!(c > 0.0)) fail("NURBS weights must be positive");
+      for (int d = 0; d < dim; ++d) {
+        w1d[d].resize(nc[d]);
+        for (int64_t a = 0; a < nc[d]; ++a) w1d[d][a] = p->weights[a * stride[d]];   // the line through node 0
+      }
+      const double cpow = dim == 3 ? c * c : c;
+      for (int64_t a2 = 0; a2 < nc[2]; ++a2)
+        for (int64_t a1 = 0; a1 < nc[1]; ++a1)
+          for (int64_t a0 = 0; a0 < nc[0]; ++a0) {
+            const double w = p->weights[a0 + a1 * stride[1] + a2 * stride[2]];
+            const double prod = w1d[0][a0] * w1d[1][a1] * (dim == 3 ? w1d[2][a2] : 1.0);
+            if (!(w > 0.0)) fail("NURBS weights must be positive");
+            if (std::fabs(w * cpow - prod) > 1e-12 * std::fabs(prod))
+              fail("NURBS weights are not a tensor product of 1-D weights (node %lld): pass this patch as flat tables "
+                   "(mimi_hip_domain_create)", (long long)(a0 + a1 * stride[1] + a2 * stride[2]));
+          }
+    }
     for (int d = 0; d < dim; ++d) {
       if (p->degree[d] < 1 || p->degree[d] > 3) fail("degree %d unsupported (1..3)", p->degree[d]);
-      t1[d] = make_tables_1d(p->knots[d], p->n_knots[d], p->degree[d], nq);
+      t1[d] = make_tables_1d(p->knots[d], p->n_knots[d], p->degree[d], nq, p->weights ? w1d[d].data() : nullptr);
       h->degree[d] = p->degree[d];
       h->nq1[d] = nq;
       h->n_ctrl[d] = t1[d].n_ctrl;

@@ -95,6 +95,8 @@ class NonlinearSolid(NonlinearBase):
                 d.n_knots[i] = len(p.knots[i])
                 d.knots[i] = p.knots[i].ctypes.data
             d.control_points = p.control_points.ctypes.data
+            if getattr(p, "weights", None) is not None:
+                d.weights = p.weights.ctypes.data
             if self.node_ids_ is not None:
                 ids = np.ascontiguousarray(self.node_ids_, dtype=np.int64)
                 self._keep.append(ids)

@@ -193,6 +193,8 @@ class Solid:
 
 def _element_tables(patch, quadrature_order=-1):
     """N[e,q,a] and w*det[e,q] for the mass matrix / body force (affine geometry)."""
+    if getattr(patch, "weights", None) is not None:
+        raise RuntimeError("rational (weighted) patches are not supported by this facade")
     dim = patch.dim
     pmax = max(patch.degrees)
     order = 2 * pmax + 3 if quadrature_order < 0 else quadrature_order

@@ -12,7 +12,9 @@ import numpy as np
 
 
 class BSplinePatch:
-    def __init__(self, degrees, knots, control_points):
+    def __init__(self, degrees, knots, control_points, weights=None):
+        """weights: NURBS weights per control point (lexicographic) or None; the library takes tensor-product weights
+        (w[a0,a1,a2] = w0[a0] w1[a1] w2[a2]) on this route, see include/mimi_hip.h."""
         self.dim = len(degrees)
         self.degrees = [int(p) for p in degrees]
         self.knots = [np.ascontiguousarray(k, dtype=np.float64) for k in knots]
@@ -23,6 +25,7 @@ class BSplinePatch:
         self.n_elements = int(np.prod(self.n_spans))
         self.n_dof = int(np.prod([p + 1 for p in self.degrees]))
         self.n_vdofs = self.n_nodes * self.dim
+        self.weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64).reshape(self.n_nodes)
 
     @classmethod
     def block(cls, n_el, degree, lengths=None):
@@ -122,6 +125,8 @@ def face_tables(patch, axis, side, quadrature_order=-1):
     The face parametrisation is oriented so that the surface normal of
     ComputeUnitNormal (integrators/integrator_utils.hpp:216-251) points out of the body.
     Returns dofs[f,a] (int32), N[f,q,a], dN_dxi[f,q,dim-1,a], weight[f,q]."""
+    if getattr(patch, "weights", None) is not None:
+        raise RuntimeError("face tables of a rational patch are not generated here: pass the reference's boundary tables")
     dim = patch.dim
     pmax = max(patch.degrees)
     order = 2 * pmax + 3 if quadrature_order < 0 else quadrature_order
