@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MIMI_HIP_ABI_VERSION 3
+#define MIMI_HIP_ABI_VERSION 4
 
 /* ---- errors ---------------------------------------------------------------- */
 const char* mimi_hip_last_error(void);
@@ -179,8 +179,24 @@ typedef struct mimi_hip_contact_s* mimi_hip_contact_t;
 
 enum mimi_hip_rigid_body_kind {
   MIMI_HIP_BODY_SPHERE = 0, /* params: centre[3], radius */
-  MIMI_HIP_BODY_PLANE = 1   /* params: point[3], unit normal[3] pointing out of the rigid half space */
+  MIMI_HIP_BODY_PLANE = 1,  /* params: point[3], unit normal[3] pointing out of the rigid half space */
+  MIMI_HIP_BODY_SPLINE = 2  /* mimi_hip_contact_tables::spline: one B-spline / NURBS curve (2-D) or surface (3-D) */
 };
+
+/* NearestDistanceToSplines with its one boundary spline (coefficients/nearest_distance.hpp:215-288): para_dim = dim - 1.
+ * Orientation as in the reference (Results::ComputeNormal, :139-184): the rigid normal is (t_y, -t_x) of the curve
+ * tangent in 2-D, S_u x S_v in 3-D, and must point out of the rigid body. */
+typedef struct mimi_hip_spline_body {
+  int32_t para_dim;
+  int32_t degree[2];             /* <= 5 */
+  int32_t n_knots[2];
+  const double* knots[2];        /* host */
+  const double* control_points;  /* host, [n_ctrl][dim], first parametric direction fastest */
+  const double* weights;         /* host, [n_ctrl], or NULL */
+  int32_t kdtree_resolution;     /* PlantKdTree(resolution, nthreads) (:243-255): sample points per direction for the
+                                    initial guess of the search */
+  int32_t max_iterations;        /* Query::max_iterations (:29); <= 0: 50 */
+} mimi_hip_spline_body;
 
 /* Flat form of the boundary-element tables MortarContact::Prepare builds
  * (mortar_contact.cpp:19-133) plus the analytic rigid body standing in for
@@ -201,6 +217,7 @@ typedef struct mimi_hip_contact_tables {
   double penalty;       /* NearestDistanceBase::coefficient_ (nearest_distance.hpp:18) */
   const int64_t* csr_rowptr;
   const int32_t* csr_col;
+  const mimi_hip_spline_body* spline;  /* body_kind == MIMI_HIP_BODY_SPLINE, else NULL */
 } mimi_hip_contact_tables;
 
 int mimi_hip_contact_create(const mimi_hip_contact_tables* tables, int device, mimi_hip_contact_t* out);

@@ -8,7 +8,7 @@ from .materials import (CompressibleOgdenNeoHookean, J2, StVenantKirchhoff, J2Li
                         JohnsonCookConstantTemperatureHardening)
 from .splines import BSplinePatch
 from . import integrators
-from .integrators import RigidSphere, RigidPlane
+from .integrators import RigidSphere, RigidPlane, RigidSpline, NearestDistanceToSplines
 from .solid import NonlinearSolid, Solid, BoundaryConditions, RuntimeCommunication
 
 __all__ = ["CompressibleOgdenNeoHookean", "J2", "Material", "BSplinePatch", "integrators", "NonlinearSolid",

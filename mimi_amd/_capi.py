@@ -48,7 +48,14 @@ class ContactTables(C.Structure):
                 ("dofs", C.c_void_p), ("N", C.c_void_p), ("dN_dxi", C.c_void_p), ("weight", C.c_void_p),
                 ("x_ref", C.c_void_p),
                 ("body_kind", C.c_int32), ("body", C.c_double * 8), ("penalty", C.c_double),
-                ("csr_rowptr", C.c_void_p), ("csr_col", C.c_void_p)]
+                ("csr_rowptr", C.c_void_p), ("csr_col", C.c_void_p), ("spline", C.c_void_p)]
+
+
+class SplineBody(C.Structure):
+    """mimi_hip_spline_body"""
+    _fields_ = [("para_dim", C.c_int32), ("degree", C.c_int32 * 2), ("n_knots", C.c_int32 * 2),
+                ("knots", C.c_void_p * 2), ("control_points", C.c_void_p), ("weights", C.c_void_p),
+                ("kdtree_resolution", C.c_int32), ("max_iterations", C.c_int32)]
 
 
 EXPORTS = [

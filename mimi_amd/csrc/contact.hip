@@ -24,10 +24,12 @@
 
 #include "common.hpp"
 #include "materials.hpp"
+#include "spline_body.hpp"
 
 namespace mimi_hip {
 
 struct ContactArgs {
+  SplineBodyDev spline;      // body_kind == MIMI_HIP_BODY_SPLINE
   int dim, n_faces, n_dof, n_q;
   const int32_t* dofs;       // [n_faces][n_dof] global node ids
   const int32_t* local;      // [n_faces][n_dof] index into the nodal arrays
@@ -76,6 +78,8 @@ MH_DEV void nearest_body(const ContactArgs& p, const double* xq, double& true_g,
     }
     true_g = g;
     distance = sqrt(dist);
+  } else if (p.body_kind == MIMI_HIP_BODY_SPLINE) {
+    sb_nearest(p.spline, xq, true_g, distance);
   } else {
     double s = 0, dist = 0, g = 0;
 #pragma unroll
@@ -318,6 +322,8 @@ struct mimi_hip_contact_s {
   const int64_t* rowptr = nullptr;
   DeviceBuffer<double> stage_u, stage_r, stage_A;
   DeviceBuffer<int> status;
+  SplineBodyDev spline{};
+  DeviceBuffer<double> sb_knots[2], sb_ctrl, sb_sample_xi, sb_sample_x;
   double last[6] = {0};
   ~mimi_hip_contact_s() {
     if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -350,6 +356,7 @@ static ContactArgs contact_args(mimi_hip_contact_s* h, const double* u, double* 
   a.rowptr = h->rowptr;
   a.pair_pos = h->pair_pos.ptr;
   a.body_kind = h->body_kind;
+  a.spline = h->spline;
   for (int i = 0; i < 8; ++i) a.body[i] = h->body[i];
   a.penalty = h->penalty;
   a.u = u;
@@ -421,6 +428,69 @@ int mimi_hip_contact_create(const mimi_hip_contact_tables* t, int device, mimi_h
     h->body_kind = t->body_kind;
     for (int i = 0; i < 8; ++i) h->body[i] = t->body[i];
     h->penalty = t->penalty;
+    if (t->body_kind == MIMI_HIP_BODY_SPLINE) {
+      // NearestDistanceToSplines::AddSpline / PlantKdTree (nearest_distance.hpp:223-255)
+      const mimi_hip_spline_body* sp = t->spline;
+      if (!sp) fail("body_kind spline without a spline description");
+      if (sp->para_dim + 1 != t->dim) fail("boundary para_dim should be one smaller than dim.");   // :121-124
+      SplineBodyDev host{};
+      host.para_dim = sp->para_dim;
+      host.dim = t->dim;
+      size_t n_ctrl = 1;
+      for (int k = 0; k < 2; ++k) {
+        host.p[k] = k < sp->para_dim ? sp->degree[k] : 0;
+        host.n_knots[k] = k < sp->para_dim ? sp->n_knots[k] : 2;
+        host.n_ctrl[k] = host.n_knots[k] - host.p[k] - 1;
+        if (host.p[k] < 0 || host.p[k] > kMaxBodyDegree) fail("spline body degree %d unsupported (<= %d)", host.p[k], kMaxBodyDegree);
+        if (host.n_ctrl[k] < host.p[k] + 1) fail("spline body knot vector too short");
+        n_ctrl *= host.n_ctrl[k];
+      }
+      const int hd = t->dim + 1;
+      std::vector<double> ctrl_h(n_ctrl * hd);
+      for (size_t a = 0; a < n_ctrl; ++a) {
+        const double w = sp->weights ? sp->weights[a] : 1.0;
+        if (!(w > 0.0)) fail("spline body weights must be positive");
+        for (int i = 0; i < t->dim; ++i) ctrl_h[a * hd + i] = w * sp->control_points[a * t->dim + i];
+        ctrl_h[a * hd + t->dim] = w;
+      }
+      static const double unit_knots[2] = {0.0, 1.0};
+      host.knots[0] = sp->knots[0];
+      host.knots[1] = sp->para_dim == 2 ? sp->knots[1] : unit_knots;
+      host.ctrl_h = ctrl_h.data();
+      const int res = sp->kdtree_resolution > 1 ? sp->kdtree_resolution : 100;
+      const int n_s = sp->para_dim == 2 ? res * res : res;
+      std::vector<double> sxi((size_t)n_s * sp->para_dim), sx((size_t)n_s * t->dim);
+      for (int s_ = 0; s_ < n_s; ++s_) {
+        const int idx[2] = {s_ % res, s_ / res};
+        double xi[2] = {0, 0}, S[3], S1[6], S2[12];
+        for (int k = 0; k < sp->para_dim; ++k) {
+          const double lo = host.knots[k][host.p[k]], hi = host.knots[k][host.n_knots[k] - host.p[k] - 1];
+          xi[k] = lo + (hi - lo) * idx[k] / (res - 1);
+          sxi[(size_t)s_ * sp->para_dim + k] = xi[k];
+        }
+        sb_evaluate(host, xi, S, S1, S2);
+        for (int i = 0; i < t->dim; ++i) sx[(size_t)s_ * t->dim + i] = S[i];
+      }
+      h->spline = host;
+      for (int k = 0; k < sp->para_dim; ++k) {
+        h->sb_knots[k].assign(sp->knots[k], (size_t)sp->n_knots[k], h->stream);
+        h->spline.knots[k] = h->sb_knots[k].ptr;
+      }
+      if (sp->para_dim == 1) {
+        h->sb_knots[1].assign(unit_knots, 2, h->stream);
+        h->spline.knots[1] = h->sb_knots[1].ptr;
+      }
+      h->sb_ctrl.assign(ctrl_h.data(), ctrl_h.size(), h->stream);
+      h->sb_sample_xi.assign(sxi.data(), sxi.size(), h->stream);
+      h->sb_sample_x.assign(sx.data(), sx.size(), h->stream);
+      h->spline.ctrl_h = h->sb_ctrl.ptr;
+      h->spline.sample_xi = h->sb_sample_xi.ptr;
+      h->spline.sample_x = h->sb_sample_x.ptr;
+      h->spline.n_samples = n_s;
+      h->spline.max_iterations = sp->max_iterations;
+    } else if (t->body_kind != MIMI_HIP_BODY_SPHERE && t->body_kind != MIMI_HIP_BODY_PLANE) {
+      fail("unknown rigid body kind %d", t->body_kind);
+    }
     const size_t nfd = (size_t)t->n_faces * t->n_dof;
     // host copy of the connectivity for the dense local numbering of marked dofs
     // (mortar_contact.cpp:41-76: sorted unique marked dofs -> 0..n_marked-1)

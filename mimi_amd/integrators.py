@@ -230,6 +230,76 @@ class RigidPlane:
         return self.point + [0.0] * (3 - dim) + self.normal + [0.0] * (3 - dim)
 
 
+class RigidSpline:
+    """One rigid boundary spline (curve in 2-D, surface in 3-D): what NearestDistanceToSplines holds
+    (coefficients/nearest_distance.hpp:215-288).  Orientation: the normal (t_y, -t_x) / S_u x S_v must point out of the
+    rigid body (nearest_distance.hpp:139-184)."""
+    kind = 2
+
+    def __init__(self, degrees, knots, control_points, weights=None, resolution=100, coefficient=1.0e4, max_iterations=-1):
+        self.degrees = [int(p) for p in degrees]
+        self.knots = [np.ascontiguousarray(k, dtype=np.float64) for k in knots]
+        n = int(np.prod([len(k) - p - 1 for k, p in zip(self.knots, self.degrees)]))
+        self.control_points = np.ascontiguousarray(control_points, dtype=np.float64).reshape(n, -1)
+        self.weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64).reshape(n)
+        self.resolution, self.max_iterations = int(resolution), int(max_iterations)
+        self.coefficient = float(coefficient)
+
+    def params(self, dim):
+        return []
+
+    def c_struct(self):
+        s = _capi.SplineBody()
+        s.para_dim = len(self.degrees)
+        for k in range(s.para_dim):
+            s.degree[k], s.n_knots[k] = self.degrees[k], len(self.knots[k])
+            s.knots[k] = self.knots[k].ctypes.data
+        s.control_points = self.control_points.ctypes.data
+        s.weights = self.weights.ctypes.data if self.weights is not None else None
+        s.kdtree_resolution, s.max_iterations = self.resolution, self.max_iterations
+        return s
+
+
+class NearestDistanceToSplines:
+    """coefficients::NearestDistanceToSplines as bound in py/py_nearest_distance.cpp: add_spline / plant_kd_tree /
+    coefficient.  `spline` is anything with the attributes degrees, knot_vectors, control_points and (optionally)
+    weights -- a splinepy spline has them."""
+    kind = 2
+
+    def __init__(self):
+        self.coefficient = 1.0e4        # nearest_distance.hpp:18
+        self.tolerance = 1.0e-24        # nearest_distance.hpp:20 (the search here stops on the step size)
+        self._splines, self._resolution = [], 100
+
+    def add_spline(self, spline):
+        self._splines.append(spline)
+        return self
+
+    def clear(self):
+        self._splines.clear()
+
+    def plant_kd_tree(self, resolution, nthreads=1):
+        self._resolution = int(resolution)
+
+    def size(self):
+        return len(self._splines)
+
+    def _body(self):
+        if len(self._splines) != 1:
+            raise RuntimeError("exactly one boundary spline is supported (nearest_distance.hpp:262-263)")
+        sp = self._splines[0]
+        w = getattr(sp, "weights", None)
+        return RigidSpline(sp.degrees, sp.knot_vectors, sp.control_points, None if w is None else np.ravel(w),
+                           resolution=self._resolution, coefficient=self.coefficient)
+
+    def params(self, dim):
+        return []
+
+    def c_struct(self):
+        self._rs = self._body()
+        return self._rs.c_struct()
+
+
 class MortarContact(NonlinearBase):
     """integrators::MortarContact (integrators/mortar_contact.hpp:23-172) against an analytic
     rigid body, on one face of a B-spline patch."""
@@ -263,6 +333,10 @@ class MortarContact(NonlinearBase):
         for i, v in enumerate(body.params(p.dim)):
             t.body[i] = v
         t.penalty = body.coefficient
+        if body.kind == 2:
+            self._spline_struct = body.c_struct()
+            self._keep.append(body)
+            t.spline = C.cast(C.pointer(self._spline_struct), C.c_void_p)
         t.csr_rowptr = ptr(self.pattern_.rowptr).value
         t.csr_col = ptr(self.pattern_.col).value
         h = C.c_void_p()

@@ -38,13 +38,262 @@ typedef struct {
   double* gap;           /* [n_marked]  average_gap_    */
   double* pressure;      /* [n_marked]  average_pressure_ */
   double last_area, last_pressure, last_force[3];
+  /* body_kind == BODY_SPLINE: one boundary spline (NearestDistanceToSplines, nearest_distance.hpp:215-288) */
+  int sp_para_dim, sp_p[2], sp_n_knots[2];
+  const double* sp_knots[2];
+  const double* sp_ctrl;      /* [n_ctrl][dim] */
+  const double* sp_weights;   /* [n_ctrl] or NULL */
+  int sp_resolution, sp_max_iterations;
 } oracle_contact;
 
 /* analytic stand-in for NearestDistance + Results::ComputeNormal<true> + NormalGap
  * (nearest_distance.hpp:139-193): rigid unit normal n_r, true gap
  * g = -n_r . (x_rigid - x_query), distance = |x_rigid - x_query| */
+#define BODY_SPLINE 2
+#define SP_MAXP 5
+
+/* Piegl & Tiller A2.1 */
+static int sp_span(const double* U, int n_knots, int p, double u) {
+  const int n = n_knots - p - 2; /* last control index */
+  if (u >= U[n + 1]) {
+    int i = n;
+    while (i > p && U[i] == U[i + 1]) --i;
+    return i;
+  }
+  int low = p, high = n + 1, mid = (low + high) / 2;
+  while (u < U[mid] || u >= U[mid + 1]) {
+    if (u < U[mid]) high = mid; else low = mid;
+    mid = (low + high) / 2;
+  }
+  return mid;
+}
+
+/* Piegl & Tiller A2.3 DersBasisFuns for derivatives 0..2: ders[k][j] */
+static void sp_ders(const double* U, int p, int i, double u, double ders[3][SP_MAXP + 1]) {
+  double ndu[SP_MAXP + 1][SP_MAXP + 1], a[2][SP_MAXP + 1], left[SP_MAXP + 1], right[SP_MAXP + 1];
+  ndu[0][0] = 1.0;
+  for (int j = 1; j <= p; ++j) {
+    left[j] = u - U[i + 1 - j];
+    right[j] = U[i + j] - u;
+    double saved = 0.0;
+    for (int r = 0; r < j; ++r) {
+      ndu[j][r] = right[r + 1] + left[j - r];
+      const double temp = ndu[r][j - 1] / ndu[j][r];
+      ndu[r][j] = saved + right[r + 1] * temp;
+      saved = left[j - r] * temp;
+    }
+    ndu[j][j] = saved;
+  }
+  for (int j = 0; j <= p; ++j) ders[0][j] = ndu[j][p];
+  for (int j = 0; j <= p; ++j) ders[1][j] = ders[2][j] = 0.0;
+  const int nd = p < 2 ? p : 2;
+  for (int r = 0; r <= p; ++r) {
+    int s1 = 0, s2 = 1;
+    a[0][0] = 1.0;
+    for (int k = 1; k <= nd; ++k) {
+      double d = 0.0;
+      const int rk = r - k, pk = p - k;
+      if (r >= k) {
+        a[s2][0] = a[s1][0] / ndu[pk + 1][rk];
+        d = a[s2][0] * ndu[rk][pk];
+      }
+      const int j1 = rk >= -1 ? 1 : -rk;
+      const int j2 = (r - 1 <= pk) ? k - 1 : p - r;
+      for (int j = j1; j <= j2; ++j) {
+        a[s2][j] = (a[s1][j] - a[s1][j - 1]) / ndu[pk + 1][rk + j];
+        d += a[s2][j] * ndu[rk + j][pk];
+      }
+      if (r <= pk) {
+        a[s2][k] = -a[s1][k - 1] / ndu[pk + 1][r];
+        d += a[s2][k] * ndu[r][pk];
+      }
+      ders[k][r] = d;
+      const int t = s1;
+      s1 = s2;
+      s2 = t;
+    }
+  }
+  double fac = p;
+  for (int k = 1; k <= nd; ++k) {
+    for (int j = 0; j <= p; ++j) ders[k][j] *= fac;
+    fac *= (p - k);
+  }
+}
+
+/* S, S_k, S_kl of the rational spline (quotient rule on the homogeneous sums) */
+static void sp_eval(const oracle_contact* C, const double* xi, double* S, double* S1, double* S2) {
+  const int dim = C->dim, pd = C->sp_para_dim;
+  double d[2][3][SP_MAXP + 1];
+  int span[2] = {0, 0}, p[2] = {C->sp_p[0], pd == 2 ? C->sp_p[1] : 0};
+  for (int k = 0; k < pd; ++k) {
+    span[k] = sp_span(C->sp_knots[k], C->sp_n_knots[k], p[k], xi[k]);
+    sp_ders(C->sp_knots[k], p[k], span[k], xi[k], d[k]);
+  }
+  if (pd == 1) {
+    d[1][0][0] = 1.0;
+    d[1][1][0] = d[1][2][0] = 0.0;
+  }
+  const int n0 = C->sp_n_knots[0] - p[0] - 1;
+  /* derivative orders (o0, o1) of the six sums */
+  static const int ord[6][2] = {{0, 0}, {1, 0}, {0, 1}, {2, 0}, {1, 1}, {0, 2}};
+  double A[6][4];
+  memset(A, 0, sizeof(A));
+  for (int a1 = 0; a1 <= p[1]; ++a1)
+    for (int a0 = 0; a0 <= p[0]; ++a0) {
+      const long node = (span[0] - p[0] + a0) + (long)n0 * (pd == 2 ? span[1] - p[1] + a1 : 0);
+      const double w = C->sp_weights ? C->sp_weights[node] : 1.0;
+      for (int t = 0; t < 6; ++t) {
+        const double b = d[0][ord[t][0]][a0] * d[1][ord[t][1]][a1] * w;
+        for (int i = 0; i < dim; ++i) A[t][i] += b * C->sp_ctrl[node * dim + i];
+        A[t][dim] += b;
+      }
+    }
+  const double W = A[0][dim];
+  for (int i = 0; i < dim; ++i) S[i] = A[0][i] / W;
+  for (int k = 0; k < pd; ++k)
+    for (int i = 0; i < dim; ++i) S1[k * dim + i] = (A[1 + k][i] - A[1 + k][dim] * S[i]) / W;
+  for (int k = 0; k < pd; ++k)
+    for (int l = 0; l < pd; ++l) {
+      const int t = (k == 0 && l == 0) ? 3 : (k == 1 && l == 1) ? 5 : 4;
+      for (int i = 0; i < dim; ++i)
+        S2[(k * pd + l) * dim + i] =
+            (A[t][i] - A[t][dim] * S[i] - A[1 + k][dim] * S1[l * dim + i] - A[1 + l][dim] * S1[k * dim + i]) / W;
+    }
+}
+
+/* the published scheme behind SplinepyVerboseProximity (nearest_distance.hpp:268-279; splinepy is absent): nearest of
+ * resolution^para_dim samples, then Newton on the squared distance, clipped to the bounds, halved while it grows */
+static void sp_nearest(const oracle_contact* C, const double* xq, double* true_g, double* distance) {
+  const int dim = C->dim, pd = C->sp_para_dim, res = C->sp_resolution;
+  double lo[2] = {0, 0}, hi[2] = {1, 1}, xi[2] = {0, 0}, S[3], S1[6], S2[12];
+  for (int k = 0; k < pd; ++k) {
+    lo[k] = C->sp_knots[k][C->sp_p[k]];
+    hi[k] = C->sp_knots[k][C->sp_n_knots[k] - C->sp_p[k] - 1];
+  }
+  {
+    const int n_s = pd == 2 ? res * res : res;
+    double best = 1e300;
+    for (int s = 0; s < n_s; ++s) {
+      double x[2] = {0, 0};
+      const int idx[2] = {s % res, s / res};
+      for (int k = 0; k < pd; ++k) x[k] = lo[k] + (hi[k] - lo[k]) * idx[k] / (res - 1);
+      sp_eval(C, x, S, S1, S2);
+      double d2 = 0;
+      for (int i = 0; i < dim; ++i) d2 += (S[i] - xq[i]) * (S[i] - xq[i]);
+      if (d2 < best) {
+        best = d2;
+        xi[0] = x[0];
+        xi[1] = x[1];
+      }
+    }
+  }
+  sp_eval(C, xi, S, S1, S2);
+  double f = 0;
+  for (int i = 0; i < dim; ++i) f += (S[i] - xq[i]) * (S[i] - xq[i]);
+  const int max_it = C->sp_max_iterations > 0 ? C->sp_max_iterations : 50;
+  for (int it = 0; it < max_it; ++it) {
+    double g[2] = {0, 0}, H[4] = {0}, GN[4] = {0}, delta[2] = {0, 0};
+    int fr[2] = {1, 1};
+    for (int k = 0; k < pd; ++k)
+      for (int i = 0; i < dim; ++i) g[k] += S1[k * dim + i] * (S[i] - xq[i]);
+    for (int k = 0; k < pd; ++k)
+      for (int l = 0; l < pd; ++l) {
+        double gn = 0, cv = 0;
+        for (int i = 0; i < dim; ++i) {
+          gn += S1[k * dim + i] * S1[l * dim + i];
+          cv += S2[(k * pd + l) * dim + i] * (S[i] - xq[i]);
+        }
+        GN[k * pd + l] = gn;
+        H[k * pd + l] = gn + cv;
+      }
+    for (int k = 0; k < pd; ++k)
+      if ((xi[k] <= lo[k] && g[k] > 0.0) || (xi[k] >= hi[k] && g[k] < 0.0)) fr[k] = 0;
+    if (!fr[0] && (pd == 1 || !fr[1])) break;
+    int ok = 0;
+    for (int attempt = 0; attempt < 2 && !ok; ++attempt) {
+      const double* Mx = attempt == 0 ? H : GN;
+      delta[0] = delta[1] = 0.0;
+      if (pd == 1) {
+        if (Mx[0] > 0.0) {
+          delta[0] = -g[0] / Mx[0];
+          ok = 1;
+        }
+      } else if (fr[0] && fr[1]) {
+        const double det = Mx[0] * Mx[3] - Mx[1] * Mx[2];
+        if (det > 0.0 && Mx[0] > 0.0) {
+          delta[0] = -(Mx[3] * g[0] - Mx[1] * g[1]) / det;
+          delta[1] = -(Mx[0] * g[1] - Mx[2] * g[0]) / det;
+          ok = 1;
+        }
+      } else if (fr[0]) {
+        if (Mx[0] > 0.0) {
+          delta[0] = -g[0] / Mx[0];
+          ok = 1;
+        }
+      } else {
+        if (Mx[3] > 0.0) {
+          delta[1] = -g[1] / Mx[3];
+          ok = 1;
+        }
+      }
+    }
+    if (!ok) break;
+    double xn[2] = {0, 0}, Sn[3], S1n[6], S2n[12], fn = f, scale = 1.0;
+    int moved = 0;
+    for (int half = 0; half < 8; ++half, scale *= 0.5) {
+      moved = 0;
+      for (int k = 0; k < pd; ++k) {
+        double v = xi[k] + scale * delta[k];
+        v = v < lo[k] ? lo[k] : (v > hi[k] ? hi[k] : v);
+        if (v != xi[k]) moved = 1;
+        xn[k] = v;
+      }
+      if (!moved) break;
+      sp_eval(C, xn, Sn, S1n, S2n);
+      fn = 0;
+      for (int i = 0; i < dim; ++i) fn += (Sn[i] - xq[i]) * (Sn[i] - xq[i]);
+      if (fn <= f) break;
+    }
+    if (!moved || fn > f) break;
+    double step = 0;
+    for (int k = 0; k < pd; ++k) {
+      if (fabs(xn[k] - xi[k]) > step) step = fabs(xn[k] - xi[k]);
+      xi[k] = xn[k];
+    }
+    memcpy(S, Sn, sizeof(Sn));
+    memcpy(S1, S1n, sizeof(S1n));
+    memcpy(S2, S2n, sizeof(S2n));
+    f = fn;
+    if (step < 1e-15 * (hi[0] - lo[0])) break;
+  }
+  /* Results::ComputeNormal<true> (nearest_distance.hpp:139-184) and NormalGap (:186-193) */
+  double n[3];
+  if (dim == 2) {
+    const double nn = sqrt(S1[0] * S1[0] + S1[1] * S1[1]);
+    n[0] = S1[1] / nn;
+    n[1] = -S1[0] / nn;
+  } else {
+    const double n0 = S1[1] * S1[5] - S1[2] * S1[4], n1 = S1[2] * S1[3] - S1[0] * S1[5], n2 = S1[0] * S1[4] - S1[1] * S1[3];
+    const double nn = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+    n[0] = n0 / nn;
+    n[1] = n1 / nn;
+    n[2] = n2 / nn;
+  }
+  double g = 0, d2 = 0;
+  for (int i = 0; i < dim; ++i) {
+    g -= n[i] * (S[i] - xq[i]);
+    d2 += (S[i] - xq[i]) * (S[i] - xq[i]);
+  }
+  *true_g = g;
+  *distance = sqrt(d2);
+}
+
 static void nearest(const oracle_contact* C, const double* xq, double* true_g, double* distance) {
   const int dim = C->dim;
+  if (C->body_kind == BODY_SPLINE) {
+    sp_nearest(C, xq, true_g, distance);
+    return;
+  }
   if (C->body_kind == BODY_SPHERE) {
     double d[3], nrm = 0;
     for (int i = 0; i < dim; ++i) {

@@ -68,7 +68,10 @@ class _Contact(C.Structure):
                 ("body_kind", C.c_int), ("body", C.c_double * 8), ("penalty", C.c_double),
                 ("area", C.c_void_p), ("gap", C.c_void_p), ("pressure", C.c_void_p),
                 ("last_area", C.c_double), ("last_pressure", C.c_double),
-                ("last_force", C.c_double * 3)]
+                ("last_force", C.c_double * 3),
+                ("sp_para_dim", C.c_int), ("sp_p", C.c_int * 2), ("sp_n_knots", C.c_int * 2),
+                ("sp_knots", C.c_void_p * 2), ("sp_ctrl", C.c_void_p), ("sp_weights", C.c_void_p),
+                ("sp_resolution", C.c_int), ("sp_max_iterations", C.c_int)]
 
 
 _lib = None
@@ -264,7 +267,24 @@ class ContactOracle:
         c.v_dofs, c.local_dofs = _ptr(self.v_dofs), _ptr(self.local_dofs)
         c.a_ids = _ptr(self.a_ids) if self.a_ids is not None else None
         c.N, c.dN_dxi, c.weight, c.x_ref = map(_ptr, (self.N, self.dN_dxi, self.weight, self.x_ref))
-        if body["kind"] == "sphere":
+        if body["kind"] == "spline":
+            # dict(kind="spline", degrees=[..], knots=[..], control_points=[n, dim], weights=None|[n], resolution=..)
+            c.body_kind = 2
+            vals = []
+            self._spline = [np.ascontiguousarray(k, dtype=np.float64) for k in body["knots"]]
+            ctrl = np.ascontiguousarray(body["control_points"], dtype=np.float64)
+            w = body.get("weights")
+            w = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+            self._spline += [ctrl, w]
+            c.sp_para_dim = len(body["degrees"])
+            for k, (p_, kn) in enumerate(zip(body["degrees"], self._spline[:c.sp_para_dim])):
+                c.sp_p[k], c.sp_n_knots[k] = int(p_), len(kn)
+                c.sp_knots[k] = kn.ctypes.data
+            c.sp_ctrl = ctrl.ctypes.data
+            c.sp_weights = w.ctypes.data if w is not None else None
+            c.sp_resolution = int(body.get("resolution", 100))
+            c.sp_max_iterations = int(body.get("max_iterations", -1))
+        elif body["kind"] == "sphere":
             c.body_kind = 0
             vals = list(body["center"]) + [0.0] * (3 - dim) + [body["radius"]]
         else:

@@ -108,3 +108,90 @@ def test_contact_parity_gpu(n_el, p, axis, bodykind):
         G.AddBoundaryResidualAndGrad(u, 0.6, r_g, A_g)
         assert rel(r_g - r0, r_o - r0) < 1e-12
         assert rel(A_g - A0, A_o - A0) < tol
+
+
+# ---- rigid SPLINE bodies (NearestDistanceToSplines, coefficients/nearest_distance.hpp:215-288) ---------------------
+def nurbs_circle(center, R):
+    """the standard 9-point quadratic NURBS circle, counter-clockwise (outward normal (t_y, -t_x))"""
+    s = np.sqrt(0.5)
+    pts = np.array([[1, 0], [1, 1], [0, 1], [-1, 1], [-1, 0], [-1, -1], [0, -1], [1, -1], [1, 0]], dtype=float)
+    w = np.array([1, s, 1, s, 1, s, 1, s, 1])
+    knots = np.array([0, 0, 0, .25, .25, .5, .5, .75, .75, 1, 1, 1])
+    return dict(kind="spline", degrees=[2], knots=[knots], control_points=np.asarray(center) + R * pts, weights=w, resolution=64)
+
+
+def dome_surface(P, axis=2, depth=0.06):
+    """biquadratic B-spline surface hanging over the top face of a 3-D block, lowest in the middle, normal S_u x S_v
+    pointing down (first parametric direction along y, second along x)"""
+    L = P.ctrl.max(axis=0)
+    n = 6
+    k = np.concatenate([np.zeros(2), np.linspace(0, 1, n - 1), np.ones(2)])
+    g = np.array([k[i + 1:i + 3].sum() / 2 for i in range(n)])
+    ctrl = np.zeros((n, n, 3))                       # [second (x)][first (y)]
+    for ix in range(n):
+        for iy in range(n):
+            x, y = -0.5 + (L[0] + 1.0) * g[ix], -0.5 + (L[1] + 1.0) * g[iy]
+            r2 = ((x - 0.5 * L[0]) / L[0]) ** 2 + ((y - 0.5 * L[1]) / L[1]) ** 2
+            ctrl[ix, iy] = [x, y, L[2] - depth + 0.8 * r2]
+    return dict(kind="spline", degrees=[2, 2], knots=[k, k], control_points=ctrl.reshape(-1, 3), weights=None, resolution=24)
+
+
+def product_spline(body):
+    from mimi_amd.integrators import RigidSpline
+    return RigidSpline(body["degrees"], body["knots"], body["control_points"], body["weights"], resolution=body["resolution"],
+                       coefficient=1e4)
+
+
+def test_oracle_spline_circle_equals_analytic_sphere():
+    """the NURBS circle IS the circle: the spline search must reproduce the analytic body"""
+    from oracle import iga, ref_path as rp
+    P = iga.Patch.block((6, 3), 2)
+    rowptr, col = P.sparsity()
+    sph = sphere_over_top(P, 1)
+    u = synthetic_u(P, scale=0.01)
+    out = []
+    for body in (sph, nurbs_circle(sph["center"], sph["radius"])):
+        Cn = rp.ContactOracle(P, 1, 1, body, penalty=1e4, rowptr=rowptr, col=col)
+        r = np.zeros(P.n_vdofs)
+        A = np.zeros(rowptr[-1])
+        Cn.add_boundary_residual_and_grad(u, 1.0, r, A, rp.TANGENT_EXACT)
+        out.append((r, A, Cn.pressure.copy(), Cn.gap_norm(u)))
+    assert np.abs(out[0][0]).max() > 0
+    for a, b in zip(out[0], out[1]):
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-9 * np.abs(a).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["circle2d", "dome3d"])
+def test_contact_spline_body_parity_gpu(case):
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, MortarContact
+    from oracle import iga, ref_path as rp
+    if case == "circle2d":
+        n_el, p, axis = (6, 3), 2, 1
+        P = iga.Patch.block(n_el, p)
+        sph = sphere_over_top(P, axis)
+        body = nurbs_circle(sph["center"], sph["radius"])
+    else:
+        n_el, p, axis = (4, 4, 2), 2, 2
+        P = iga.Patch.block(n_el, p)
+        body = dome_surface(P)
+    rowptr, col = P.sparsity()
+    Cn = rp.ContactOracle(P, axis, 1, body, penalty=1e4, rowptr=rowptr, col=col)
+    patch = mimi_amd.BSplinePatch.block(n_el, p)
+    pattern = CSRPattern(rowptr.astype(np.int64), col.astype(np.int32), rowptr[-1])
+    G = MortarContact(product_spline(body), "contact", pattern, patch, axis, 1).Prepare()
+    u = synthetic_u(P, scale=0.01)
+
+    def rel(a, b):
+        return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+    r_o, r_g = np.zeros(P.n_vdofs), np.zeros(P.n_vdofs)
+    A_o, A_g = np.zeros(rowptr[-1]), np.zeros(rowptr[-1])
+    Cn.add_boundary_residual_and_grad(u, 0.6, r_o, A_o, rp.TANGENT_EXACT)
+    G.AddBoundaryResidualAndGrad(u, 0.6, r_g, A_g)
+    assert np.abs(r_o).max() > 0 and Cn.pressure.min() < 0          # in contact
+    assert rel(r_g, r_o) < 1e-11
+    assert rel(A_g, A_o) < 1e-10
+    assert np.allclose(G.AveragePressure(), Cn.pressure, rtol=1e-10, atol=1e-10)
+    assert np.isclose(G.GapNorm(u), Cn.gap_norm(u), rtol=1e-10)

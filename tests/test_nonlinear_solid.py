@@ -203,3 +203,42 @@ def test_3d_cantilever_runs_through_tensor_kernels():
         sols.append(nl.solution_view("displacement", "x").copy())
     assert np.abs(sols[0]).max() > 1e-4
     assert np.allclose(sols[0], sols[1], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_contact_with_rigid_spline_through_the_facade():
+    """examples/nl_contact.py in miniature: a rigid NURBS circle (NearestDistanceToSplines().add_spline, plant_kd_tree)
+    pressed into the top edge of the beam by its own penalty; the steps converge and the contact carries load."""
+    import types
+    import mimi_amd as mimi
+    nl = balken(2, 1)
+    mat = mimi.CompressibleOgdenNeoHookean()
+    mat.density = 1
+    mat.viscosity = -1
+    mat.set_young_poisson(2100, 0.3)
+    nl.set_material(mat)
+    s = np.sqrt(0.5)
+    pts = np.array([[1, 0], [1, 1], [0, 1], [-1, 1], [-1, 0], [-1, -1], [0, -1], [1, -1], [1, 0]], dtype=float)
+    circle = types.SimpleNamespace(degrees=[2], knot_vectors=[[0, 0, 0, .25, .25, .5, .5, .75, .75, 1, 1, 1]],
+                                   control_points=np.array([4.0, 1.0 + 0.5 - 0.1]) + 0.5 * pts,
+                                   weights=np.array([1, s, 1, s, 1, s, 1, s, 1]))
+    nd = mimi.NearestDistanceToSplines()
+    nd.add_spline(circle)
+    nd.plant_kd_tree(200, 1)
+    nd.coefficient = 1e4
+    bc = mimi.BoundaryConditions()
+    bc.initial.dirichlet(2, 0).dirichlet(2, 1)
+    top = [a - 1 for a, f in nl._faces.items() if f == (1, 1)][0]
+    bc.current.contact(top, nd)
+    nl.boundary_condition = bc
+    nl.setup(1)
+    nl.configure_newton("nonlinear_solid", 1e-10, 1e-8, 20, False)
+    nl.time_step_size = 0.01
+    for _ in range(3):
+        nl.step_time2()
+        assert nl.newton_history[-1]["converged"]
+    u = nl.solution_view("displacement", "x").reshape(-1, 2)
+    assert u[:, 1].min() < -1e-6                     # pushed down under the circle
+    c = nl.contacts_[0]
+    c.BoundaryPostTimeAdvance(nl.x)
+    assert c.last_force_[1] != 0.0
