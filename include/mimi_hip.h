@@ -239,6 +239,17 @@ int mimi_hip_contact_last_history(mimi_hip_contact_t h, double* out5);
 /* nodal average_pressure_ (mortar_contact.hpp:59), [n_marked]; returns n_marked via *n */
 int mimi_hip_contact_get_pressure(mimi_hip_contact_t h, double* out, int64_t capacity, int64_t* n);
 
+/* Multi-GPU (one handle per rank over the faces of its element slab): the nodal area / gap of nodes shared between
+ * slabs must be summed over the ranks before the pressure is formed (mortar_contact.cpp:195-261 runs over all marked
+ * faces).  gap_area = pass 1 only; marked_nodes = the sorted global node ids behind the nodal arrays (out == NULL: count
+ * only); nodal = read (set 0) or write (set 1) the nodal area / gap arrays [n_marked], host or device pointers;
+ * add_residual_from_nodal = pressure + pass 2 (A_values == NULL: residual only). */
+int mimi_hip_contact_gap_area(mimi_hip_contact_t h, const double* u);
+int mimi_hip_contact_marked_nodes(mimi_hip_contact_t h, int32_t* out, int64_t capacity, int64_t* n);
+int mimi_hip_contact_nodal(mimi_hip_contact_t h, int set, double* area, double* gap);
+int mimi_hip_contact_add_residual_from_nodal(mimi_hip_contact_t h, const double* u, double grad_factor, double* r,
+                                             double* A_values);
+
 /* ---- the callers' steps around the assembly, device-resident ---------------------------
  * One handle per CSR pattern (rowptr / col host or device; device arrays are used in place and must outlive the
  * handle) and list of essential dofs (forms::Nonlinear's zero_dofs). */

@@ -322,6 +322,7 @@ struct mimi_hip_contact_s {
   const int64_t* rowptr = nullptr;
   DeviceBuffer<double> stage_u, stage_r, stage_A;
   DeviceBuffer<int> status;
+  std::vector<int32_t> marked_nodes;   // sorted global node ids of the marked dofs (local index -> node)
   SplineBodyDev spline{};
   DeviceBuffer<double> sb_knots[2], sb_ctrl, sb_sample_xi, sb_sample_x;
   double last[6] = {0};
@@ -371,14 +372,9 @@ static ContactArgs contact_args(mimi_hip_contact_s* h, const double* u, double* 
   return a;
 }
 
-static void run_contact(mimi_hip_contact_s* h, const double* u, double* r, double* A, double gf, bool with_grad) {
-  MH_HIP(hipSetDevice(h->device));
-  if (!u || !r || (with_grad && !A)) fail("null vector argument");
-  Mirror<double> mu = Mirror<double>::in(u, h->n_vdofs, h->stage_u, h->stream);
-  Mirror<double> mr = Mirror<double>::inout(r, h->n_vdofs, h->stage_r, h->stream);
-  Mirror<double> mA;
-  if (with_grad) mA = Mirror<double>::inout(A, h->nnz, h->stage_A, h->stream);
-  ContactArgs a = contact_args(h, mu.dev, mr.dev, mA.dev, gf);
+// pass 1 (mortar_contact.cpp:148-193): nodal area / gap of this handle's faces; pressure not formed yet
+static void contact_pass1(mimi_hip_contact_s* h, const double* u_dev) {
+  ContactArgs a = contact_args(h, u_dev, nullptr, nullptr, 0.0);
   // InitializeGapAreaPressure + last_* reset (mortar_contact.cpp:135-146,302-306)
   MH_HIP(hipMemsetAsync(h->area.ptr, 0, h->n_marked * sizeof(double), h->stream));
   MH_HIP(hipMemsetAsync(h->gap.ptr, 0, h->n_marked * sizeof(double), h->stream));
@@ -386,21 +382,38 @@ static void run_contact(mimi_hip_contact_s* h, const double* u, double* r, doubl
   const int threads = 128;
   const int64_t npts = (int64_t)h->n_faces * h->n_q;
   const unsigned b1 = (unsigned)((npts + threads - 1) / threads);
+  if (h->dim == 2) hipLaunchKernelGGL(contact_gap_area_kernel<2>, dim3(b1), dim3(threads), 0, h->stream, a, 0);
+  else hipLaunchKernelGGL(contact_gap_area_kernel<3>, dim3(b1), dim3(threads), 0, h->stream, a, 0);
+  MH_HIP(hipGetLastError());
+}
+
+// pressure from the nodal area / gap (mortar_contact.cpp:195-261), then pass 2: residual (+ tangent)
+static void contact_pass2(mimi_hip_contact_s* h, const double* u_dev, double* r_dev, double* A_dev, double gf, bool with_grad) {
+  ContactArgs a = contact_args(h, u_dev, r_dev, A_dev, gf);
+  const int threads = 128;
   const unsigned b2 = (unsigned)((h->n_marked + threads - 1) / threads);
   const unsigned b3 = (unsigned)((h->n_faces + 63) / 64);
-  if (h->dim == 2) {
-    hipLaunchKernelGGL(contact_gap_area_kernel<2>, dim3(b1), dim3(threads), 0, h->stream, a, 0);
-    hipLaunchKernelGGL(contact_pressure_kernel, dim3(b2), dim3(threads), 0, h->stream, h->n_marked, h->area.ptr, h->gap.ptr, h->penalty, h->pressure.ptr);
-    hipLaunchKernelGGL(contact_residual_kernel<2>, dim3(b3), dim3(64), 0, h->stream, a, with_grad ? 1 : 0);
-  } else {
-    hipLaunchKernelGGL(contact_gap_area_kernel<3>, dim3(b1), dim3(threads), 0, h->stream, a, 0);
-    hipLaunchKernelGGL(contact_pressure_kernel, dim3(b2), dim3(threads), 0, h->stream, h->n_marked, h->area.ptr, h->gap.ptr, h->penalty, h->pressure.ptr);
-    hipLaunchKernelGGL(contact_residual_kernel<3>, dim3(b3), dim3(64), 0, h->stream, a, with_grad ? 1 : 0);
-  }
+  hipLaunchKernelGGL(contact_pressure_kernel, dim3(b2), dim3(threads), 0, h->stream, h->n_marked, h->area.ptr, h->gap.ptr, h->penalty, h->pressure.ptr);
+  if (h->dim == 2) hipLaunchKernelGGL(contact_residual_kernel<2>, dim3(b3), dim3(64), 0, h->stream, a, with_grad ? 1 : 0);
+  else hipLaunchKernelGGL(contact_residual_kernel<3>, dim3(b3), dim3(64), 0, h->stream, a, with_grad ? 1 : 0);
   MH_HIP(hipGetLastError());
-  mr.finish(h->stream);
-  if (with_grad) mA.finish(h->stream);
-  if (mu.host || mr.host || (with_grad && mA.host)) MH_HIP(hipStreamSynchronize(h->stream));
+}
+
+// which: 1 = pass 1 only (u), 2 = pass 2 only (u, r, A), 3 = both (the single-process call)
+static void run_contact(mimi_hip_contact_s* h, const double* u, double* r, double* A, double gf, bool with_grad, int which = 3) {
+  MH_HIP(hipSetDevice(h->device));
+  if (!u || ((which & 2) && (!r || (with_grad && !A)))) fail("null vector argument");
+  Mirror<double> mu = Mirror<double>::in(u, h->n_vdofs, h->stage_u, h->stream);
+  Mirror<double> mr, mA;
+  if (which & 2) mr = Mirror<double>::inout(r, h->n_vdofs, h->stage_r, h->stream);
+  if ((which & 2) && with_grad) mA = Mirror<double>::inout(A, h->nnz, h->stage_A, h->stream);
+  if (which & 1) contact_pass1(h, mu.dev);
+  if (which & 2) {
+    contact_pass2(h, mu.dev, mr.dev, mA.dev, gf, with_grad);
+    mr.finish(h->stream);
+    if (with_grad) mA.finish(h->stream);
+  }
+  if (mu.host || mr.host || mA.host) MH_HIP(hipStreamSynchronize(h->stream));
 }
 
 extern "C" {
@@ -503,6 +516,7 @@ int mimi_hip_contact_create(const mimi_hip_contact_tables* t, int device, mimi_h
     std::sort(marked.begin(), marked.end());
     marked.erase(std::unique(marked.begin(), marked.end()), marked.end());
     h->n_marked = (int)marked.size();
+    h->marked_nodes = marked;
     std::vector<int32_t> local(nfd);
     for (size_t k = 0; k < nfd; ++k)
       local[k] = (int32_t)(std::lower_bound(marked.begin(), marked.end(), dofs[k]) - marked.begin());
@@ -622,6 +636,47 @@ int mimi_hip_contact_last_history(mimi_hip_contact_t h, double* out5) {
     MH_HIP(hipSetDevice(h->device));
     MH_HIP(hipMemcpyAsync(out5, h->scalars.ptr, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     MH_HIP(hipStreamSynchronize(h->stream));
+  });
+}
+
+int mimi_hip_contact_gap_area(mimi_hip_contact_t h, const double* u) {
+  return guarded_c([&] {
+    if (!h) fail("null handle");
+    run_contact(h, u, nullptr, nullptr, 0.0, false, 1);
+  });
+}
+
+int mimi_hip_contact_marked_nodes(mimi_hip_contact_t h, int32_t* out, int64_t capacity, int64_t* n) {
+  return guarded_c([&] {
+    if (!h || !n) fail("null argument");
+    *n = h->n_marked;
+    if (!out) return;
+    if (capacity < h->n_marked) fail("node buffer too small");
+    std::copy(h->marked_nodes.begin(), h->marked_nodes.end(), out);
+  });
+}
+
+int mimi_hip_contact_nodal(mimi_hip_contact_t h, int set, double* area, double* gap) {
+  return guarded_c([&] {
+    if (!h || !area || !gap) fail("null argument");
+    MH_HIP(hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->n_marked * sizeof(double);
+    if (set) {
+      MH_HIP(hipMemcpyAsync(h->area.ptr, area, bytes, hipMemcpyDefault, h->stream));
+      MH_HIP(hipMemcpyAsync(h->gap.ptr, gap, bytes, hipMemcpyDefault, h->stream));
+    } else {
+      MH_HIP(hipMemcpyAsync(area, h->area.ptr, bytes, hipMemcpyDefault, h->stream));
+      MH_HIP(hipMemcpyAsync(gap, h->gap.ptr, bytes, hipMemcpyDefault, h->stream));
+    }
+    if (!is_device_pointer(area) || !is_device_pointer(gap)) MH_HIP(hipStreamSynchronize(h->stream));
+  });
+}
+
+int mimi_hip_contact_add_residual_from_nodal(mimi_hip_contact_t h, const double* u, double grad_factor, double* r,
+                                             double* A_values) {
+  return guarded_c([&] {
+    if (!h) fail("null handle");
+    run_contact(h, u, r, A_values, grad_factor, A_values != nullptr, 2);
   });
 }
 

@@ -304,8 +304,10 @@ class MortarContact(NonlinearBase):
     """integrators::MortarContact (integrators/mortar_contact.hpp:23-172) against an analytic
     rigid body, on one face of a B-spline patch."""
 
-    def __init__(self, nearest_distance_coeff, name, pattern, patch, axis, side, device=0, quadrature_order=-1):
+    def __init__(self, nearest_distance_coeff, name, pattern, patch, axis, side, device=0, quadrature_order=-1,
+                 element_box=None):
         super().__init__(name)
+        self.element_box_ = element_box          # multi-GPU: only the faces of the elements of this slab
         self.nearest_distance_coeff_ = nearest_distance_coeff
         self.pattern_, self.patch_ = pattern, patch
         self.axis_, self.side_ = axis, side
@@ -319,7 +321,9 @@ class MortarContact(NonlinearBase):
         from . import splines
         L = _capi.lib()
         p = self.patch_
-        dofs, N, dN, weight = splines.face_tables(p, self.axis_, self.side_, self.quadrature_order_)
+        dofs, N, dN, weight = splines.face_tables(p, self.axis_, self.side_, self.quadrature_order_, self.element_box_)
+        if len(dofs) == 0:
+            raise RuntimeError("no marked boundary faces in this element box")
         t = _capi.ContactTables()
         t.dim = p.dim
         t.n_faces, t.n_dof = dofs.shape
@@ -349,6 +353,32 @@ class MortarContact(NonlinearBase):
         if self._h is None:
             raise RuntimeError("Prepare() has not been called")
         return self._h
+
+    def Synchronize(self):
+        check(_capi.lib().mimi_hip_contact_synchronize(self._handle()))
+
+    # -- the two halves of an evaluation, for element slabs on several GPUs (mimi_amd/parallel.py ShardedContact) -----
+    def GapArea(self, current_u):
+        """pass 1 only: nodal area / gap of this handle's faces"""
+        check(_capi.lib().mimi_hip_contact_gap_area(self._handle(), ptr(current_u)))
+
+    def MarkedNodes(self):
+        n = C.c_int64(0)
+        check(_capi.lib().mimi_hip_contact_marked_nodes(self._handle(), None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=np.int32)
+        check(_capi.lib().mimi_hip_contact_marked_nodes(self._handle(), ptr(out), out.size, C.byref(n)))
+        return out
+
+    def GetNodal(self, area, gap):
+        check(_capi.lib().mimi_hip_contact_nodal(self._handle(), 0, ptr(area), ptr(gap)))
+
+    def SetNodal(self, area, gap):
+        check(_capi.lib().mimi_hip_contact_nodal(self._handle(), 1, ptr(area), ptr(gap)))
+
+    def AddBoundaryResidualFromNodal(self, current_u, grad_factor, residual, grad=None):
+        """pressure from the (summed) nodal area / gap, then pass 2"""
+        check(_capi.lib().mimi_hip_contact_add_residual_from_nodal(self._handle(), ptr(current_u), float(grad_factor),
+                                                                   ptr(residual), ptr(grad)))
 
     def SetTangentMode(self, mode):
         check(_capi.lib().mimi_hip_contact_set_tangent_mode(self._handle(), mode))

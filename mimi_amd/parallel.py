@@ -216,3 +216,68 @@ class InterfaceExchange:
 
     def sum_residual_and_grad(self):
         self._exchange(True)
+
+
+class ShardedContact:
+    """MortarContact over the faces of this rank's element slab.  The one extra exchange of the contact
+    path: the nodal area / gap of the nodes shared between slabs are summed over the ranks before the pressure is
+    formed -- a small all-reduce over the nodes of the contact face (two doubles per node); the residual / Jacobian rows
+    then travel with the domain integrator's InterfaceExchange like any other contribution."""
+
+    def __init__(self, shard, body, pattern, axis, side, device=0, quadrature_order=-1, name="contact"):
+        import torch
+        import torch.distributed as dist
+        from .integrators import MortarContact
+        self.torch, self.dist = torch, dist
+        self.shard = shard
+        patch = shard.patch
+        self.contact = None
+        try:
+            self.contact = MortarContact(body, name, pattern, patch, axis, side, device=device,
+                                         quadrature_order=quadrature_order, element_box=shard.element_box).Prepare()
+        except RuntimeError as e:                      # this slab does not touch the contact face
+            if "no marked boundary faces" not in str(e):
+                raise
+        face_nodes = patch.boundary_nodes(axis, side)                 # sorted global node ids of the whole face
+        self.n_face = len(face_nodes)
+        if self.contact is not None:
+            self.slot = torch.from_numpy(np.searchsorted(face_nodes, self.contact.MarkedNodes()).astype(np.int64))
+        backend = dist.get_backend() if dist.is_initialized() else None
+        self.comm_device = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
+        self.device = torch.device("cuda", device)
+
+    def SetStream(self, stream):
+        if self.contact is not None:
+            self.contact.SetStream(stream)
+
+    def _sum_nodal(self, u):
+        torch = self.torch
+        buf = torch.zeros(2, self.n_face, dtype=torch.float64, device=self.comm_device)
+        if self.contact is not None:
+            c = self.contact
+            c.GapArea(u)
+            n = len(self.slot)
+            area = torch.empty(n, dtype=torch.float64, device=self.device)
+            gap = torch.empty(n, dtype=torch.float64, device=self.device)
+            c.GetNodal(area, gap)
+            c.Synchronize()
+            slot = self.slot.to(self.comm_device)
+            buf[0, slot] = area.to(self.comm_device)
+            buf[1, slot] = gap.to(self.comm_device)
+        if self.dist.is_initialized() and self.dist.get_world_size() > 1:
+            self.dist.all_reduce(buf)
+        if self.contact is not None:
+            area = buf[0, slot].to(self.device).contiguous()
+            gap = buf[1, slot].to(self.device).contiguous()
+            self.contact.SetNodal(area, gap)
+            self._keep = (area, gap)
+
+    def AddBoundaryResidual(self, u, r):
+        self._sum_nodal(u)
+        if self.contact is not None:
+            self.contact.AddBoundaryResidualFromNodal(u, 0.0, r, None)
+
+    def AddBoundaryResidualAndGrad(self, u, grad_factor, r, A):
+        self._sum_nodal(u)
+        if self.contact is not None:
+            self.contact.AddBoundaryResidualFromNodal(u, grad_factor, r, A)

@@ -118,13 +118,14 @@ def _tables_1d(knots, p, nq):
     return np.array(spans), B, D, w
 
 
-def face_tables(patch, axis, side, quadrature_order=-1):
+def face_tables(patch, axis, side, quadrature_order=-1, element_box=None):
     """Boundary-element tables of the patch face {xi_axis = side}: what the reference's
     MortarContact reads from PrecomputedData for its marked boundary elements
     (QuadData::N, dN_dxi, integration_weight; src/mimi/utils/precomputed.cpp:100-143,295-311).
     The face parametrisation is oriented so that the surface normal of
     ComputeUnitNormal (integrators/integrator_utils.hpp:216-251) points out of the body.
-    Returns dofs[f,a] (int32), N[f,q,a], dN_dxi[f,q,dim-1,a], weight[f,q]."""
+    Returns dofs[f,a] (int32), N[f,q,a], dN_dxi[f,q,dim-1,a], weight[f,q].
+    element_box = (begin, end): only the faces of the elements in that box (multi-GPU element slabs)."""
     if getattr(patch, "weights", None) is not None:
         raise RuntimeError("face tables of a rational patch are not generated here: pass the reference's boundary tables")
     dim = patch.dim
@@ -153,6 +154,7 @@ def face_tables(patch, axis, side, quadrature_order=-1):
         if flip:
             N, dN, wq = N[:, ::-1, :], -dN[:, ::-1, :, :], wq[::-1]
         weight = np.broadcast_to(wq, (len(spans), nq)).copy()
+        face_el = [np.arange(len(spans))]
     else:
         (s0, B0, D0, w0), (s1, B1, D1, w1) = tabs
         t0, t1 = tang
@@ -169,5 +171,13 @@ def face_tables(patch, axis, side, quadrature_order=-1):
         d1 = np.einsum("fax,fby->fyxba", B0[f0], D1[f1]).reshape(nf, nq * nq, -1)
         dN = np.stack([d0, d1], axis=2)
         weight = np.broadcast_to(np.einsum("y,x->yx", w1, w0).ravel(), (nf, nq * nq)).copy()
+        face_el = [f0, f1]
+    if element_box is not None:
+        b, e = element_box
+        parent = 0 if side == 0 else patch.n_spans[axis] - 1
+        keep = np.full(len(dofs), b[axis] <= parent < e[axis])
+        for t, fe in zip(tang, face_el):
+            keep &= (fe >= b[t]) & (fe < e[t])
+        dofs, N, dN, weight = dofs[keep], N[keep], dN[keep], weight[keep]
     return (np.ascontiguousarray(dofs, dtype=np.int32), np.ascontiguousarray(N), np.ascontiguousarray(dN),
             np.ascontiguousarray(weight))

@@ -95,3 +95,26 @@ def test_slab_shard_boxes():
     assert boxes[0] == ([0, 0, 0], [128, 16, 16]) and boxes[7] == ([0, 112, 0], [128, 128, 16])
     with pytest.raises(RuntimeError):
         parallel.SlabShard(mimi_amd.BSplinePatch.block((2, 2, 3), 2), None, 0, 3)
+
+
+def test_contact_faces_follow_their_element_slab():
+    """the faces of a patch face split between the slabs without overlap or loss (mimi_amd/splines.py face_tables)"""
+    import mimi_amd
+    from mimi_amd import parallel, splines
+    from mimi_amd.integrators import CSRPattern
+    patch = mimi_amd.BSplinePatch.block((3, 7, 2), 2)
+    full = splines.face_tables(patch, 2, 1)
+    pattern = CSRPattern(np.zeros(patch.n_vdofs + 1, dtype=np.int64), np.zeros(0, dtype=np.int32), 0)
+    rows = []
+    for rank in range(3):
+        shard = parallel.SlabShard(patch, pattern, rank, 3)
+        part = splines.face_tables(patch, 2, 1, element_box=shard.element_box)
+        rows.append(part[0])
+        assert part[1].shape[0] == part[0].shape[0] == part[2].shape[0] == part[3].shape[0]
+    got = np.concatenate(rows)
+    assert got.shape == full[0].shape
+    assert sorted(map(tuple, got)) == sorted(map(tuple, full[0]))
+    # a face on the far side of the slab axis belongs to the last slab only
+    patch2 = mimi_amd.BSplinePatch.block((3, 2, 6), 2)
+    n = [len(splines.face_tables(patch2, 2, 1, element_box=parallel.SlabShard(patch2, pattern, r, 2).element_box)[0]) for r in range(2)]
+    assert n == [0, 6]

@@ -107,3 +107,82 @@ def test_slabs_on_one_gpu(world, n_el, mode):
     assert all(ok is True for _, ok, _ in results), results
     if mode.startswith("owner"):
         assert sum(n for _, _, n in results) == int(np.prod([n + 2 for n in n_el]))
+
+
+def _contact_worker(rank, world, port, n_el, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        import mimi_amd
+        from mimi_amd import parallel
+        from mimi_amd.integrators import CSRPattern, MortarContact, RigidSphere
+        dev = torch.device("cuda", 0)
+        patch = mimi_amd.BSplinePatch.block(n_el, 2)
+        pattern = CSRPattern.of_bspline_patch(patch, on_device=True)
+        shard = parallel.SlabShard(patch, pattern, rank, world)
+        L = patch.control_points.max(axis=0)
+        R = 0.25 * L[0]
+        centre = 0.5 * L
+        centre[2] = L[2] + 0.9 * R                                   # sphere over the top face
+        body = RigidSphere(list(centre), R, 1e4)
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        sc = parallel.ShardedContact(shard, body, pattern, 2, 1)
+        sc.SetStream(stream.cuda_stream)
+        u = torch.from_numpy(bench.synthetic_u(patch, scale=0.01)).to(dev)
+        r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
+        A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
+        ex = parallel.InterfaceExchange(shard, r, A, dev, mode="replicate")
+        sc.AddBoundaryResidualAndGrad(u, 0.7, r, A)
+        if sc.contact is not None:
+            sc.contact.Synchronize()
+        stream.synchronize()
+        ex.sum_residual_and_grad()
+        stream.synchronize()
+        # the whole face on one handle
+        Gf = MortarContact(body, "contact", pattern, patch, 2, 1).Prepare()
+        rf, Af = torch.zeros_like(r), torch.zeros_like(A)
+        Gf.AddBoundaryResidualAndGrad(u, 0.7, rf, Af)
+        Gf.Synchronize()
+        # after the replicate exchange this rank holds the complete rows of every node its elements touch
+        b, e = shard.element_box
+        mi_axis = patch.node_multi_index()[shard.axis]
+        mine = np.nonzero((mi_axis >= b[shard.axis]) & (mi_axis < e[shard.axis] + 2))[0]
+        rowptr = pattern.rowptr.cpu().numpy()
+        r_h, A_h, rf_h, Af_h = r.cpu().numpy(), A.cpu().numpy(), rf.cpu().numpy(), Af.cpu().numpy()
+        er = eA = 0.0
+        for node in mine:
+            for i in range(3):
+                row = node * 3 + i
+                s, t = rowptr[row], rowptr[row + 1]
+                er = max(er, abs(r_h[row] - rf_h[row]))
+                eA = max(eA, np.abs(A_h[s:t] - Af_h[s:t]).max())
+        ok = np.abs(rf_h).max() > 0 and er < 1e-11 * np.abs(rf_h).max() and eA < 1e-11 * np.abs(Af_h).max()
+        q.put((rank, bool(ok), (er, eA, float(np.abs(rf_h).max()))))
+    except Exception as exc:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_el", [(2, (4, 6, 2)), (3, (3, 9, 2))])
+def test_sharded_contact_on_one_gpu(world, n_el):
+    """cfg4 in miniature: contact faces follow their element slab; the nodal area / gap of the nodes shared between
+    slabs are summed over the ranks before the pressure is formed; rows then travel with the interface exchange."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31700 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_contact_worker, args=(r, world, port, n_el, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+    assert all(ok is True for _, ok, _ in results), results
