@@ -32,6 +32,7 @@ WORKLOADS = {
     "northstar": ((128, 128, 16), 2, "neohookean"),
     "cfg3": ((128, 128, 16), 3, "j2"),
     "northstar_j2": ((128, 128, 16), 2, "j2"),
+    "cfg3_neo": ((128, 128, 16), 3, "neohookean"),
     # the reference's other materials (general kernels, dual-number tangents): measured for DESIGN.md only
     "cfg2_stvk": ((64, 64, 8), 2, "stvk"),
     "cfg2_j2linear": ((64, 64, 8), 2, "j2linear"),

@@ -255,12 +255,66 @@ static GeneralArgs general_args(mimi_hip_domain_s* h, const double* u, double* r
   return a;
 }
 
+// two-phase general path (64-node elements): element blocks densely into scratch_k, then general_gather_kernel.  Needs
+// n_el * 192^2 doubles (77 GB at 128 x 128 x 16 p = 3) and the node -> element adjacency; falls back to the atomics when
+// the scratch does not fit (MIMI_HIP_GENERAL_NO_TWO_PHASE=1 forces that)
+static bool ensure_general_two_phase(mimi_hip_domain_s* h) {
+  static const bool off = getenv("MIMI_HIP_GENERAL_NO_TWO_PHASE") && getenv("MIMI_HIP_GENERAL_NO_TWO_PHASE")[0] == '1';
+  if (off || h->general_two_phase_failed) return false;
+  const size_t need = (size_t)h->n_el * 192 * 192;
+  if (h->scratch_k.count < need) {
+    size_t free_b = 0, total_b = 0;
+    MH_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t have = h->scratch_k.count * sizeof(double);
+    if (need * sizeof(double) > free_b + have || need * sizeof(double) > (total_b / 2)) {
+      h->general_two_phase_failed = true;
+      return false;
+    }
+    h->scratch_k.resize(need);
+  }
+  if (!h->adj_ptr.ptr) {
+    // the gather kernel keeps one CSR row in LDS: rows longer than its image (not the structured p = 3 pattern) -> atomics
+    std::vector<int64_t> rp((size_t)h->n_vdofs + 1);
+    MH_HIP(hipMemcpy(rp.data(), h->rowptr, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+    int64_t longest = 0;
+    for (int64_t v = 0; v < h->n_vdofs; ++v) longest = std::max(longest, rp[v + 1] - rp[v]);
+    if (longest > GG_MAX_ROW) {
+      h->general_two_phase_failed = true;
+      return false;
+    }
+    const size_t n = (size_t)h->n_el * 64;
+    std::vector<int32_t> dofs(n);
+    MH_HIP(hipMemcpy(dofs.data(), h->dofs.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int64_t n_nodes = h->n_vdofs / 3;
+    std::vector<int64_t> ptr(n_nodes + 1, 0);
+    for (size_t k = 0; k < n; ++k) ++ptr[dofs[k] + 1];
+    for (int64_t v = 0; v < n_nodes; ++v) ptr[v + 1] += ptr[v];
+    std::vector<int32_t> adj(n);
+    std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
+    for (size_t k = 0; k < n; ++k) adj[fill[dofs[k]]++] = (int32_t)k;   // k = e * 64 + a
+    h->adj_ptr.assign(ptr.data(), ptr.size(), h->stream);
+    h->adj.assign(adj.data(), adj.size(), h->stream);
+  }
+  return true;
+}
+
 #ifndef GEN_BIG_PP
 #define GEN_BIG_PP 8
 #define GEN_BIG_THREADS 512
 #endif
 template<int DIM>
-static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a) {
+static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a_in) {
+  GeneralArgs a = a_in;
+  static const bool no_mfma_env = getenv("MIMI_HIP_GENERAL_NO_MFMA") && getenv("MIMI_HIP_GENERAL_NO_MFMA")[0] == '1';
+  const bool two_phase = grad == 1 && DIM == 3 && h->n_dof == 64 && !no_mfma_env && ensure_general_two_phase(h);
+  a.scratch_k = two_phase ? h->scratch_k.ptr : nullptr;
+  auto gather = [&]() {
+    if (!two_phase) return;
+    const int64_t n_rows = h->n_vdofs;
+    hipLaunchKernelGGL(general_gather_kernel, dim3((unsigned)((n_rows + GG_WAVES - 1) / GG_WAVES)), dim3(64 * GG_WAVES), 0, h->stream,
+                       n_rows, h->rowptr, h->adj_ptr.ptr, h->adj.ptr, h->pair_pos.ptr, h->scratch_k.ptr, a.grad_factor, a.A);
+    MH_HIP(hipGetLastError());
+  };
   const size_t lds = general_lds_bytes(DIM, h->n_dof, h->n_q, grad);
   if (lds > 160 * 1024) fail("element too large for LDS (%zu bytes)", lds);
   auto go = [&](auto kernel, int threads = 256) {
@@ -269,15 +323,19 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a)
     hipLaunchKernelGGL(kernel, dim3(h->n_el), dim3(threads), lds, h->stream, a);
     MH_HIP(hipGetLastError());
   };
+  // MIMI_HIP_GENERAL_NO_MFMA=1: the vector-pipe node-pair phase also for 64-node elements (A/B comparisons)
+  static const bool no_mfma = getenv("MIMI_HIP_GENERAL_NO_MFMA") && getenv("MIMI_HIP_GENERAL_NO_MFMA")[0] == '1';
   if (!material_closed_form(h->mat.m.kind)) {
     // the other materials: same kernel, stress and tangent from materials_other.hpp
     if (grad == 0) go(domain_general_kernel<DIM, 0, 3, 256, 1>);
+    else if (grad == 1 && DIM == 3 && h->n_dof == 64 && !no_mfma) { go(domain_general_kernel<3, 1, GEN_BIG_PP, GEN_BIG_THREADS, 1, 1>, GEN_BIG_THREADS); gather(); }
     else if (grad == 1 && h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, GEN_BIG_PP, GEN_BIG_THREADS, 1>, GEN_BIG_THREADS);
     else if (grad == 1) go(domain_general_kernel<DIM, 1, 3, 256, 1>);
     else go(domain_general_kernel<DIM, 2, 3, 256, 1>);
     return;
   }
   if (grad == 0) go(domain_general_kernel<DIM, 0>);
+  else if (grad == 1 && DIM == 3 && h->n_dof == 64 && !no_mfma) { go(domain_general_kernel<3, 1, GEN_BIG_PP, GEN_BIG_THREADS, 0, 1>, GEN_BIG_THREADS); gather(); }
   else if (grad == 1 && h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, GEN_BIG_PP, GEN_BIG_THREADS>, GEN_BIG_THREADS);
   else if (grad == 1) go(domain_general_kernel<DIM, 1, 3>);
   else go(domain_general_kernel<DIM, 2>);

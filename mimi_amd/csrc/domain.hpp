@@ -22,6 +22,9 @@ struct mimi_hip_domain_s {
   mimi_hip::DeviceBuffer<double> wdet;       // [n_el][n_q]
   mimi_hip::DeviceBuffer<int32_t> pair_pos;  // [n_el][n_dof][n_dof]
   mimi_hip::DeviceBuffer<int64_t> rowptr_own;
+  mimi_hip::DeviceBuffer<int64_t> adj_ptr;   // two-phase general path: node -> incident (element, local index) list
+  mimi_hip::DeviceBuffer<int32_t> adj;
+  bool general_two_phase_failed = false;
   const int64_t* rowptr = nullptr;           // device
 
   // tensor path tables

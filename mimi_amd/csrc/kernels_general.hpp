@@ -39,6 +39,7 @@ struct GeneralArgs {
   MaterialDev mat;
   StateView state;
   int* status;
+  double* scratch_k;        // MF kernels: dense element blocks [n_el][(a, i)][(b, j)] instead of atomics (then gathered)
 };
 
 MH_DEV void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
@@ -97,7 +98,11 @@ MH_DEV void compute_F_general(int n_dof, const double* __restrict__ g /* [DIM][n
 // passes of larger elements)
 // THREADS: workgroup size (256; 512 for elements with more than 768 node pairs: one pass of the node-pair phase for p = 3)
 // FAMILY: 0 neo-Hookean / J2 (closed-form tangents, materials.hpp); 1 the other materials (materials_other.hpp)
-template<int DIM, int GRAD, int PP = 3, int THREADS = 256, int FAMILY = 0>
+// MF: 1 = node-pair phase on the fp64 matrix instruction (3-D, 64 nodes per element = p 3, 512 threads): per quadrature
+//     point K[(a), (b, i, j)] += sum_J g[J][a] * (sum_L A_q[iJ, jL] g[L][b]) is a 64 x 576 x 3 product; wave w owns the
+//     16 column nodes b of tile w & 3 and two of the four 16-row tiles, 18 accumulator tiles (2 x 9 (i, j)) in registers
+typedef double mhg_d4 __attribute__((ext_vector_type(4)));
+template<int DIM, int GRAD, int PP = 3, int THREADS = 256, int FAMILY = 0, int MF = 0>
 __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domain_general_kernel(GeneralArgs p) {
   constexpr int DD = DIM * DIM;
   constexpr int D4 = DD * DD;
@@ -178,7 +183,86 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
     atomic_add_f64(&p.r[(int64_t)node[a] * DIM + i], s);
   }
 
-  if constexpr (GRAD == 1) {
+  if constexpr (GRAD == 1 && MF == 1) {
+    static_assert(DIM == 3 && THREADS == 512, "matrix-instruction node-pair phase: 3-D, 512 threads");
+    // phase 3 on v_mfma_f64_16x16x4: A operand [row = lane % 16][k = lane / 16] = g[J = k][a], B operand
+    // [k = lane / 16][col = lane % 16] = sum_L A_q[iJ, jL] g[L][b], D register r of lane l:
+    // row (l / 16) + 4 r, column l % 16
+    constexpr int QC = 8;
+    double* gC = Aw + n_q * D4 + n_dof * (DD * DIM);   // [QC][DIM][n_dof] (the T buffer of the other route is unused)
+    const int wave = tid >> 6, lane = tid & 63;
+    const int nt = wave & 3, mh = wave >> 2;
+    const int l16 = lane & 15, kk = lane >> 4;
+    mhg_d4 acc[2][DD];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int c = 0; c < DD; ++c) acc[mt][c] = mhg_d4{0.0, 0.0, 0.0, 0.0};
+    for (int q0 = 0; q0 < n_q; q0 += QC) {
+      const int nqc = n_q - q0 < QC ? n_q - q0 : QC;
+      __syncthreads();
+      for (int t = tid; t < nqc * n_tdof; t += blockDim.x) gC[t] = gE[(int64_t)q0 * n_tdof + t];
+      __syncthreads();
+      // the K index of the product is the flattened (point, J): four consecutive values per matrix instruction, no padding
+      // (lane group kk takes value 4 s + kk of the chunk: its own point and J)
+      const int n_k = nqc * DIM;
+      for (int s4 = 0; s4 < n_k; s4 += 4) {
+        const int kidx = s4 + kk;
+        const bool valid = kidx < n_k;
+        const int qq = valid ? kidx / DIM : 0, J = valid ? kidx % DIM : 0;
+        const double* g = gC + qq * n_tdof;
+        const double* Aq = Aw + (q0 + qq) * D4;
+        const double a0 = valid ? g[J * n_dof + 16 * (2 * mh) + l16] : 0.0;
+        const double a1 = valid ? g[J * n_dof + 16 * (2 * mh + 1) + l16] : 0.0;
+        double gb[DIM];
+#pragma unroll
+        for (int L = 0; L < DIM; ++L) gb[L] = g[L * n_dof + 16 * nt + l16];
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+#pragma unroll
+          for (int j = 0; j < DIM; ++j) {
+            const double* Ar = Aq + ((i * DIM + J) * DIM + j) * DIM;
+            double bv = 0.0;
+#pragma unroll
+            for (int L = 0; L < DIM; ++L) bv += Ar[L] * gb[L];
+            bv = valid ? bv : 0.0;
+            acc[0][i * DIM + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0][i * DIM + j], 0, 0, 0);
+            acc[1][i * DIM + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1][i * DIM + j], 0, 0, 0);
+          }
+      }
+    }
+    const int32_t* pp_tab = p.pair_pos + (int64_t)e * n_dof * n_dof;
+    const int b = 16 * nt + l16;
+    if (p.scratch_k) {
+      // two-phase: the element block goes out densely, row (a, i) = 192 contiguous doubles [b][j]; general_gather_kernel
+      // sums the rows of every CSR row afterwards (the scattered fp64 atomics below run memory-side and bound this path)
+      double* Ke = p.scratch_k + (int64_t)e * (n_tdof * n_tdof);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = 16 * (2 * mh + mt) + kk + 4 * r;
+#pragma unroll
+          for (int i = 0; i < DIM; ++i)
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) Ke[((a * DIM + i) * n_dof + b) * DIM + j] = acc[mt][i * DIM + j][r];
+        }
+    } else
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = 16 * (2 * mh + mt) + kk + 4 * r;
+        const int64_t rowA = (int64_t)node[a] * DIM;
+        const int32_t off = pp_tab[a * n_dof + b];
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) {
+          double* dst = p.A + p.rowptr[rowA + i] + off;
+#pragma unroll
+          for (int j = 0; j < DIM; ++j) atomic_add_f64(dst + j, p.grad_factor * acc[mt][i * DIM + j][r]);
+        }
+      }
+  } else if constexpr (GRAD == 1) {
     // phase 3: node-pair blocks K(ai,bj) = sum_q sum_J ga[J] T_b[iJ][j],  T_b[iJ][j] = sum_L A_q[iJ,jL] gb[L].
     // Per quadrature point T is built once for all nodes b (n_dof DIM^3 values in LDS), then every lane adds its
     // node pairs: DIM^3 multiply-adds per (pair, point) instead of DIM^4 + DIM^3.
@@ -329,6 +413,44 @@ __global__ __launch_bounds__(256) void post_time_advance_general_kernel(GeneralA
     else status |= accumulate_state<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F);
   }
   if (status) atomicOr(p.status, status);
+}
+
+// phase 2 of the two-phase general path (64-node elements): one wave per CSR row (node, i).  The wave walks the elements
+// that contain the node (adjacency built at setup), adds row (a, i) of each element block into an LDS image of the CSR
+// row through the pair positions (lane = column node b: distinct positions within an instruction), then adds the image
+// to the caller's values in one coalesced pass: no atomics, a fixed summation order.
+constexpr int GG_WAVES = 4;
+constexpr int GG_MAX_ROW = 1056;   // (2 p + 1)^3 neighbours x 3 at p = 3 is 1029
+__global__ __launch_bounds__(64 * GG_WAVES) void general_gather_kernel(int64_t n_rows, const int64_t* __restrict__ rowptr,
+                                                                       const int64_t* __restrict__ adj_ptr, const int32_t* __restrict__ adj,
+                                                                       const int32_t* __restrict__ pair_pos, const double* __restrict__ scratch_k,
+                                                                       double grad_factor, double* __restrict__ A) {
+  constexpr int DIM = 3, ND = 64, NT = ND * DIM;
+  __shared__ double img_all[GG_WAVES][GG_MAX_ROW];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * GG_WAVES + wave;
+  if (row >= n_rows) return;
+  double* img = img_all[wave];
+  const int64_t node = row / DIM;
+  const int i = (int)(row % DIM);
+  const int64_t beg = rowptr[row];
+  const int len = (int)(rowptr[row + 1] - beg);
+  for (int k = lane; k < len; k += 64) img[k] = 0.0;
+  __builtin_amdgcn_wave_barrier();
+  for (int64_t t = adj_ptr[node]; t < adj_ptr[node + 1]; ++t) {
+    const int32_t ea = adj[t];
+    const int64_t e = ea >> 6;
+    const int a = ea & 63;
+    const double* Kr = scratch_k + (e * NT + (a * DIM + i)) * (int64_t)NT + lane * DIM;
+    const int32_t off = pair_pos[(e * ND + a) * ND + lane];
+    const double v0 = Kr[0], v1 = Kr[1], v2 = Kr[2];
+    img[off] += v0;
+    img[off + 1] += v1;
+    img[off + 2] += v2;
+    __builtin_amdgcn_wave_barrier();
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int k = lane; k < len; k += 64) A[beg + k] += grad_factor * img[k];
 }
 
 inline size_t general_lds_bytes(int dim, int n_dof, int n_q, int grad) {
