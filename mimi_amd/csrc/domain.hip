@@ -315,8 +315,25 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a_
                        n_rows, h->rowptr, h->adj_ptr.ptr, h->adj.ptr, h->pair_pos.ptr, h->scratch_k.ptr, a.grad_factor, a.A);
     MH_HIP(hipGetLastError());
   };
-  const size_t lds = general_lds_bytes(DIM, h->n_dof, h->n_q, grad);
+  size_t lds = general_lds_bytes(DIM, h->n_dof, h->n_q, grad);
   if (lds > 160 * 1024) fail("element too large for LDS (%zu bytes)", lds);
+  // small elements (one pass of the node-pair phase fits one wave: 2-D p <= 3, 3-D p = 1): one wave per element, four
+  // elements per workgroup (MIMI_HIP_GENERAL_NO_WPE=1: one workgroup per element as for the large ones)
+  static const bool no_wpe = getenv("MIMI_HIP_GENERAL_NO_WPE") && getenv("MIMI_HIP_GENERAL_NO_WPE")[0] == '1';
+  const bool wpe = !no_wpe && grad != 2 && h->n_dof * ((h->n_dof + 2) / 3) <= 128 && h->n_q <= 64;
+  if (wpe) {
+    a.lds_per_element = (int)((lds + 15) / 16 * 16);
+    lds = (size_t)a.lds_per_element * 4;
+    auto gow = [&](auto kernel) {
+      if (lds > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)((h->n_el + 3) / 4)), dim3(256), lds, h->stream, a);
+      MH_HIP(hipGetLastError());
+    };
+    const bool other = !material_closed_form(h->mat.m.kind);
+    if (grad == 0) { if (other) gow(domain_general_kernel<DIM, 0, 3, 256, 1, 0, 1>); else gow(domain_general_kernel<DIM, 0, 3, 256, 0, 0, 1>); }
+    else { if (other) gow(domain_general_kernel<DIM, 1, 3, 256, 1, 0, 1>); else gow(domain_general_kernel<DIM, 1, 3, 256, 0, 0, 1>); }
+    return;
+  }
   auto go = [&](auto kernel, int threads = 256) {
     if (lds > 64 * 1024)
       ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);

@@ -39,6 +39,7 @@ struct GeneralArgs {
   MaterialDev mat;
   StateView state;
   int* status;
+  int lds_per_element;      // WPE kernels: bytes of LDS per element (general_lds_bytes rounded up to 16)
   double* scratch_k;        // MF kernels: dense element blocks [n_el][(a, i)][(b, j)] instead of atomics (then gathered)
 };
 
@@ -102,14 +103,20 @@ MH_DEV void compute_F_general(int n_dof, const double* __restrict__ g /* [DIM][n
 //     point K[(a), (b, i, j)] += sum_J g[J][a] * (sum_L A_q[iJ, jL] g[L][b]) is a 64 x 576 x 3 product; wave w owns the
 //     16 column nodes b of tile w & 3 and two of the four 16-row tiles, 18 accumulator tiles (2 x 9 (i, j)) in registers
 typedef double mhg_d4 __attribute__((ext_vector_type(4)));
-template<int DIM, int GRAD, int PP = 3, int THREADS = 256, int FAMILY = 0, int MF = 0>
+#define GEN_SYNC() do { if constexpr (WPE) __builtin_amdgcn_wave_barrier(); else __syncthreads(); } while (0)
+// WPE: 1 = one WAVE per element (small elements: 2-D, p = 1): THREADS / 64 elements per workgroup, every barrier a wave
+//      barrier, the LDS block of the element at wave * general_lds_bytes
+template<int DIM, int GRAD, int PP = 3, int THREADS = 256, int FAMILY = 0, int MF = 0, int WPE = 0>
 __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domain_general_kernel(GeneralArgs p) {
   constexpr int DD = DIM * DIM;
   constexpr int D4 = DD * DD;
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  const int e = blockIdx.x;
-  const int tid = threadIdx.x;
+  extern __shared__ __align__(16) unsigned char smem_all[];
+  const int e = WPE ? blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6) : blockIdx.x;
+  if (WPE && e >= p.n_el) return;   // the whole wave leaves together; the others only use wave barriers
+  const int tid = WPE ? (threadIdx.x & 63) : threadIdx.x;
+  const int n_threads = WPE ? 64 : (int)blockDim.x;
   const int n_dof = p.n_dof, n_q = p.n_q, n_tdof = n_dof * DIM;
+  unsigned char* smem_raw = smem_all + (WPE ? (threadIdx.x >> 6) * p.lds_per_element : 0);
 
   double* u_e = reinterpret_cast<double*>(smem_raw);  // [DIM][n_dof]
   double* Pw = u_e + n_tdof;                          // [n_q][DD]   w*det*P
@@ -120,17 +127,17 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
   const double* gE = p.dN_dX + (int64_t)e * n_q * n_tdof;
   const double* wE = p.wdet + (int64_t)e * n_q;
 
-  for (int t = tid; t < n_dof; t += blockDim.x) node[t] = p.dofs[(int64_t)e * n_dof + t];
-  __syncthreads();
-  for (int t = tid; t < n_tdof; t += blockDim.x) {
+  for (int t = tid; t < n_dof; t += n_threads) node[t] = p.dofs[(int64_t)e * n_dof + t];
+  GEN_SYNC();
+  for (int t = tid; t < n_tdof; t += n_threads) {
     const int a = t % n_dof, i = t / n_dof;
     u_e[t] = p.u[(int64_t)node[a] * DIM + i];
   }
-  __syncthreads();
+  GEN_SYNC();
 
   // phase 1: constitutive update per quadrature point
   int status = 0;
-  for (int q = tid; q < n_q; q += blockDim.x) {
+  for (int q = tid; q < n_q; q += n_threads) {
     double F[DD];
     compute_F_general<DIM>(n_dof, gE + (int64_t)q * n_tdof, u_e, F);
     const double wd = wE[q];
@@ -168,10 +175,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
       }
     }
   }
-  __syncthreads();
+  GEN_SYNC();
 
   // phase 2: residual (AddMult_a_ABt, nonlinear_solid.hpp:79-82)
-  for (int t = tid; t < n_tdof; t += blockDim.x) {
+  for (int t = tid; t < n_tdof; t += n_threads) {
     const int a = t % n_dof, i = t / n_dof;
     double s = 0.0;
     for (int q = 0; q < n_q; ++q) {
@@ -200,9 +207,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
       for (int c = 0; c < DD; ++c) acc[mt][c] = mhg_d4{0.0, 0.0, 0.0, 0.0};
     for (int q0 = 0; q0 < n_q; q0 += QC) {
       const int nqc = n_q - q0 < QC ? n_q - q0 : QC;
-      __syncthreads();
-      for (int t = tid; t < nqc * n_tdof; t += blockDim.x) gC[t] = gE[(int64_t)q0 * n_tdof + t];
-      __syncthreads();
+      GEN_SYNC();
+      for (int t = tid; t < nqc * n_tdof; t += n_threads) gC[t] = gE[(int64_t)q0 * n_tdof + t];
+      GEN_SYNC();
       // the K index of the product is the flattened (point, J): four consecutive values per matrix instruction, no padding
       // (lane group kk takes value 4 s + kk of the chunk: its own point and J)
       const int n_k = nqc * DIM;
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
     // all of them (the LDS traffic of this phase is what bounds large elements)
     const int n_groups = (n_dof + PP - 1) / PP;
     const int n_slots = n_dof * n_groups;
-    for (int slot0 = 0; slot0 < n_slots; slot0 += (int)blockDim.x) {
+    for (int slot0 = 0; slot0 < n_slots; slot0 += (int)n_threads) {
       const int slot = slot0 + tid;
       const bool active = slot < n_slots;
       const int b = active ? slot % n_dof : 0, ag = active ? slot / n_dof : 0;
@@ -288,19 +295,19 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
       for (int q0 = 0; q0 < n_q; q0 += QC) {
         // the gradients of QC quadrature points -> LDS (one global read per value instead of one per use)
         const int nqc = n_q - q0 < QC ? n_q - q0 : QC;
-        for (int t = tid; t < nqc * n_tdof; t += blockDim.x) gC[t] = gE[(int64_t)q0 * n_tdof + t];
-        __syncthreads();
+        for (int t = tid; t < nqc * n_tdof; t += n_threads) gC[t] = gE[(int64_t)q0 * n_tdof + t];
+        GEN_SYNC();
         for (int qq = 0; qq < nqc; ++qq) {
           const double* g = gC + qq * n_tdof;
           const double* Aq = Aw + (q0 + qq) * D4;
-          for (int t = tid; t < n_dof * D3; t += blockDim.x) {
+          for (int t = tid; t < n_dof * D3; t += n_threads) {
             const int bb = t / D3, c = t % D3;   // c = (i*DIM + J)*DIM + j
             double tv = 0.0;
 #pragma unroll
             for (int L = 0; L < DIM; ++L) tv += Aq[c * DIM + L] * g[L * n_dof + bb];
             T[t] = tv;
           }
-          __syncthreads();
+          GEN_SYNC();
           if (active) {
             double Tb[D3];
 #pragma unroll
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
               }
             }
           }
-          __syncthreads();
+          GEN_SYNC();
         }
       }
       if (active) {
@@ -348,14 +355,14 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
     const int n_pairs = n_dof * n_dof;
     const int32_t* pp = p.pair_pos + (int64_t)e * n_pairs;
     for (int c = 0; c < n_tdof; ++c) {
-      __syncthreads();
+      GEN_SYNC();
       const double orig = u_e[c];
       const double step = (orig != 0.0) ? fabs(orig) * 1.0e-8 : 1.0e-10;
       const double step_inv = 1. / step;
-      __syncthreads();
+      GEN_SYNC();
       if (tid == 0) u_e[c] = orig + step;
-      __syncthreads();
-      for (int q = tid; q < n_q; q += blockDim.x) {
+      GEN_SYNC();
+      for (int q = tid; q < n_q; q += n_threads) {
         double F[DD];
         compute_F_general<DIM>(n_dof, gE + (int64_t)q * n_tdof, u_e, F);
         const double wd = wE[q];
@@ -371,10 +378,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
           for (int k = 0; k < DD; ++k) Pw[q * DD + k] = wd * w.P[k];
         }
       }
-      __syncthreads();
+      GEN_SYNC();
       if (tid == 0) u_e[c] = orig;
       const int b = c % n_dof, j = c / n_dof;
-      for (int t = tid; t < n_tdof; t += blockDim.x) {
+      for (int t = tid; t < n_tdof; t += n_threads) {
         const int a = t % n_dof, i = t / n_dof;
         double s = 0.0;
         for (int q = 0; q < n_q; ++q) {
@@ -391,6 +398,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
 
   if (status) atomicOr(p.status, status);
 }
+
+#undef GEN_SYNC
 
 // DomainPostTimeAdvance (nonlinear_solid.cpp:179-199): one lane per quadrature point
 template<int DIM, int FAMILY = 0>
