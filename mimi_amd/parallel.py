@@ -40,8 +40,10 @@ class SlabShard:
         self.element_box = (begin, end)
         self.n_local_elements = int(np.prod([end[d] - begin[d] for d in range(patch.dim)]))
 
-    def overlap_boxes(self):
+    def overlap_boxes(self, layers=None):
         """Split of this slab for overlapping the exchange with compute: (boundary boxes, interior box).
+        layers: element layers per boundary box (default and minimum: the degree p -- more layers give the boundary
+        launch more element columns to fill the chip with, at no cost in exchanged rows).
         The rows of the node planes shared with a neighbour only receive contributions from the `p`
         element layers next to that neighbour, so those layers are integrated first, their interface
         rows go on the wire, and the interior is integrated while they travel.  ([], whole slab) when
@@ -50,7 +52,10 @@ class SlabShard:
         lo, hi = b[self.axis], e[self.axis]
         p = self.patch.degrees[self.axis]
         has_lower, has_upper = self.rank > 0, self.rank < self.world_size - 1
-        need = (p if has_lower else 0) + (p if has_upper else 0)
+        n_sides = int(has_lower) + int(has_upper)
+        if layers is not None and n_sides:
+            p = max(p, min(int(layers), (hi - lo - 1) // n_sides))
+        need = p * n_sides
         if need == 0 or hi - lo < need + 1:
             return [], (list(b), list(e))
 
