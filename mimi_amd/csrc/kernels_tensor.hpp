@@ -60,7 +60,9 @@ struct TensorArgs {
   double* scratch_r;         // two-phase path: [n_el][3][27] element residual pieces
   double* scratch_pt;        // two-phase path, J2: [n_el][24][n_q] material results per quadrature point
   const int64_t* perm;       // two-phase path: lexicographic -> caller's node id (nullptr = identity)
-  int cols_per_wg;           // symmetric-half kernel: element columns a workgroup walks back to back
+  int cols_per_wg;           // symmetric-half kernel: units (element columns / column segments) a workgroup walks back to back
+  int seg_len;               // elements per unit along the walked direction (box_n[2] = whole columns); phase 2: an
+                             // element at the end of a unit holds the carried rows (third part of its pieces)
   const unsigned char* nbr_pos;  // two-phase path, permuted numbering: [n_nodes][125] positions inside a CSR row
 };
 
@@ -737,6 +739,7 @@ inline TensorArgs tensor_args(mimi_hip_domain_s* h, const double* u, double* r, 
     a.tabB[d] = h->tab1d.ptr + h->tab_off_B[d];
     a.tabD[d] = h->tab1d.ptr + h->tab_off_D[d];
   }
+  a.seg_len = a.box_n[2];   // whole columns unless the launcher cuts them (launch_tensor_wgsym)
   // walk along the shortest axis (most units), colour over the other two
   int seq = 0;
   for (int d = 1; d < 3; ++d)

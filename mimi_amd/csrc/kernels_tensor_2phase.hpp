@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
   __builtin_amdgcn_wave_barrier();
   for (int ez = ez_lo; ez <= ez_hi; ++ez) {
     const int a2 = A2 - ez;
-    const int nb = (a2 == 0 || ez == last_ez) ? NROW : ND;
+    const bool unit_end = ez == last_ez || (ez - bx2) % p.seg_len == p.seg_len - 1;
+    const int nb = (a2 == 0 || unit_end) ? NROW : ND;
     const bool act0 = lane < nb, act1 = k1 < nb;
     // P2_BATCH pieces in flight per wave (registers against occupancy)
 #ifndef P2_BATCH

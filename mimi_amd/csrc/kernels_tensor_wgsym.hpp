@@ -29,6 +29,9 @@
 
 namespace mimi_hip {
 
+#ifndef WGSYM_SPLIT_BELOW
+#define WGSYM_SPLIT_BELOW 512   // cut the columns into segments while the launch has at most this many workgroups
+#endif
 #ifndef WGSYM_MAX_COLS
 #define WGSYM_MAX_COLS 4      // element columns per workgroup at most
 #define WGSYM_MIN_WGS 2048    // ... while at least this many workgroups remain (4 per resident slot)
@@ -129,20 +132,22 @@ MH_DEV void wgsym_x_loop(const TensorArgs& p, double* lds, int col0, int n_cols,
   constexpr int TROUNDS = 2;
   const int lane = threadIdx.x & 63;
   double* ue = lds + L::off_ue;
-  // the workgroup walks n_cols element columns back to back: sequence index g = column-in-workgroup * nz + ez
-  const int nz = p.box_n[2];
-  const int n_seq = n_cols * nz;
+  // the workgroup walks n_cols units back to back, a unit = one segment of seg_len elements of an element column
+  // (unit index = column * segments-per-column + segment): sequence index g = unit-in-workgroup * seg_len + position
+  const int sl = p.seg_len, nseg = p.box_n[2] / sl;
+  const int n_seq = n_cols * sl;
+  auto ez_at = [&](int g) -> int { return ((col0 + g / sl) % nseg) * sl + g % sl; };
   auto element_at = [&](int g) -> int64_t {
-    const int col = col0 + g / nz;
-    return col % p.box_n[0] + (int64_t)p.box_n[0] * (col / p.box_n[0] + (int64_t)p.box_n[1] * (g % nz));
+    const int col = (col0 + g / sl) / nseg;
+    return col % p.box_n[0] + (int64_t)p.box_n[0] * (col / p.box_n[0] + (int64_t)p.box_n[1] * ez_at(g));
   };
   auto table_src = [&](int g, int t) -> const double* {
     const int dir = t / (2 * NB * NQ);
     const int rem = t % (2 * NB * NQ);
     const int isD = rem / (NB * NQ);
     const int k = rem % (NB * NQ);
-    const int col = col0 + g / nz;
-    const int span = (dir == 0 ? p.box_begin[0] + col % p.box_n[0] : dir == 1 ? p.box_begin[1] + col / p.box_n[0] : p.box_begin[2] + g % nz);
+    const int col = (col0 + g / sl) / nseg;
+    const int span = (dir == 0 ? p.box_begin[0] + col % p.box_n[0] : dir == 1 ? p.box_begin[1] + col / p.box_n[0] : p.box_begin[2] + ez_at(g));
     return (isD ? (dir == 0 ? p.tabD[0] : dir == 1 ? p.tabD[1] : p.tabD[2])
                 : (dir == 0 ? p.tabB[0] : dir == 1 ? p.tabB[1] : p.tabB[2])) + (int64_t)span * NB * NQ + k;
   };
@@ -262,14 +267,14 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols)
   constexpr int I1 = W == 0 ? 1 : 2, J1 = W == 2 ? 1 : 0;
   const WgsLane lc = wgs_lane_constants();
   const int lane = lc.lane;
-  const int nz = p.box_n[2];
-  const int n_seq = n_cols * nz;   // sequence index g = column-in-workgroup * nz + ez
+  const int sl = p.seg_len, nseg = p.box_n[2] / sl;
+  const int n_seq = n_cols * sl;   // sequence index g = unit-in-workgroup * seg_len + position (see wgsym_x_loop)
   const double* AH0 = lds + L::off_ah + L::ah_block(W, W) * NQ3;
   const double* AH1 = lds + L::off_ah + L::ah_block(I1, J1) * NQ3;
   auto st_of = [&](int piece) -> double* { return lds + L::off_st + piece * WgsLds::st_size; };
   auto piece_i = [&](int g, int i) -> double* {
-    const int col = col0 + g / nz;
-    const int64_t e = col % p.box_n[0] + (int64_t)p.box_n[0] * (col / p.box_n[0] + (int64_t)p.box_n[1] * (g % nz));
+    const int unit = col0 + g / sl, col = unit / nseg;
+    const int64_t e = col % p.box_n[0] + (int64_t)p.box_n[0] * (col / p.box_n[0] + (int64_t)p.box_n[1] * ((unit % nseg) * sl + g % sl));
     return p.scratch_k + (e * 3 + i) * (int64_t)NK;
   };
   auto piece_of = [&](int g) -> double* { return piece_i(g, W); };
@@ -333,8 +338,8 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols)
       wgs_barrier();
       wgs_contract_block<1>(lc, ah, aS0, aS2, uB1, uD1, C1, st_of(I1), J1, st_of(J1), I1);
       wgs_barrier();
-      if (it % nz == nz - 1) {
-        // last element of a column: the carried rows have no successor -- straight from the registers into the third
+      if (it % sl == sl - 1) {
+        // last element of a unit (column, or column segment): the carried rows have no successor -- straight from the registers into the third
         // part of the pieces (no LDS, no lock step) -- and the next column starts with an empty carry
         wgs_stage_carry<WGSYM_DIAG_MODE>(lc, C0, piece_i(it, W) + WgsLds::n_final, W, piece_i(it, W) + WgsLds::n_final, W);
         wgs_stage_carry<1>(lc, C1, piece_i(it, I1) + WgsLds::n_final, J1, piece_i(it, J1) + WgsLds::n_final, I1);
@@ -351,21 +356,21 @@ template<int KIND>
 __global__ __launch_bounds__(256, 2) void tensor_wgsym_kernel(TensorArgs p) {
   extern __shared__ __align__(16) double smem_wgsym[];
   const int role = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) + WGS_ROT(blockIdx.x)) & 3);
-  const int n_cols_all = p.box_n[0] * p.box_n[1];
+  const int n_cols_all = p.box_n[0] * p.box_n[1] * (p.box_n[2] / p.seg_len);   // units
   const int col0 = blockIdx.x * p.cols_per_wg;
   const int n_cols = n_cols_all - col0 < p.cols_per_wg ? n_cols_all - col0 : p.cols_per_wg;
   // (WGSYM_EXP_SKIP_X / _Y: timing experiments only — the skipped role just keeps the barrier count)
   if (role == 0) {
     int status = 0;
 #ifdef WGSYM_EXP_SKIP_X
-    for (int k = 0; k < 2 * n_cols * p.box_n[2] + 1; ++k) wgs_barrier();
+    for (int k = 0; k < 2 * n_cols * p.seg_len + 1; ++k) wgs_barrier();
 #else
     wgsym_x_loop<KIND>(p, smem_wgsym, col0, n_cols, status);
 #endif
     if (status) atomicOr(p.status, status);
   } else {
 #ifdef WGSYM_EXP_SKIP_Y
-    for (int k = 0; k < 2 * n_cols * p.box_n[2] + 1; ++k) wgs_barrier();
+    for (int k = 0; k < 2 * n_cols * p.seg_len + 1; ++k) wgs_barrier();
 #else
     if (role == 1) wgsym_y_loop<0>(p, smem_wgsym, col0, n_cols);
     else if (role == 2) wgsym_y_loop<1>(p, smem_wgsym, col0, n_cols);
@@ -387,7 +392,12 @@ inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a) {
   ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
   // several columns per workgroup (the pipeline of the four waves then runs through the column boundaries: one
   // prologue per workgroup instead of one per column) as long as the grid still fills the chip several times over
-  const int n_cols_all = a.box_n[0] * a.box_n[1];
+  // few columns (the boundary layers of a multi-GPU slab): each column is cut into segments with their own workgroup, so
+  // that the launch still fills the chip; a segment end stores its carried rows like a column end (phase 2 knows)
+  int nseg = 1;
+  while (a.box_n[0] * a.box_n[1] * nseg * 2 <= WGSYM_SPLIT_BELOW && a.box_n[2] % (nseg * 2) == 0 && a.box_n[2] / (nseg * 2) >= 4) nseg *= 2;
+  a.seg_len = a.box_n[2] / nseg;
+  const int n_cols_all = a.box_n[0] * a.box_n[1] * nseg;
   a.cols_per_wg = n_cols_all / WGSYM_MIN_WGS < 1 ? 1 : (n_cols_all / WGSYM_MIN_WGS > WGSYM_MAX_COLS ? WGSYM_MAX_COLS : n_cols_all / WGSYM_MIN_WGS);
   hipLaunchKernelGGL(kernel, dim3((n_cols_all + a.cols_per_wg - 1) / a.cols_per_wg), dim3(256), lds, h->stream, a);
   MH_HIP(hipGetLastError());
