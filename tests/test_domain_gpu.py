@@ -258,6 +258,21 @@ def test_medium_block_parity(matname):
     assert relmax(A_g, A_o) < 1e-11
 
 
+@pytest.mark.parametrize("n_el", [(3, 4, 16), (5, 3, 12), (2, 2, 24), (7, 1, 8)], ids=lambda n: "x".join(map(str, n)))
+def test_column_segments(n_el):
+    """Few, long element columns: the symmetric kernel cuts them into segments with their own workgroup (4 x 4, 2 x 6,
+    4 x 6, 2 x 4 elements here); the carried rows at every segment end, against the oracle; and a sub-box of the same."""
+    from oracle import ref_path as rp
+    P, D, G = make_pair(n_el, 2, None, "neohook", "bspline")
+    u = synthetic_u(P, scale=0.04)
+    r_o, A_o = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    r_g, A_g = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    D.add_domain_residual_and_grad(u, 1.0, r_o, A_o, rp.TANGENT_EXACT)
+    G.AddDomainResidualAndGrad(u, 1.0, r_g, A_g)
+    assert relmax(r_g, r_o) < 1e-12
+    assert relmax(A_g, A_o) < 1e-11
+
+
 def test_many_columns_per_workgroup():
     """65 x 65 columns of 2 elements: the symmetric kernel walks two columns per workgroup here (4225 columns, so the
     last workgroup has only one) -- the column boundary inside a workgroup (carry stored and reset), against the oracle."""
