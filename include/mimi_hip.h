@@ -239,6 +239,11 @@ int mimi_hip_contact_last_history(mimi_hip_contact_t h, double* out5);
 /* nodal average_pressure_ (mortar_contact.hpp:59), [n_marked]; returns n_marked via *n */
 int mimi_hip_contact_get_pressure(mimi_hip_contact_t h, double* out, int64_t capacity, int64_t* n);
 
+/* The rigid body moved (examples/nl_contact.py moves the curve's control points and calls plant_kd_tree again before
+ * every step) and / or the penalty changed (scene.coefficient = ...): spline != NULL re-uploads the boundary spline and its
+ * sampled initial guesses (same layout rules as at create time); penalty > 0 replaces coefficient_. */
+int mimi_hip_contact_update_body(mimi_hip_contact_t h, const mimi_hip_spline_body* spline, double penalty);
+
 /* Multi-GPU (one handle per rank over the faces of its element slab): the nodal area / gap of nodes shared between
  * slabs must be summed over the ranks before the pressure is formed (mortar_contact.cpp:195-261 runs over all marked
  * faces).  gap_area = pass 1 only; marked_nodes = the sorted global node ids behind the nodal arrays (out == NULL: count

@@ -71,7 +71,7 @@ EXPORTS = [
     "mimi_hip_contact_set_stream", "mimi_hip_contact_synchronize", "mimi_hip_contact_add_residual",
     "mimi_hip_contact_add_residual_and_grad", "mimi_hip_contact_gap_norm",
     "mimi_hip_contact_last_history", "mimi_hip_contact_get_pressure",
-    "mimi_hip_contact_gap_area", "mimi_hip_contact_marked_nodes", "mimi_hip_contact_nodal",
+    "mimi_hip_contact_update_body", "mimi_hip_contact_gap_area", "mimi_hip_contact_marked_nodes", "mimi_hip_contact_nodal",
     "mimi_hip_contact_add_residual_from_nodal",
     "mimi_hip_linear_create", "mimi_hip_linear_destroy", "mimi_hip_linear_set_stream", "mimi_hip_linear_eliminate",
     "mimi_hip_linear_gmres",
@@ -129,6 +129,7 @@ def lib():
     L.mimi_hip_contact_gap_norm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mimi_hip_contact_last_history.argtypes = [C.c_void_p, C.c_void_p]
     L.mimi_hip_contact_get_pressure.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.mimi_hip_contact_update_body.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
     L.mimi_hip_contact_gap_area.argtypes = [C.c_void_p, C.c_void_p]
     L.mimi_hip_contact_marked_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     L.mimi_hip_contact_nodal.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]

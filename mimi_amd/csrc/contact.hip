@@ -331,6 +331,71 @@ struct mimi_hip_contact_s {
   }
 };
 
+// NearestDistanceToSplines::AddSpline / PlantKdTree (nearest_distance.hpp:223-255): (re)upload the rigid spline and the
+// sampled initial guesses.  Called at create time and whenever the caller moved the body and re-planted its tree.
+static void upload_spline_body(mimi_hip_contact_s* h, const mimi_hip_spline_body* sp, int dim) {
+  // NearestDistanceToSplines::AddSpline / PlantKdTree (nearest_distance.hpp:223-255)
+  if (!sp) fail("body_kind spline without a spline description");
+  if (sp->para_dim + 1 != dim) fail("boundary para_dim should be one smaller than dim.");   // :121-124
+  SplineBodyDev host{};
+  host.para_dim = sp->para_dim;
+  host.dim = dim;
+  size_t n_ctrl = 1;
+  for (int k = 0; k < 2; ++k) {
+    host.p[k] = k < sp->para_dim ? sp->degree[k] : 0;
+    host.n_knots[k] = k < sp->para_dim ? sp->n_knots[k] : 2;
+    host.n_ctrl[k] = host.n_knots[k] - host.p[k] - 1;
+    if (host.p[k] < 0 || host.p[k] > kMaxBodyDegree) fail("spline body degree %d unsupported (<= %d)", host.p[k], kMaxBodyDegree);
+    if (host.n_ctrl[k] < host.p[k] + 1) fail("spline body knot vector too short");
+    n_ctrl *= host.n_ctrl[k];
+  }
+  const int hd = dim + 1;
+  std::vector<double> ctrl_h(n_ctrl * hd);
+  for (size_t a = 0; a < n_ctrl; ++a) {
+    const double w = sp->weights ? sp->weights[a] : 1.0;
+    if (!(w > 0.0)) fail("spline body weights must be positive");
+    for (int i = 0; i < dim; ++i) ctrl_h[a * hd + i] = w * sp->control_points[a * dim + i];
+    ctrl_h[a * hd + dim] = w;
+  }
+  static const double unit_knots[2] = {0.0, 1.0};
+  host.knots[0] = sp->knots[0];
+  host.knots[1] = sp->para_dim == 2 ? sp->knots[1] : unit_knots;
+  host.ctrl_h = ctrl_h.data();
+  int res = sp->kdtree_resolution > 1 ? sp->kdtree_resolution : 100;
+  if (sp->para_dim == 2 && res > 1000) res = 1000;   // res^2 samples: the reference's kd-tree takes what it is given
+  if (res > 1000000) res = 1000000;
+  const int n_s = sp->para_dim == 2 ? res * res : res;
+  std::vector<double> sxi((size_t)n_s * sp->para_dim), sx((size_t)n_s * dim);
+  for (int s_ = 0; s_ < n_s; ++s_) {
+    const int idx[2] = {s_ % res, s_ / res};
+    double xi[2] = {0, 0}, S[3], S1[6], S2[12];
+    for (int k = 0; k < sp->para_dim; ++k) {
+      const double lo = host.knots[k][host.p[k]], hi = host.knots[k][host.n_knots[k] - host.p[k] - 1];
+      xi[k] = lo + (hi - lo) * idx[k] / (res - 1);
+      sxi[(size_t)s_ * sp->para_dim + k] = xi[k];
+    }
+    sb_evaluate(host, xi, S, S1, S2);
+    for (int i = 0; i < dim; ++i) sx[(size_t)s_ * dim + i] = S[i];
+  }
+  h->spline = host;
+  for (int k = 0; k < sp->para_dim; ++k) {
+    h->sb_knots[k].assign(sp->knots[k], (size_t)sp->n_knots[k], h->stream);
+    h->spline.knots[k] = h->sb_knots[k].ptr;
+  }
+  if (sp->para_dim == 1) {
+    h->sb_knots[1].assign(unit_knots, 2, h->stream);
+    h->spline.knots[1] = h->sb_knots[1].ptr;
+  }
+  h->sb_ctrl.assign(ctrl_h.data(), ctrl_h.size(), h->stream);
+  h->sb_sample_xi.assign(sxi.data(), sxi.size(), h->stream);
+  h->sb_sample_x.assign(sx.data(), sx.size(), h->stream);
+  h->spline.ctrl_h = h->sb_ctrl.ptr;
+  h->spline.sample_xi = h->sb_sample_xi.ptr;
+  h->spline.sample_x = h->sb_sample_x.ptr;
+  h->spline.n_samples = n_s;
+  h->spline.max_iterations = sp->max_iterations;
+}
+
 template<typename F>
 static int guarded_c(F&& f) {
   try {
@@ -442,65 +507,7 @@ int mimi_hip_contact_create(const mimi_hip_contact_tables* t, int device, mimi_h
     for (int i = 0; i < 8; ++i) h->body[i] = t->body[i];
     h->penalty = t->penalty;
     if (t->body_kind == MIMI_HIP_BODY_SPLINE) {
-      // NearestDistanceToSplines::AddSpline / PlantKdTree (nearest_distance.hpp:223-255)
-      const mimi_hip_spline_body* sp = t->spline;
-      if (!sp) fail("body_kind spline without a spline description");
-      if (sp->para_dim + 1 != t->dim) fail("boundary para_dim should be one smaller than dim.");   // :121-124
-      SplineBodyDev host{};
-      host.para_dim = sp->para_dim;
-      host.dim = t->dim;
-      size_t n_ctrl = 1;
-      for (int k = 0; k < 2; ++k) {
-        host.p[k] = k < sp->para_dim ? sp->degree[k] : 0;
-        host.n_knots[k] = k < sp->para_dim ? sp->n_knots[k] : 2;
-        host.n_ctrl[k] = host.n_knots[k] - host.p[k] - 1;
-        if (host.p[k] < 0 || host.p[k] > kMaxBodyDegree) fail("spline body degree %d unsupported (<= %d)", host.p[k], kMaxBodyDegree);
-        if (host.n_ctrl[k] < host.p[k] + 1) fail("spline body knot vector too short");
-        n_ctrl *= host.n_ctrl[k];
-      }
-      const int hd = t->dim + 1;
-      std::vector<double> ctrl_h(n_ctrl * hd);
-      for (size_t a = 0; a < n_ctrl; ++a) {
-        const double w = sp->weights ? sp->weights[a] : 1.0;
-        if (!(w > 0.0)) fail("spline body weights must be positive");
-        for (int i = 0; i < t->dim; ++i) ctrl_h[a * hd + i] = w * sp->control_points[a * t->dim + i];
-        ctrl_h[a * hd + t->dim] = w;
-      }
-      static const double unit_knots[2] = {0.0, 1.0};
-      host.knots[0] = sp->knots[0];
-      host.knots[1] = sp->para_dim == 2 ? sp->knots[1] : unit_knots;
-      host.ctrl_h = ctrl_h.data();
-      const int res = sp->kdtree_resolution > 1 ? sp->kdtree_resolution : 100;
-      const int n_s = sp->para_dim == 2 ? res * res : res;
-      std::vector<double> sxi((size_t)n_s * sp->para_dim), sx((size_t)n_s * t->dim);
-      for (int s_ = 0; s_ < n_s; ++s_) {
-        const int idx[2] = {s_ % res, s_ / res};
-        double xi[2] = {0, 0}, S[3], S1[6], S2[12];
-        for (int k = 0; k < sp->para_dim; ++k) {
-          const double lo = host.knots[k][host.p[k]], hi = host.knots[k][host.n_knots[k] - host.p[k] - 1];
-          xi[k] = lo + (hi - lo) * idx[k] / (res - 1);
-          sxi[(size_t)s_ * sp->para_dim + k] = xi[k];
-        }
-        sb_evaluate(host, xi, S, S1, S2);
-        for (int i = 0; i < t->dim; ++i) sx[(size_t)s_ * t->dim + i] = S[i];
-      }
-      h->spline = host;
-      for (int k = 0; k < sp->para_dim; ++k) {
-        h->sb_knots[k].assign(sp->knots[k], (size_t)sp->n_knots[k], h->stream);
-        h->spline.knots[k] = h->sb_knots[k].ptr;
-      }
-      if (sp->para_dim == 1) {
-        h->sb_knots[1].assign(unit_knots, 2, h->stream);
-        h->spline.knots[1] = h->sb_knots[1].ptr;
-      }
-      h->sb_ctrl.assign(ctrl_h.data(), ctrl_h.size(), h->stream);
-      h->sb_sample_xi.assign(sxi.data(), sxi.size(), h->stream);
-      h->sb_sample_x.assign(sx.data(), sx.size(), h->stream);
-      h->spline.ctrl_h = h->sb_ctrl.ptr;
-      h->spline.sample_xi = h->sb_sample_xi.ptr;
-      h->spline.sample_x = h->sb_sample_x.ptr;
-      h->spline.n_samples = n_s;
-      h->spline.max_iterations = sp->max_iterations;
+      upload_spline_body(h.get(), t->spline, t->dim);
     } else if (t->body_kind != MIMI_HIP_BODY_SPHERE && t->body_kind != MIMI_HIP_BODY_PLANE) {
       fail("unknown rigid body kind %d", t->body_kind);
     }
@@ -636,6 +643,20 @@ int mimi_hip_contact_last_history(mimi_hip_contact_t h, double* out5) {
     MH_HIP(hipSetDevice(h->device));
     MH_HIP(hipMemcpyAsync(out5, h->scalars.ptr, 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     MH_HIP(hipStreamSynchronize(h->stream));
+  });
+}
+
+int mimi_hip_contact_update_body(mimi_hip_contact_t h, const mimi_hip_spline_body* spline, double penalty) {
+  return guarded_c([&] {
+    if (!h) fail("null handle");
+    MH_HIP(hipSetDevice(h->device));
+    MH_HIP(hipStreamSynchronize(h->stream));
+    if (spline) {
+      if (h->body_kind != MIMI_HIP_BODY_SPLINE) fail("this contact handle has no spline body");
+      upload_spline_body(h, spline, h->dim);
+      MH_HIP(hipStreamSynchronize(h->stream));
+    }
+    if (penalty > 0.0) h->penalty = penalty;
   });
 }
 

@@ -267,9 +267,21 @@ class NearestDistanceToSplines:
     kind = 2
 
     def __init__(self):
-        self.coefficient = 1.0e4        # nearest_distance.hpp:18
+        self._coefficient = 1.0e4       # nearest_distance.hpp:18
         self.tolerance = 1.0e-24        # nearest_distance.hpp:20 (the search here stops on the step size)
         self._splines, self._resolution = [], 100
+        self._attached = []             # MortarContact integrators built on this scene
+
+    @property
+    def coefficient(self):
+        return self._coefficient
+
+    @coefficient.setter
+    def coefficient(self, value):
+        """the reference reads coefficient_ at every evaluation: a change after setup reaches the device handles"""
+        self._coefficient = float(value)
+        for c in getattr(self, "_attached", []):
+            c.UpdateBody(penalty=self._coefficient)
 
     def add_spline(self, spline):
         self._splines.append(spline)
@@ -279,7 +291,11 @@ class NearestDistanceToSplines:
         self._splines.clear()
 
     def plant_kd_tree(self, resolution, nthreads=1):
+        """PlantKdTree (nearest_distance.hpp:243-255).  examples/nl_contact.py moves the spline's control points and
+        calls this before every step: the attached device handles get the moved body."""
         self._resolution = int(resolution)
+        for c in self._attached:
+            c.UpdateBody(spline=True)
 
     def size(self):
         return len(self._splines)
@@ -341,6 +357,8 @@ class MortarContact(NonlinearBase):
             self._spline_struct = body.c_struct()
             self._keep.append(body)
             t.spline = C.cast(C.pointer(self._spline_struct), C.c_void_p)
+            if hasattr(body, "_attached"):
+                body._attached.append(self)
         t.csr_rowptr = ptr(self.pattern_.rowptr).value
         t.csr_col = ptr(self.pattern_.col).value
         h = C.c_void_p()
@@ -356,6 +374,14 @@ class MortarContact(NonlinearBase):
 
     def Synchronize(self):
         check(_capi.lib().mimi_hip_contact_synchronize(self._handle()))
+
+    def UpdateBody(self, spline=False, penalty=-1.0):
+        """the rigid body moved (spline=True: re-read it from nearest_distance_coeff_) and / or the penalty changed"""
+        sp = None
+        if spline:
+            self._spline_struct = self.nearest_distance_coeff_.c_struct()
+            sp = C.cast(C.pointer(self._spline_struct), C.c_void_p)
+        check(_capi.lib().mimi_hip_contact_update_body(self._handle(), sp, float(penalty)))
 
     # -- the two halves of an evaluation, for element slabs on several GPUs (mimi_amd/parallel.py ShardedContact) -----
     def GapArea(self, current_u):

@@ -242,3 +242,17 @@ def test_contact_with_rigid_spline_through_the_facade():
     c = nl.contacts_[0]
     c.BoundaryPostTimeAdvance(nl.x)
     assert c.last_force_[1] != 0.0
+    # the body moves between steps and the penalty changes, as in examples/nl_contact.py: lifted clear of the beam the
+    # contact force vanishes; back down with a stiffer penalty it returns
+    f0 = abs(c.last_force_[1])
+    circle.control_points[:, 1] += 5.0
+    nd.plant_kd_tree(200, 1)
+    r = np.zeros_like(nl.x)
+    c.AddBoundaryResidual(nl.x, r)
+    assert np.all(r == 0.0)
+    circle.control_points[:, 1] -= 5.0
+    nd.plant_kd_tree(200, 1)
+    nd.coefficient = 4e4
+    c.AddBoundaryResidual(nl.x, r)
+    c.BoundaryPostTimeAdvance(nl.x)
+    assert abs(c.last_force_[1]) > 2.0 * f0
