@@ -17,7 +17,8 @@ The linear solves (UMFPack / CG in the reference) use scipy's sparse LU.  The el
 integration itself always goes through libmimi_hip (no CPU fallback).
 
 Differences a user must know: dofs are numbered lexicographically (the reference exposes MFEM's
-NURBS numbering); meshes must be single-patch boxes with unit weights (affine geometry), which
+NURBS numbering); meshes must be single-cell degree-1 descriptions with unit weights (any quadrilateral / hexahedron:
+the refined control net is the cell's multilinear map at the Greville abscissae), which
 covers every mesh the reference's solver tests use.
 """
 import re
@@ -118,20 +119,25 @@ def _read_mfem_nurbs_box(fname):
     coords = np.array([float(x) for x in tok[i:i + nvert * dim]]).reshape(nvert, dim)
     if any(p != 1 for p, _ in knots) or nvert != 2 ** dim:
         raise RuntimeError("this reader expects the degree-1 single-element description the reference's solver tests use")
+    # element vertices in MFEM's order (quadrilateral counter-clockwise; hexahedron bottom face counter-clockwise, then
+    # top) -> reference coordinates of each vertex
+    i = section("elements") + 1
+    ev = [int(v) for v in tok[i + 2:i + 2 + 2 ** dim]]
+    ref2 = [(0, 0), (1, 0), (1, 1), (0, 1)]
+    ref = ref2 if dim == 2 else [r + (0,) for r in ref2] + [r + (1,) for r in ref2]
+    ref_of = {v: np.array(rc) for v, rc in zip(ev, ref)}
+    corners = np.zeros((2,) * dim + (dim,))                 # corners[k, j, i] (first direction fastest = last index)
+    for v, rc in ref_of.items():
+        corners[tuple(rc[::-1])] = coords[v]
     lo, hi = coords.min(axis=0), coords.max(axis=0)
-    corners = np.array(np.meshgrid(*[[lo[d], hi[d]] for d in range(dim)], indexing="ij")).reshape(dim, -1).T
-    if not all(np.any(np.all(np.isclose(c, coords), axis=1)) for c in corners):
-        raise RuntimeError("only axis-aligned box geometries are supported")
-    # boundary attribute -> (axis, side) from the vertices of the boundary element
+    # boundary attribute -> (axis, side): the reference coordinate all vertices of the boundary element share
     faces = {}
     for attr, verts in bdr:
-        x = coords[verts]
+        rc = np.array([ref_of[v] for v in verts])
         for d in range(dim):
-            if np.allclose(x[:, d], lo[d]):
-                faces[attr] = (d, 0)
-            elif np.allclose(x[:, d], hi[d]):
-                faces[attr] = (d, 1)
-    return dim, lo, hi, faces
+            if np.all(rc[:, d] == rc[0, d]):
+                faces[attr] = (d, int(rc[0, d]))
+    return dim, lo, hi, faces, corners
 
 
 def _open_knots(n_el, p):
@@ -149,7 +155,7 @@ class Solid:
         self.current_time = 0.0
 
     def read_mesh(self, fname):
-        self._dim, self._lo, self._hi, self._faces = _read_mfem_nurbs_box(fname)
+        self._dim, self._lo, self._hi, self._faces, self._corners = _read_mfem_nurbs_box(fname)
         self._degrees = [1] * self._dim
         self._n_el = [1] * self._dim
 
@@ -177,17 +183,26 @@ class Solid:
 
     def patch(self):
         knots = [_open_knots(m, p) for m, p in zip(self._n_el, self._degrees)]
+        # degree elevation / knot insertion of the (multi)linear cell: control points = the cell's map at the Greville
+        # abscissae (a degree-p tensor-product spline reproduces multilinear functions from those exactly)
         grev = []
         for d, (k, p) in enumerate(zip(knots, self._degrees)):
             n = len(k) - p - 1
-            g = np.array([k[i + 1:i + p + 1].sum() / p for i in range(n)])
-            grev.append(self._lo[d] + (self._hi[d] - self._lo[d]) * g)
+            grev.append(np.array([k[i + 1:i + p + 1].sum() / p for i in range(n)]))
         dim = self._dim
-        pts = np.zeros([len(g) for g in grev][::-1] + [dim])
+        shape = [len(g) for g in grev][::-1]
+        pts = np.zeros(shape + [dim])
+        t = []
         for d in range(dim):
-            shape = [1] * dim
-            shape[dim - 1 - d] = -1
-            pts[..., d] = grev[d].reshape(shape)
+            sh = [1] * dim
+            sh[dim - 1 - d] = -1
+            t.append(grev[d].reshape(sh))
+        for idx in np.ndindex(*(2,) * dim):                 # idx = (k, j, i) with the first direction last
+            wgt = np.ones(shape)
+            for d in range(dim):
+                c = idx[dim - 1 - d]
+                wgt = wgt * (t[d] if c == 1 else 1.0 - t[d])
+            pts += wgt[..., None] * self._corners[idx]
         return BSplinePatch(self._degrees, knots, pts.reshape(-1, dim))
 
 
@@ -214,13 +229,6 @@ def _element_tables(patch, quadrature_order=-1):
         w = np.einsum("z,y,x->zyx", tabs[2][3], tabs[1][3], tabs[0][3]).ravel()
     ne = len(em[0])
     N = N.reshape(ne, w.size, -1)
-    # affine box: det = prod(span length * physical length)
-    det = np.ones(ne)
-    ext = patch.control_points.max(axis=0) - patch.control_points.min(axis=0)
-    for d in range(dim):
-        k, p = patch.knots[d], patch.degrees[d]
-        spans = tabs[d][0]
-        det *= (k[spans + 1] - k[spans])[em[d]] * ext[d]
     # connectivity
     conn = np.zeros((ne, N.shape[2]), dtype=np.int64)
     a = np.arange(N.shape[2])
@@ -229,7 +237,23 @@ def _element_tables(patch, quadrature_order=-1):
         ad = (a // int(np.prod([pp + 1 for pp in patch.degrees[:d]]))) % (patch.degrees[d] + 1)
         conn += ((tabs[d][0][em[d]] - patch.degrees[d])[:, None] + ad[None, :]) * stride
         stride *= patch.n_ctrl[d]
-    return N, w[None, :] * det[:, None], conn
+    # geometry Jacobian per point from the control net (derivatives wrt the element's reference coordinates)
+    B = [t[1] for t in tabs]
+    D = [t[2] for t in tabs]
+    dN = []
+    for k in range(dim):
+        f = [D[d] if d == k else B[d] for d in range(dim)]
+        if dim == 2:
+            g = np.einsum("eax,eby->eyxba", f[0][em[0]], f[1][em[1]])
+        else:
+            g = np.einsum("eax,eby,ecz->ezyxcba", f[0][em[0]], f[1][em[1]], f[2][em[2]])
+        dN.append(g.reshape(ne, w.size, -1))
+    X = patch.control_points[conn]                                      # [e, a, i]
+    J = np.stack([np.einsum("eai,eqa->eqi", X, g) for g in dN], axis=-1)   # [e, q, i, k]
+    det = np.linalg.det(J)
+    if not np.all(det > 0):
+        raise RuntimeError("geometry map has a non-positive Jacobian determinant")
+    return N, w[None, :] * det, conn
 
 
 class NonlinearSolid(Solid):
