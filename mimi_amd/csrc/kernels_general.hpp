@@ -442,6 +442,7 @@ __global__ __launch_bounds__(64 * GG_WAVES) void general_gather_kernel(int64_t n
   double* img = img_all[wave];
   const int64_t node = row / DIM;
   const int i = (int)(row % DIM);
+  if (adj_ptr[node] == adj_ptr[node + 1]) return;   // no element of this handle touches the node (element slabs)
   const int64_t beg = rowptr[row];
   const int len = (int)(rowptr[row + 1] - beg);
   for (int k = lane; k < len; k += 64) img[k] = 0.0;

@@ -199,6 +199,30 @@ def test_element_boxes_add_up_to_the_whole(axis, matname):
     assert relmax(A_g, A_o) < 1e-11
 
 
+def test_element_boxes_p3_general_path():
+    """element boxes on the general path with 64-node elements (store + gather assembly: nodes no element of a box
+    touches are skipped by the gather kernel); the boxes add up to the oracle's whole-patch assembly"""
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    from oracle import iga, ref_path as rp
+    n_el = (3, 5, 2)
+    P = iga.Patch.block(n_el, 3)
+    D = rp.DomainOracle(P, oracle_material("neohook"), n_threads=2)
+    pattern = CSRPattern(D.rowptr.astype(np.int64), D.col.astype(np.int32), D.nnz)
+    patch = mimi_amd.BSplinePatch.block(n_el, 3)
+    u = synthetic_u(P, scale=0.04)
+    r_o, A_o = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    D.add_domain_residual_and_grad(u, 1.0, r_o, A_o, rp.TANGENT_EXACT)
+    r_g, A_g = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    for b, e in ((0, 1), (1, 5)):
+        G = NonlinearSolid("domain", product_material("neohook"), pattern, patch=patch,
+                           element_box=([0, b, 0], [3, e, 2])).Prepare()
+        assert G.path_ == 0
+        G.AddDomainResidualAndGrad(u, 1.0, r_g, A_g)
+    assert relmax(r_g, r_o) < 1e-12
+    assert relmax(A_g, A_o) < 1e-11
+
+
 @pytest.mark.parametrize("matname", ["neohook", "j2"])
 def test_permuted_node_numbering(matname):
     """node_ids = lexicographic -> caller's node id (what MFEM's NURBS dof map is for the reference): u, r and
