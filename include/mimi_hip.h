@@ -274,6 +274,12 @@ int mimi_hip_linear_eliminate(mimi_hip_linear_t h, double* r, double* A_values);
 int mimi_hip_linear_gmres(mimi_hip_linear_t h, const double* A_values, const double* b, double* x, double rel_tol,
                           double abs_tol, int max_iter, int kdim, int use_jacobi, int32_t* iterations,
                           double* final_norm, int32_t* converged);
+/* The mass solve of operators::NonlinearSolid (operators/nonlinear_solid.cpp:39-50,155; .hpp:38-42: mfem::CGSolver +
+ * mfem::DSmoother, rel 1e-8, abs 1e-12, 1000 iterations): x = 0 start, preconditioned conjugate gradients, stops when
+ * (r, M r) <= max(rel_tol^2 (r0, M r0), abs_tol^2); final_norm = sqrt of that product. */
+int mimi_hip_linear_cg(mimi_hip_linear_t h, const double* A_values, const double* b, double* x, double rel_tol,
+                       double abs_tol, int max_iter, int use_jacobi, int32_t* iterations, double* final_norm,
+                       int32_t* converged);
 
 #ifdef __cplusplus
 }

@@ -74,7 +74,7 @@ EXPORTS = [
     "mimi_hip_contact_update_body", "mimi_hip_contact_gap_area", "mimi_hip_contact_marked_nodes", "mimi_hip_contact_nodal",
     "mimi_hip_contact_add_residual_from_nodal",
     "mimi_hip_linear_create", "mimi_hip_linear_destroy", "mimi_hip_linear_set_stream", "mimi_hip_linear_eliminate",
-    "mimi_hip_linear_gmres",
+    "mimi_hip_linear_gmres", "mimi_hip_linear_cg",
 ]
 
 
@@ -140,6 +140,8 @@ def lib():
     L.mimi_hip_linear_eliminate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mimi_hip_linear_gmres.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mimi_hip_linear_cg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 

@@ -152,6 +152,34 @@ __global__ __launch_bounds__(KR_THREADS) void kr_update_kernel(int64_t n, int k_
   }
 }
 
+// conjugate gradients: z = dinv o r (or r), partial_out = partial sums of r . z
+__global__ __launch_bounds__(KR_THREADS) void kr_cg_precond_kernel(int64_t n, const double* __restrict__ r, const double* __restrict__ dinv,
+                                                                   double* __restrict__ z, double* __restrict__ partial_out) {
+  __shared__ double sh[KR_THREADS / 64];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * KR_THREADS + threadIdx.x; i < n; i += (int64_t)KR_BLOCKS * KR_THREADS) {
+    const double ri = r[i], zi = dinv ? dinv[i] * ri : ri;
+    z[i] = zi;
+    acc += ri * zi;
+  }
+  const double t = kr_block_sum(acc, sh);
+  if (threadIdx.x == 0) partial_out[blockIdx.x] = t;
+}
+
+// x += alpha d; r -= alpha q
+__global__ __launch_bounds__(KR_THREADS) void kr_cg_update_kernel(int64_t n, double alpha, const double* __restrict__ d,
+                                                                  const double* __restrict__ q, double* __restrict__ x, double* __restrict__ r) {
+  for (int64_t i = (int64_t)blockIdx.x * KR_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * KR_THREADS) {
+    x[i] += alpha * d[i];
+    r[i] -= alpha * q[i];
+  }
+}
+
+// d = z + beta d
+__global__ __launch_bounds__(KR_THREADS) void kr_cg_direction_kernel(int64_t n, double beta, const double* __restrict__ z, double* __restrict__ d) {
+  for (int64_t i = (int64_t)blockIdx.x * KR_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * KR_THREADS) d[i] = z[i] + beta * d[i];
+}
+
 // forms/nonlinear.hpp:76-80: r[ess] = 0
 __global__ void kr_zero_entries_kernel(int64_t n_ess, const int64_t* __restrict__ ess, double* __restrict__ r) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -462,6 +490,98 @@ int mimi_hip_linear_gmres(mimi_hip_linear_t h, const double* A_values, const dou
       }
     }
     finish(max_iter, beta, false);
+  });
+}
+
+/* mfem::CGSolver + mfem::DSmoother as operators::NonlinearSolid configures its mass solve (operators/nonlinear_solid.cpp:
+ * 39-50, .hpp:38-42: rel 1e-8, abs 1e-12, 1000 iterations, iterative_mode false): preconditioned conjugate gradients,
+ * stops when (r, M r) <= max(rel_tol^2 (r0, M r0), abs_tol^2)  (mfem linalg/solvers.cpp, CGSolver::Mult) */
+int mimi_hip_linear_cg(mimi_hip_linear_t h, const double* A_values, const double* b, double* x, double rel_tol, double abs_tol,
+                       int max_iter, int use_jacobi, int32_t* iterations, double* final_norm, int32_t* converged) {
+  return guarded_k([&] {
+    if (!h || !A_values || !b || !x) fail("null argument");
+    MH_HIP(hipSetDevice(h->device));
+    const int64_t n = h->n;
+    hipStream_t s = h->stream;
+    Mirror<double> mA = Mirror<double>::in(A_values, (size_t)h->nnz, h->stage_val, s);
+    Mirror<double> mb = Mirror<double>::in(b, (size_t)n, h->stage_b, s);
+    Mirror<double> mx = Mirror<double>::inout(x, (size_t)n, h->stage_x, s);
+    h->V.resize((size_t)3 * n);            // d, z, q
+    h->r.resize((size_t)n);
+    h->partials.resize((size_t)2 * KR_BLOCKS);
+    h->totals.resize(2);
+    const double* dinv = nullptr;
+    if (use_jacobi) {
+      h->dinv.resize((size_t)n);
+      hipLaunchKernelGGL(kr_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, h->rowptr, h->diag_pos.ptr, mA.dev,
+                         h->dinv.ptr);
+      dinv = h->dinv.ptr;
+    }
+    double* d = h->V.ptr;
+    double* z = d + n;
+    double* q = z + n;
+    double* r = h->r.ptr;
+    double* part = h->partials.ptr;
+    auto total_of = [&]() -> double {
+      hipLaunchKernelGGL(kr_totals_kernel, dim3(1), dim3(KR_THREADS), 0, s, part, h->totals.ptr);
+      MH_HIP(hipGetLastError());
+      double t = 0.0;
+      MH_HIP(hipMemcpyAsync(&t, h->totals.ptr, sizeof(double), hipMemcpyDeviceToHost, s));
+      MH_HIP(hipStreamSynchronize(s));
+      return t;
+    };
+    auto finish = [&](int it, double nom, bool conv) {
+      if (iterations) *iterations = it;
+      if (final_norm) *final_norm = std::sqrt(std::fabs(nom));
+      if (converged) *converged = conv ? 1 : 0;
+      mx.finish(s);
+      MH_HIP(hipStreamSynchronize(s));
+    };
+    // x = 0, r = b, z = M r, d = z
+    MH_HIP(hipMemsetAsync(mx.dev, 0, sizeof(double) * n, s));
+    MH_HIP(hipMemcpyAsync(r, mb.dev, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(kr_cg_precond_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, r, dinv, z, part);
+    MH_HIP(hipMemcpyAsync(d, z, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    double nom = total_of();
+    const double r0 = std::fmax(nom * rel_tol * rel_tol, abs_tol * abs_tol);
+    if (nom <= r0) {
+      finish(0, nom, true);
+      return;
+    }
+    spmv(h, mA.dev, d, nullptr, nullptr, q);
+    hipLaunchKernelGGL(kr_mgs_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, q, (const double*)nullptr, (const double*)nullptr,
+                       (const double*)d, part);
+    double den = total_of();
+    if (!(den > 0.0)) {   // not positive definite: mfem warns and stops
+      finish(0, nom, false);
+      return;
+    }
+    int it = 1;
+    for (;; ++it) {
+      const double alpha = nom / den;
+      hipLaunchKernelGGL(kr_cg_update_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, alpha, d, q, mx.dev, r);
+      hipLaunchKernelGGL(kr_cg_precond_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, r, dinv, z, part);
+      const double betanom = total_of();
+      if (betanom <= r0) {
+        finish(it, betanom, true);
+        return;
+      }
+      if (it >= max_iter) {
+        finish(it, betanom, false);
+        return;
+      }
+      const double beta = betanom / nom;
+      hipLaunchKernelGGL(kr_cg_direction_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, beta, z, d);
+      spmv(h, mA.dev, d, nullptr, nullptr, q);
+      hipLaunchKernelGGL(kr_mgs_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, q, (const double*)nullptr, (const double*)nullptr,
+                         (const double*)d, part);
+      den = total_of();
+      if (!(den > 0.0)) {
+        finish(it, betanom, false);
+        return;
+      }
+      nom = betanom;
+    }
   });
 }
 

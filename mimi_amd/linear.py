@@ -47,6 +47,15 @@ class LinearSolver:
         self.final_iter_, self.final_norm_, self.converged_ = it.value, nrm.value, bool(conv.value)
         return x
 
+    def MultCG(self, A_values, b, x, rel_tol=1e-8, abs_tol=1e-12, max_iter=1000):
+        """x = A^-1 b by preconditioned conjugate gradients: the mass solve of operators::NonlinearSolid
+        (operators/nonlinear_solid.cpp:39-50,155)"""
+        it, conv, nrm = C.c_int32(0), C.c_int32(0), C.c_double(0.0)
+        check(_capi.lib().mimi_hip_linear_cg(self._h, ptr(A_values), ptr(b), ptr(x), rel_tol, abs_tol, int(max_iter),
+                                             1 if self.use_jacobi else 0, C.byref(it), C.byref(nrm), C.byref(conv)))
+        self.final_iter_, self.final_norm_, self.converged_ = it.value, nrm.value, bool(conv.value)
+        return x
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

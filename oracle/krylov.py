@@ -66,3 +66,41 @@ def gmres(A, b, rel_tol=1e-8, abs_tol=1e-12, max_iter=300, kdim=50, jacobi=True)
         if beta <= goal:
             return x, j - 1, beta, True
     return x, max_iter, beta, False
+
+
+def cg(A, b, rel_tol=1e-8, abs_tol=1e-12, max_iter=1000, jacobi=True):
+    """mfem::CGSolver::Mult with a DSmoother preconditioner, iterative_mode false (the mass solve of
+    operators::NonlinearSolid, operators/nonlinear_solid.cpp:39-50,155).  (x, iterations, sqrt((r, M r)), converged)"""
+    n = len(b)
+    dinv = 1.0 / A.diagonal() if jacobi else np.ones(n)
+    x = np.zeros(n)
+    r = b.copy()
+    z = dinv * r
+    d = z.copy()
+    nom = r @ z
+    r0 = max(nom * rel_tol * rel_tol, abs_tol * abs_tol)
+    if nom <= r0:
+        return x, 0, np.sqrt(abs(nom)), True
+    q = A @ d
+    den = q @ d
+    if not den > 0:
+        return x, 0, np.sqrt(abs(nom)), False
+    it = 1
+    while True:
+        alpha = nom / den
+        x += alpha * d
+        r -= alpha * q
+        z = dinv * r
+        betanom = r @ z
+        if betanom <= r0:
+            return x, it, np.sqrt(abs(betanom)), True
+        if it >= max_iter:
+            return x, it, np.sqrt(abs(betanom)), False
+        beta = betanom / nom
+        d = z + beta * d
+        q = A @ d
+        den = d @ q
+        if not den > 0:
+            return x, it, np.sqrt(abs(betanom)), False
+        nom = betanom
+        it += 1

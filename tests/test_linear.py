@@ -103,3 +103,44 @@ def test_hip_gmres_is_reproducible():
     S.Eliminate(r, J)
     xs = [S.Mult(J, r, np.empty_like(r)).copy() for _ in range(3)]
     assert np.array_equal(xs[0], xs[1]) and np.array_equal(xs[0], xs[2])
+
+
+def mass_system():
+    from oracle import iga, ref_path as rp, harness as hz
+    P = iga.Patch.block((4, 3, 2), 2)
+    D = rp.DomainOracle(P, oracle_material("neohook"), n_threads=2)
+    mass = hz.assemble_mass(P, D.tables, 1.0, D.rowptr, D.col)
+    nodes = P.boundary_nodes(0, 0)
+    ess = np.sort(np.concatenate([nodes * 3 + c for c in range(3)])).astype(np.int64)
+    b = np.random.default_rng(3).standard_normal(P.n_vdofs)
+    Mv, bv = eliminate_host(D.rowptr, D.col, mass, b, ess)
+    return P, D, Mv, bv, ess
+
+
+def test_restated_cg_against_direct_solve():
+    from oracle import krylov
+    P, D, Mv, bv, ess = mass_system()
+    A = sp.csr_matrix((Mv, D.col, D.rowptr), shape=(P.n_vdofs, P.n_vdofs))
+    x_ref = spla.splu(A.tocsc()).solve(bv)
+    x, it, nrm, conv = krylov.cg(A, bv)
+    assert conv and 1 < it < 1000
+    assert np.abs(x - x_ref).max() <= 1e-6 * np.abs(x_ref).max()
+
+
+@pytest.mark.gpu
+def test_hip_cg_against_restatement():
+    """the mass solve of operators::NonlinearSolid (CG + Jacobi) on the device against the restatement"""
+    from mimi_amd.integrators import CSRPattern
+    from mimi_amd.linear import LinearSolver
+    from oracle import krylov
+    P, D, Mv, bv, ess = mass_system()
+    A = sp.csr_matrix((Mv, D.col, D.rowptr), shape=(P.n_vdofs, P.n_vdofs))
+    x_o, it_o, nrm_o, conv_o = krylov.cg(A, bv)
+    S = LinearSolver(CSRPattern(D.rowptr.astype(np.int64), D.col.astype(np.int32), D.nnz), ess)
+    x = S.MultCG(Mv, bv, np.empty_like(bv))
+    # (conjugate gradients lose orthogonality in floating point: the two summation orders differ by a few iterations)
+    assert S.converged_ and conv_o and abs(S.final_iter_ - it_o) <= max(3, it_o // 20)
+    assert np.abs(x - x_o).max() <= 1e-7 * np.abs(x_o).max()     # both stop at rel 1e-8, a few iterations apart
+    assert np.linalg.norm(A @ x - bv) <= 1e-6 * np.linalg.norm(bv)
+    x2 = S.MultCG(Mv, bv, np.empty_like(bv))
+    assert np.array_equal(x, x2)              # deterministic reductions
