@@ -153,3 +153,49 @@ def test_j2_fullsize_properties():
     G.AddDomainResidualAndGrad(u, 1.0, r2, A2)
     G.Synchronize()
     assert torch.equal(r2, r) and torch.equal(A2, A)
+
+
+@pytest.mark.parametrize("material", ["stvk", "j2simo", "j2log"])
+def test_other_materials_fullsize_properties(material):
+    """The tangent-record route (material pre-pass with dual-number tangents + nine-block phase 1 + phase 2) at cfg2 size
+    (64 x 64 x 8): force balance, rigid translations in the null space of the tangent, linearity in grad_factor, bitwise
+    reproducibility; StVenantKirchhoff (hyperelastic): major symmetry of the assembled matrix."""
+    import torch
+    import bench
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    dev = torch.device("cuda", 0)
+    patch = mimi_amd.BSplinePatch.block((64, 64, 8), 2)
+    pattern = CSRPattern.of_bspline_patch(patch, on_device=True)
+    G = NonlinearSolid("domain", bench.make_material(material), pattern, patch=patch).Prepare()
+    assert G.path_ == 1
+    G.dt_ = 0.5
+    u = torch.from_numpy(bench.synthetic_u(patch)).to(dev)
+    r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
+    A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
+    G.AddDomainResidualAndGrad(u, 1.0, r, A)
+    G.Synchronize()
+    rv = r.view(-1, 3)
+    assert float(rv.abs().max()) > 0
+    assert float(rv.sum(0).abs().max()) < 1e-11 * float(rv.abs().sum(0).max())
+    s = dict(torch=torch, dev=dev, pattern=pattern)
+    Aabs = float(A.abs().max())
+    for j in range(3):
+        t = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
+        t[j::3] = 1.0
+        assert float(csr_matvec(s, A, t).abs().max()) < 1e-10 * Aabs * 375
+    r2, A2 = torch.zeros_like(r), torch.zeros_like(A)
+    G.AddDomainResidualAndGrad(u, 2.0, r2, A2)
+    G.Synchronize()
+    assert torch.equal(r2, r)
+    assert float((A2 - 2.0 * A).abs().max()) <= 1e-15 * Aabs
+    r3, A3 = torch.zeros_like(r), torch.zeros_like(A)
+    G.AddDomainResidualAndGrad(u, 1.0, r3, A3)
+    G.Synchronize()
+    assert torch.equal(r3, r) and torch.equal(A3, A)
+    if material == "stvk":
+        x = torch.from_numpy(np.random.default_rng(1).standard_normal(patch.n_vdofs)).to(dev)
+        y = torch.from_numpy(np.random.default_rng(2).standard_normal(patch.n_vdofs)).to(dev)
+        a = float(torch.dot(y, csr_matvec(s, A, x)))
+        b = float(torch.dot(x, csr_matvec(s, A, y)))
+        assert abs(a - b) < 1e-10 * (abs(a) + abs(b) + Aabs)
