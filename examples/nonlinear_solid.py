@@ -1,50 +1,55 @@
-"""The reference's examples/nonlinear_solid.py on the HIP integrators (headless: the reference shows the deforming spline
-with splinepy / gustaf, which are not part of this repository).
+"""Cantilever under its own weight: the scenario of the reference's examples/nonlinear_solid.py, driven through
+mimi_amd (HIP integrators) and printed instead of plotted.
 
-    python examples/nonlinear_solid.py [--steps 20]
+    python examples/nonlinear_solid.py [--steps 20] [--dt 0.05]
 """
 import argparse
 import os
 import sys
 
-import numpy as np
-
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
 import mimi_amd as mimi  # noqa: E402
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=20)
-args = ap.parse_args()
 
-HERE = os.path.dirname(os.path.abspath(__file__))
+def build_beam(mesh_file):
+    """5 x 1 beam, clamped at x = 0, neo-Hookean, gravity-like body force"""
+    solid = mimi.NonlinearSolid()
+    solid.read_mesh(mesh_file)
+    solid.elevate_degrees(1)          # p = 2
+    solid.subdivide(2)                # 4 x 4 elements
 
-# create nl solid
-nl = mimi.NonlinearSolid()
-nl.read_mesh(os.path.join(HERE, "..", "tests", "golden", "meshes", "balken.mesh"))
-# refine
-nl.elevate_degrees(1)
-nl.subdivide(2)
+    rubber = mimi.CompressibleOgdenNeoHookean()
+    rubber.density, rubber.viscosity = 1, -1
+    rubber.set_young_poisson(2100, 0.3)
+    solid.set_material(rubber)
 
-# create material
-mat = mimi.CompressibleOgdenNeoHookean()
-mat.density = 1
-mat.viscosity = -1
-# define material properties (young's modulus, poisson's ratio)
-mat.set_young_poisson(2100, 0.3)
-nl.set_material(mat)
+    conditions = mimi.BoundaryConditions()
+    clamp = conditions.initial
+    clamp.dirichlet(2, 0)
+    clamp.dirichlet(2, 1)
+    conditions.initial.body_force(1, -5)
+    solid.boundary_condition = conditions
 
-bc = mimi.BoundaryConditions()
-bc.initial.dirichlet(2, 0).dirichlet(2, 1)
-bc.initial.body_force(1, -5)
-nl.boundary_condition = bc
+    solid.setup(2)
+    solid.configure_newton("nonlinear_solid", 1e-12, 1e-8, 10, False)
+    return solid
 
-nl.setup(2)
-nl.configure_newton("nonlinear_solid", 1e-12, 1e-8, 10, False)
-nl.time_step_size = 0.05
 
-u = nl.solution_view("displacement", "x").reshape(-1, nl.mesh_dim())
-for i in range(args.steps):
-    nl.step_time2()
-    h = nl.newton_history[-1]
-    print(f"step {i:3d}  t = {nl.current_time:.3f}  Newton iterations {h['iterations']:2d}  |r| = {h['norm']:.2e}  "
-          f"tip deflection {u[:, 1].min():+.5f}")
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--dt", type=float, default=0.05)
+    args = ap.parse_args()
+    beam = build_beam(os.path.join(REPO, "tests", "golden", "meshes", "balken.mesh"))
+    beam.time_step_size = args.dt
+    displacement = beam.solution_view("displacement", "x").reshape(-1, beam.mesh_dim())
+    for k in range(args.steps):
+        beam.step_time2()
+        info = beam.newton_history[-1]
+        print(f"step {k:3d}  t = {beam.current_time:.3f}  Newton iterations {info['iterations']:2d}  |r| = {info['norm']:.2e}  "
+              f"tip deflection {displacement[:, 1].min():+.5f}")
+
+
+if __name__ == "__main__":
+    main()
