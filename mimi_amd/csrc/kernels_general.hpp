@@ -103,6 +103,9 @@ MH_DEV void compute_F_general(int n_dof, const double* __restrict__ g /* [DIM][n
 //     point K[(a), (b, i, j)] += sum_J g[J][a] * (sum_L A_q[iJ, jL] g[L][b]) is a 64 x 576 x 3 product; wave w owns the
 //     16 column nodes b of tile w & 3 and two of the four 16-row tiles, 18 accumulator tiles (2 x 9 (i, j)) in registers
 typedef double mhg_d4 __attribute__((ext_vector_type(4)));
+#ifndef GEN_MF_QC
+#define GEN_MF_QC 8   // quadrature points staged per barrier pair of the matrix-instruction node-pair phase
+#endif
 #define GEN_SYNC() do { if constexpr (WPE) __builtin_amdgcn_wave_barrier(); else __syncthreads(); } while (0)
 // WPE: 1 = one WAVE per element (small elements: 2-D, p = 1): THREADS / 64 elements per workgroup, every barrier a wave
 //      barrier, the LDS block of the element at wave * general_lds_bytes
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
   double* u_e = reinterpret_cast<double*>(smem_raw);  // [DIM][n_dof]
   double* Pw = u_e + n_tdof;                          // [n_q][DD]   w*det*P
   double* Aw = Pw + n_q * DD;                         // [n_q][D4]   w*det*dP/dF   (GRAD==1)
-  double* R_e = Aw + (GRAD == 1 ? n_q * D4 + n_dof * DD * DIM + 8 * n_tdof : 0);  // [n_tdof] (GRAD==2); GRAD==1: T[n_dof][DIM^3], gC[8][n_tdof] sit before it
+  double* R_e = Aw + (GRAD == 1 ? n_q * D4 + n_dof * DD * DIM + (GEN_MF_QC > 8 ? GEN_MF_QC : 8) * n_tdof : 0);  // [n_tdof] (GRAD==2); GRAD==1: T[n_dof][DIM^3], gC[8][n_tdof] sit before it
   int32_t* node = reinterpret_cast<int32_t*>(R_e + (GRAD == 2 ? n_tdof : 0));  // [n_dof]
 
   const double* gE = p.dN_dX + (int64_t)e * n_q * n_tdof;
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
     // phase 3 on v_mfma_f64_16x16x4: A operand [row = lane % 16][k = lane / 16] = g[J = k][a], B operand
     // [k = lane / 16][col = lane % 16] = sum_L A_q[iJ, jL] g[L][b], D register r of lane l:
     // row (l / 16) + 4 r, column l % 16
-    constexpr int QC = 8;
+    constexpr int QC = GEN_MF_QC;
     double* gC = Aw + n_q * D4 + n_dof * (DD * DIM);   // [QC][DIM][n_dof] (the T buffer of the other route is unused)
     const int wave = tid >> 6, lane = tid & 63;
     const int nt = wave & 3, mh = wave >> 2;
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(64 * GG_WAVES) void general_gather_kernel(int64_t n
 inline size_t general_lds_bytes(int dim, int n_dof, int n_q, int grad) {
   const int dd = dim * dim, n_tdof = n_dof * dim;
   size_t doubles = n_tdof + (size_t)n_q * dd;
-  if (grad == 1) doubles += (size_t)n_q * dd * dd + (size_t)n_dof * dd * dim + (size_t)8 * n_tdof;
+  if (grad == 1) doubles += (size_t)n_q * dd * dd + (size_t)n_dof * dd * dim + (size_t)(GEN_MF_QC > 8 ? GEN_MF_QC : 8) * n_tdof;
   if (grad == 2) doubles += n_tdof;
   return doubles * sizeof(double) + (size_t)n_dof * sizeof(int32_t);
 }
