@@ -244,7 +244,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
     const int32_t* pp_tab = p.pair_pos + (int64_t)e * n_dof * n_dof;
     const int b = 16 * nt + l16;
     if (p.scratch_k) {
-      // two-phase: the element block goes out densely, row (a, i) = 192 contiguous doubles [b][j]; general_gather_kernel
+      // two-phase: the element block goes out densely, row (a, i) = 192 contiguous doubles [j][b] (16 lanes of an
+      // accumulator register cover 128 contiguous bytes); general_gather_kernel
       // sums the rows of every CSR row afterwards (the scattered fp64 atomics below run memory-side and bound this path)
       double* Ke = p.scratch_k + (int64_t)e * (n_tdof * n_tdof);
 #pragma unroll
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
 #pragma unroll
           for (int i = 0; i < DIM; ++i)
 #pragma unroll
-            for (int j = 0; j < DIM; ++j) Ke[((a * DIM + i) * n_dof + b) * DIM + j] = acc[mt][i * DIM + j][r];
+            for (int j = 0; j < DIM; ++j) Ke[(a * DIM + i) * n_tdof + j * n_dof + b] = acc[mt][i * DIM + j][r];
         }
     } else
 #pragma unroll
@@ -454,9 +455,9 @@ __global__ __launch_bounds__(64 * GG_WAVES) void general_gather_kernel(int64_t n
     const int32_t ea = adj[t];
     const int64_t e = ea >> 6;
     const int a = ea & 63;
-    const double* Kr = scratch_k + (e * NT + (a * DIM + i)) * (int64_t)NT + lane * DIM;
+    const double* Kr = scratch_k + (e * NT + (a * DIM + i)) * (int64_t)NT + lane;   // row (a, i): [j][b], lane = b
     const int32_t off = pair_pos[(e * ND + a) * ND + lane];
-    const double v0 = Kr[0], v1 = Kr[1], v2 = Kr[2];
+    const double v0 = Kr[0], v1 = Kr[ND], v2 = Kr[2 * ND];
     img[off] += v0;
     img[off + 1] += v1;
     img[off + 2] += v2;
