@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MIMI_HIP_ABI_VERSION 4
+#define MIMI_HIP_ABI_VERSION 5
 
 /* ---- errors ---------------------------------------------------------------- */
 const char* mimi_hip_last_error(void);
