@@ -69,6 +69,20 @@ def measured_traffic(workload, world, grad, material):
     return t.get(key, {}).get("bytes_per_step")
 
 
+def measured_traffic_per_kernel(workload, world, grad, material):
+    """(phase 1 bytes, phase 2 bytes) of the same PMC passes, or None"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f).get(f"{workload}/{material}/{'grad' if grad else 'residual'}/n{world}")
+        f2 = sum(v for k, v in t["fetch_size_kb_raw"].items() if "p2" in k)
+        w2 = sum(v for k, v in t["write_size_kb"].items() if "p2" in k)
+        f1 = sum(t["fetch_size_kb_raw"].values()) - f2
+        w1 = sum(t["write_size_kb"].values()) - w2
+        return (2 * f1 + w1) * 1024, (2 * f2 + w2) * 1024
+    except (OSError, TypeError, KeyError, AttributeError):
+        return None
+
+
 def make_material(kind):
     import mimi_amd
     if kind == "neohookean":
@@ -260,6 +274,18 @@ def main():
     kernel_ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]))
     # "also reported per full Newton iteration (= 1 x (R+J) + 2 x (R) assemblies, newton.cpp:142-190)":
     # the residual-only assembly is timed AFTER the timed region above (N = 1 only; informational)
+    # per-kernel durations, live: events inside the library around phase 1 and phase 2 (after the timed region)
+    phase_ms = None
+    if world == 1 and not args.residual_only and integ.path_ == 1:
+        integ.SetPhaseTiming(True)
+        acc1 = acc2 = 0.0
+        for _ in range(5):
+            integ.AddDomainResidualAndGrad(u, 1.0, r, A)
+            a1, a2 = integ.PhaseMs()
+            acc1 += a1
+            acc2 += a2
+        integ.SetPhaseTiming(False)
+        phase_ms = (acc1 / 5, acc2 / 5)
     residual_ms = None
     if world == 1 and not args.residual_only:
         for _ in range(3):
@@ -297,7 +323,15 @@ def main():
                                    "(integration, phase 1) + tensor_p2_kernel (row gather, phase 2) on rank 0; "
                                    "avg_launch_ms is their sum, measured with events on the launch stream",
                          "algorithmic_bytes_per_element": balg, "elements_per_launch": local_elements,
-                         "avg_launch_ms": kernel_ms},
+                         "avg_launch_ms": kernel_ms,
+                         "phase_ms": None if phase_ms is None else
+                         {"phase1_integration_kernels": phase_ms[0], "phase2_row_gather": phase_ms[1],
+                          **({} if measured_traffic_per_kernel(args.workload, world, True, material) is None else
+                             {"phase1_hbm_GB_per_s": measured_traffic_per_kernel(args.workload, world, True, material)[0] / phase_ms[0] / 1e6,
+                              "phase2_hbm_GB_per_s": measured_traffic_per_kernel(args.workload, world, True, material)[1] / phase_ms[1] / 1e6}),
+                          "how": "HIP events recorded by the library on the launch stream around the kernels of each phase, "
+                                 "mean of 5 assemblies after the timed region; phase 1 is fp64-pipe-bound, phase 2 HBM-bound "
+                                 "(DESIGN.md 4.1)"}},
         }
         if not args.residual_only and patch.dim == 3:
             # second view of the same step (the tangent contraction is fp64-matrix-bound before it is HBM-bound):

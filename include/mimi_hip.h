@@ -164,6 +164,11 @@ int mimi_hip_domain_post_time_advance(mimi_hip_domain_t h, const double* u);
  *        3 its second one: beta (J2Linear, materials.hpp:158), F_old (J2Simo, materials.hpp:434) */
 int mimi_hip_domain_get_state(mimi_hip_domain_t h, int what, double* out, int64_t capacity);
 int mimi_hip_domain_reset_state(mimi_hip_domain_t h);
+/* measurement aid (bench.py): HIP events on the launch stream around the two phases of the last two-phase tangent
+ * assembly -- phase 1 = the integration kernel(s), phase 2 = the row gather.  Off by default (three event records per
+ * call when on). */
+int mimi_hip_domain_set_phase_timing(mimi_hip_domain_t h, int on);
+int mimi_hip_domain_phase_ms(mimi_hip_domain_t h, double* phase1_ms, double* phase2_ms);
 /* sizes: what = 0 n_elements, 1 n_quad, 2 n_dof, 3 nnz, 4 n_vdofs, 5 path (0 general, 1 tensor) */
 int64_t mimi_hip_domain_info(mimi_hip_domain_t h, int what);
 

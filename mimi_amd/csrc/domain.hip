@@ -386,6 +386,8 @@ static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double*
 using namespace mimi_hip;
 
 mimi_hip_domain_s::~mimi_hip_domain_s() {
+  for (auto& ev : phase_ev)
+    if (ev) (void)hipEventDestroy(ev);
   if (status_dev) (void)hipFree(status_dev);
   if (status_host) (void)hipHostFree(status_host);
   if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -749,6 +751,31 @@ int mimi_hip_domain_get_state(mimi_hip_domain_t h, int what, double* out, int64_
     } else {
       fail("unknown state id %d", what);
     }
+  });
+}
+
+int mimi_hip_domain_set_phase_timing(mimi_hip_domain_t h, int on) {
+  return guarded([&] {
+    if (!h) fail("null handle");
+    MH_HIP(hipSetDevice(h->device));
+    if (on)
+      for (auto& ev : h->phase_ev)
+        if (!ev) MH_HIP(hipEventCreate(&ev));
+    h->phase_timing = on != 0;
+  });
+}
+
+int mimi_hip_domain_phase_ms(mimi_hip_domain_t h, double* phase1_ms, double* phase2_ms) {
+  return guarded([&] {
+    if (!h || !phase1_ms || !phase2_ms) fail("null argument");
+    if (!h->phase_timing) fail("phase timing is off (mimi_hip_domain_set_phase_timing)");
+    MH_HIP(hipSetDevice(h->device));
+    MH_HIP(hipEventSynchronize(h->phase_ev[2]));
+    float a = 0.f, b = 0.f;
+    MH_HIP(hipEventElapsedTime(&a, h->phase_ev[0], h->phase_ev[1]));
+    MH_HIP(hipEventElapsedTime(&b, h->phase_ev[1], h->phase_ev[2]));
+    *phase1_ms = a;
+    *phase2_ms = b;
   });
 }
 

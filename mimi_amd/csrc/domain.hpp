@@ -48,6 +48,10 @@ struct mimi_hip_domain_s {
   int* status_dev = nullptr;
   int* status_host = nullptr;  // pinned
   unsigned long long* prof_dev = nullptr;  // MH_PROFILE builds only
+  // mimi_hip_domain_set_phase_timing: events around phase 1 (integration kernels) and phase 2 (gather) of the last
+  // two-phase assembly, on the launch stream
+  bool phase_timing = false;
+  hipEvent_t phase_ev[3] = {nullptr, nullptr, nullptr};
 
   // staging for host-resident u / r / A
   mimi_hip::DeviceBuffer<double> stage_u, stage_r, stage_A;

@@ -930,6 +930,7 @@ inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a) {
   const size_t lds = WgsLds::total * sizeof(double);
   const int kind = h->mat.m.kind;
   const bool record = kind != MIMI_HIP_MAT_NEOHOOKEAN && kind != MIMI_HIP_MAT_J2;
+  if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[0], h->stream));   // phase 1 = material pre-pass + nine-block kernel
   if (kind != MIMI_HIP_MAT_NEOHOOKEAN) {
     h->scratch_pt.resize((size_t)h->n_el * (record ? WGS_REC_FIELDS : WGS_PT_FIELDS) * 64);
     a.scratch_pt = h->scratch_pt.ptr;
@@ -942,7 +943,9 @@ inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a) {
   ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
   hipLaunchKernelGGL(kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
   MH_HIP(hipGetLastError());
+  if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[1], h->stream));
   launch_tensor_p2(h, a);
+  if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[2], h->stream));
 }
 
 }  // namespace mimi_hip

@@ -187,6 +187,15 @@ class NonlinearSolid(NonlinearBase):
         check(_capi.lib().mimi_hip_domain_get_state(self._handle(), ids[what], ptr(out), out.size))
         return out
 
+    def SetPhaseTiming(self, on=True):
+        check(_capi.lib().mimi_hip_domain_set_phase_timing(self._handle(), 1 if on else 0))
+
+    def PhaseMs(self):
+        """(phase 1, phase 2) milliseconds of the last two-phase tangent assembly (events on the launch stream)"""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        check(_capi.lib().mimi_hip_domain_phase_ms(self._handle(), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def ResetState(self):
         check(_capi.lib().mimi_hip_domain_reset_state(self._handle()))
 
