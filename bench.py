@@ -120,6 +120,17 @@ def synthetic_u(patch, scale=0.05, seed=20241008):
     return u
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(p, material, seconds_hint=12.0):
     """The restated reference CPU path (oracle/ref_path.c: forward-FD element Jacobian,
     per-thread full-size arrays + reduction pass, OpenMP) on a bounded sample of the workload."""
@@ -161,7 +172,7 @@ def cpu_baseline(p, material, seconds_hint=12.0):
     return dict(value=P.n_el * reps / t_total, unit="element-integrations/s", cores=threads, kind="port",
                 sample=f"{'x'.join(map(str, n_el))} p={p} {material} block ({P.n_el} elements), {reps} residual+Jacobian "
                        f"assemblies, reference forward-FD element Jacobian, OpenMP {threads} threads "
-                       f"(host has {os.cpu_count()} logical cores)",
+                       f"(host has {os.cpu_count()} logical cores, {_cpu_model()})",
                 analytic_tangent_value=P.n_el * reps_a / t_a,
                 analytic_tangent_note="same restated path and threads with the oracle's analytic element tangent instead of "
                                       "the reference's forward differences")
