@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmimi_hip.so")
-SOURCES = ["domain.hip", "contact.hip", "krylov.hip"]
+SOURCES = ["domain.hip", "tensor_p3.hip", "contact.hip", "krylov.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
          "-Wno-unused-result"]
 
@@ -21,16 +21,38 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=()):
     """Compile every HIP source of the package into mimi_amd/lib/libmimi_hip.so."""
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc] + FLAGS + ["-o", LIB + ".tmp"] + srcs
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "mimi_hip.h"))
+    newest_header = max(os.path.getmtime(h) for h in headers)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), newest_header):
+            return obj
+        cmd = [hipcc] + cflags + ["-c", path, "-o", obj] + list(extra_flags)
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+        return obj
+
+    # one translation unit per source, compiled side by side
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(srcs)) as pool:
+        objs = list(pool.map(compile_one, srcs))
+    cmd = [hipcc] + FLAGS + ["-o", LIB + ".tmp"] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)
     os.replace(LIB + ".tmp", LIB)
     return LIB

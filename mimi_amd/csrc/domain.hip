@@ -12,6 +12,7 @@
 #include "kernels_tensor_wgs.hpp"
 #include "kernels_tensor_wgsym.hpp"
 #include "kernels_tensor_residual.hpp"
+#include "tensor_dispatch.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -368,7 +369,7 @@ static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double*
   const int grad = !with_grad ? 0 : (h->tangent_mode == MIMI_HIP_TANGENT_REFERENCE_FD ? 2 : 1);
   // (the colour-partitioned tensor kernel, the fallback when the CSR is not the structured pattern, has closed-form
   // materials only: the other materials then take the general kernels)
-  if (h->path == 1 && grad != 2 && (material_closed_form(h->mat.m.kind) || two_phase_supported(h))) {
+  if (tensor_usable(h) && grad != 2 && (material_closed_form(h->mat.m.kind) || two_phase_supported(h))) {
     launch_tensor(h, grad, mu.dev, mr.dev, mA.dev, gf);
   } else {
     ensure_general_tables(h);
@@ -642,8 +643,10 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
       h->structured_perm = (*h->status_host == 0);
       MH_HIP(hipMemsetAsync(h->status_dev, 0, sizeof(int), h->stream));
     }
+    // degree 3 has the two-phase tensor kernels only: anything else about the handle (numbering, pattern) -> general path
+    if (h->path == 1 && !tensor_usable(h.get())) h->path = 0;
     // pair positions now unless this handle will run the two-phase kernels (then on demand, ensure_pair_pos)
-    if (!(h->path == 1 && two_phase_supported(h.get()))) build_pair_pos(h.get(), p->csr_col);
+    if (!(tensor_usable(h.get()) && two_phase_supported(h.get()))) build_pair_pos(h.get(), p->csr_col);
     init_state(h.get());
     MH_HIP(hipStreamSynchronize(h->stream));
     *out = h.release();

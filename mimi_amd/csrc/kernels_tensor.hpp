@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256) void tensor_post_kernel(TensorArgs p, int n_el
 inline bool tensor_supported(int dim, const int* degree, int nq) {
   if (dim != 3) return false;
   if (degree[0] != degree[1] || degree[1] != degree[2]) return false;
-  if (degree[0] != 2) return false;
+  if (degree[0] != 2 && degree[0] != 3) return false;   // p = 3: tensor_p3.hip
   return nq == degree[0] + 2;
 }
 
@@ -788,43 +788,6 @@ inline void launch_tensor_p(mimi_hip_domain_s* h, int grad, TensorArgs a) {
       hipLaunchKernelGGL(kernel, dim3(n_units * 3), dim3(64), lds, h->stream, a);
       MH_HIP(hipGetLastError());
     }
-}
-
-inline bool two_phase_supported(const mimi_hip_domain_s* h);                     // kernels_tensor_2phase.hpp
-inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a);               // kernels_tensor_wgs.hpp
-inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a);             // kernels_tensor_wgsym.hpp
-inline void launch_tensor_residual(mimi_hip_domain_s* h, TensorArgs a);          // kernels_tensor_residual.hpp
-static void ensure_pair_pos(mimi_hip_domain_s* h);                                // domain.hip
-
-inline void launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, double* r, double* A, double gf) {
-  TensorArgs a = tensor_args(h, u, r, A, gf);
-  // MIMI_HIP_TENSOR_VARIANT: default when supported = two-phase with role-specialised workgroups, the
-  // symmetric-half kernel for hyperelastic materials; "wgs" forces the full nine-block kernel,
-  // "valu" the colour-partitioned read-modify-write kernel
-  static const char* variant = getenv("MIMI_HIP_TENSOR_VARIANT");
-  const bool closed_form = h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN || h->mat.m.kind == MIMI_HIP_MAT_J2;
-  const bool want_valu = variant && variant[0] == 'v' && closed_form;   // the colour kernel has the closed-form materials only
-  if (grad && !want_valu && two_phase_supported(h)) {
-    const bool want_full = variant && variant[0] == 'w';
-    if (h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN && !want_full) launch_tensor_wgsym(h, a);
-    else launch_tensor_wgs(h, a);
-  }
-  else if (!grad && !want_valu && two_phase_supported(h))
-    launch_tensor_residual(h, a);
-  else {
-    if (grad) {
-      ensure_pair_pos(h);       // domain.hip: the colour kernel scatters the tangent through the pair-position table
-      a.pair_pos = h->pair_pos.ptr;
-    }
-    launch_tensor_p<2>(h, grad, a);
-  }
-}
-
-inline void launch_tensor_post(mimi_hip_domain_s* h, const double* u) {
-  TensorArgs a = tensor_args(h, u, nullptr, nullptr, 0.0);
-  const int blocks = (h->n_el + 3) / 4;
-  hipLaunchKernelGGL(tensor_post_kernel<2>, dim3(blocks), dim3(256), 0, h->stream, a, h->n_el);
-  MH_HIP(hipGetLastError());
 }
 
 }  // namespace mimi_hip

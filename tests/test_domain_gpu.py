@@ -75,8 +75,8 @@ def test_residual_and_tangent_parity(case, matname, creator):
     from oracle import ref_path as rp
     n_el, p, lengths = case
     P, D, G = make_pair(n_el, p, lengths, matname, creator)
-    # structured 3-D p=2 patches must take the sum-factorised (tensor) kernels
-    assert G.path_ == (1 if (creator == "bspline" and len(n_el) == 3 and p == 2) else 0)
+    # structured 3-D p=2 and p=3 patches must take the sum-factorised (tensor) kernels
+    assert G.path_ == (1 if (creator == "bspline" and len(n_el) == 3 and p in (2, 3)) else 0)
     dt = 0.5
     D.set_dt(dt)
     G.dt_ = dt
