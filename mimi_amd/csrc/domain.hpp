@@ -39,7 +39,7 @@ struct mimi_hip_domain_s {
   bool structured_perm = false;              // permuted numbering whose CSR rows are the permuted structured pattern
   mimi_hip::DeviceBuffer<unsigned char> nbr_pos;  // [n_nodes][125] rank of each window neighbour inside the row (structured_perm)
   bool first_is_identity = false;            // span e's first basis function is e (no repeated interior knots)
-  mimi_hip::DeviceBuffer<double> scratch_k, scratch_r, scratch_pt;  // two-phase tangent path
+  mimi_hip::DeviceBuffer<double> scratch_k, scratch_r, scratch_pt, scratch_tail;  // two-phase tangent path
 
   // J2 state, SoA over points
   mimi_hip::DeviceBuffer<double> eqps, temperature, plastic_strain, state2;

@@ -64,6 +64,7 @@ struct TensorArgs {
   int seg_len;               // elements per unit along the walked direction (box_n[2] = whole columns); phase 2: an
                              // element at the end of a unit holds the carried rows (third part of its pieces)
   const unsigned char* nbr_pos;  // two-phase path, permuted numbering: [n_nodes][125] positions inside a CSR row
+  double* scratch_tail;      // p = 3 two-phase path: [column][3][48*144] carried rows of the last element of a column
 };
 
 // wave-private LDS carve, in doubles

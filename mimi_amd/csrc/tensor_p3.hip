@@ -25,6 +25,8 @@
 // Nothing is atomic: results are bitwise reproducible.
 #include "tensor_p3.hpp"
 
+#include <type_traits>
+
 namespace mimi_hip {
 
 namespace {
@@ -33,7 +35,8 @@ typedef double t3_d4 __attribute__((ext_vector_type(4)));
 
 constexpr int T3_NB = 4, T3_NQ = 5, T3_ND = 64, T3_NPT = 125, T3_PS = 128, T3_NROW = 192;
 constexpr int T3_REC = 90;                        // 81 Ahat + 9 Phat (the record layout of kernels_tensor_wgs.hpp)
-constexpr int T3_PIECE = T3_ND * T3_NROW;         // doubles per (element, i)
+constexpr int T3_PIECE = 16 * 192 + 48 * 48;       // doubles per (element, i): rows a2 = 0, then rows a2 >= 1 at b2 = 0
+constexpr int T3_TAIL = 48 * 144;                  // per (column, i): rows a2 >= 1 at b2 >= 1 of the column's last element
 
 // ------------------------------------------------------------------------------------------------
 // pre-pass
@@ -205,8 +208,24 @@ MH_DEV double t3_readlane(double x, int l) {
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
+// lanes 0..31: a of the same lane; lanes 32..63: b of lane - 32   (v_permlane32_swap: checked on gfx950, scratch/pl)
+MH_DEV double t3_low_halves(double a, double b) {
+  const unsigned long long ua = __double_as_longlong(a), ub = __double_as_longlong(b);
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  return __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]);
+}
+
 // Lane layout of v_mfma_f64_16x16x4 (gfx950): A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15],
-// D register r: [row = (lane >> 4) + 4 r][col = lane & 15].  Node pairs are indexed 4 a + b.
+// D register r: [row = (lane >> 4) + 4 r][col = lane & 15].
+//
+// One wave per (element column along the third direction, row component i, column component j); it walks the column.
+// Node pairs of directions 0 and 1 are indexed 4 a + b; those of direction 2 -- the rows of the result --
+// DIAGONALLY, (b2 - a2 mod 4) + 4 a2, so that result register r is a2 and the lane group is b2 - a2: the entry
+// (a2, b2) of this element and the entry (a2 - 1, b2 - 1) of the next one -- the same pair of nodes -- are registers
+// r and r - 1 of the SAME lane.  The sums over the elements of a column therefore run inside the wave (the carry of the
+// 48 values per lane waits in LDS, private to the wave, and enters the next element as the accumulator input of S3), and
+// every (node pair, column) leaves the wave once, from the highest element that contains both nodes.
 //
 // S1, per (m, n): two tiles of 16 point rows rho = kk + 4 r (kk = lane >> 4 of the RESULT, r = result register)
 //   tile U: rho -> (q0, q1) = (rho & 3, rho >> 2)                        i.e. result lane group kk = q0, register r = q1
@@ -216,90 +235,104 @@ MH_DEV double t3_readlane(double x, int l) {
 //   two k-steps each: q2 = kk, then q2 = 4 (operand lane group 0 only).
 // S2 runs lane-local on the result registers: the points q0 < 4 with wave-uniform coefficients, the plane q0 = 4
 // with per-lane ones (two partial sums, lane groups 0 and 1).
-// S3, per (a1, b1) and table variant g: one k-step q0 = kk and one for q0 = 4, whose two partial sums the instruction
-// adds itself (k = 0, 1; k = 2, 3 are zero).
+// S3, per (a1, b1): one k-step q0 = kk per table variant g, and for the plane q0 = 4 two k-steps that each take the
+// partial sums of two variants (k = 0, 1: variant g, k = 2, 3: variant g + 1, moved there by one v_permlane32_swap pair).
+//
+// Piece of (element, i), 5376 doubles -- what phase 2 reads contiguously:
+//   [0, 3072)     rows a2 = 0:  (a0 + 4 a1) 192 + j 64 + b1 16 + b2 4 + b0
+//   [3072, 5376)  rows a2 >= 1, b2 = 0:  3072 + (a0 + 4 a1 + 16 (a2 - 1)) 48 + j 16 + b1 4 + b0
+// and per (column, i) the tail of its last element, rows a2 >= 1, b2 >= 1:
+//   (a0 + 4 a1 + 16 (a2 - 1)) 144 + j 48 + b1 12 + (b2 - 1) 4 + b0
 __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
-  constexpr int NB = T3_NB, NQ = T3_NQ, PS = T3_PS, NROW = T3_NROW;
+  constexpr int NB = T3_NB, NQ = T3_NQ, PS = T3_PS;
+  extern __shared__ __align__(16) double carry[];   // [16 (a1, b1)][3][64 lanes], then the direction-1 table [6][2][4]
   const int lane = threadIdx.x;
-  const int64_t e = blockIdx.x / 3;
-  const int I = (int)(blockIdx.x % 3);
+  const int J = (int)(blockIdx.x % 3), I = (int)((blockIdx.x / 3) % 3);
+  const int64_t col = blockIdx.x / 9;
+  const int eu = (int)(col % p.box_n[0]), ev = (int)(col / p.box_n[0]);
+  const int n_seq = p.box_n[2];
+  const int64_t e_step = (int64_t)p.box_n[0] * p.box_n[1];
   const int c16 = lane & 15, kk = lane >> 4, pa = c16 >> 2, pb = c16 & 3;
-  int span[3];
-  span[0] = p.box_begin[0] + (int)(e % p.box_n[0]);
-  span[1] = p.box_begin[1] + (int)((e / p.box_n[0]) % p.box_n[1]);
-  span[2] = p.box_begin[2] + (int)(e / ((int64_t)p.box_n[0] * p.box_n[1]));
+  const int pa2 = c16 >> 2, pb2 = (pa2 + (c16 & 3)) & 3;   // direction 2: diagonal pair index
 
-  // matrix B operands: pair tables of direction 2 (S1) and direction 0 (S3), variants (a: B / D) + 2 (b: B / D)
-  double bS2[4][2], bS0[4][2];
+  // direction 0 (S3 B operands): variants (a: B / D) + 2 (b: B / D); k-step 0: q0 = kk; the plane q0 = 4: variants 0 | 1 and 2 | 3
+  double bS0[4], bS0x[2];
   {
-    const double* B2 = p.tabB[2] + (int64_t)span[2] * NB * NQ;
-    const double* D2 = p.tabD[2] + (int64_t)span[2] * NB * NQ;
-    const double* B0 = p.tabB[0] + (int64_t)span[0] * NB * NQ;
-    const double* D0 = p.tabD[0] + (int64_t)span[0] * NB * NQ;
+    const double* B0 = p.tabB[0] + (int64_t)(p.box_begin[0] + eu) * NB * NQ;
+    const double* D0 = p.tabD[0] + (int64_t)(p.box_begin[0] + eu) * NB * NQ;
+    const double Ba = B0[pa * NQ + kk], Da = D0[pa * NQ + kk], Bb = B0[pb * NQ + kk], Db = D0[pb * NQ + kk];
+    const double Bax = B0[pa * NQ + 4], Dax = D0[pa * NQ + 4], Bbx = B0[pb * NQ + 4], Dbx = D0[pb * NQ + 4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int q = s == 0 ? kk : NQ - 1;
-      const bool ok2 = s == 0 || kk == 0, ok0 = s == 0 || kk < 2;
-      const double Ba2 = B2[pa * NQ + q], Da2 = D2[pa * NQ + q], Bb2 = B2[pb * NQ + q], Db2 = D2[pb * NQ + q];
-      const double Ba0 = B0[pa * NQ + q], Da0 = D0[pa * NQ + q], Bb0 = B0[pb * NQ + q], Db0 = D0[pb * NQ + q];
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        bS2[v][s] = ok2 ? ((v & 1) ? Da2 : Ba2) * ((v & 2) ? Db2 : Bb2) : 0.0;
-        bS0[v][s] = ok0 ? ((v & 1) ? Da0 : Ba0) * ((v & 2) ? Db0 : Bb0) : 0.0;
-      }
-    }
+    for (int v = 0; v < 4; ++v) bS0[v] = ((v & 1) ? Da : Ba) * ((v & 2) ? Db : Bb);
+    bS0x[0] = kk < 2 ? Bax * Bbx : Dax * Bbx;
+    bS0x[1] = kk < 2 ? Bax * Dbx : Dax * Dbx;
   }
-  // direction-1 tables: wave-uniform [B, D][a][q1] ...
-  double uT[2][NB][NQ];
-  {
-    const int k = lane < NB * NQ ? lane : (lane < 2 * NB * NQ ? lane - NB * NQ : 0);
-    const double t1 = ((lane < NB * NQ ? p.tabB[1] : p.tabD[1]) + (int64_t)span[1] * NB * NQ)[k];
-#pragma unroll
-    for (int v = 0; v < 2; ++v)
-#pragma unroll
-      for (int a = 0; a < NB; ++a)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) uT[v][a][q] = t3_readlane(t1, v * NB * NQ + a * NQ + q);
+  // direction 1 (S2 coefficients): table rows [q1][B, D][a] in LDS, q1 = 0..4 and a row of zeros.  The points q0 < 4 read
+  // row q1 = slot (the same for every lane); for the plane q0 = 4 register r = 1..3 of tile V holds q1 = r - 1 in lane
+  // group 0 and q1 = r + 2 in lane group 1 (nothing elsewhere): per-lane rows
+  double* tl = carry + 16 * 3 * 64;
+  if (lane < 2 * NB * NQ) {
+    const int v = lane / (NB * NQ), a = (lane % (NB * NQ)) / NQ, q = lane % NQ;
+    tl[q * 8 + v * 4 + a] = ((v ? p.tabD[1] : p.tabB[1]) + (int64_t)(p.box_begin[1] + ev) * NB * NQ)[a * NQ + q];
+  } else if (lane < 2 * NB * NQ + 8) {
+    tl[lane] = 0.0;
   }
-  // ... and per lane for the plane q0 = 4: register r = 1..3 of tile V holds q1 = r - 1 (lane group 0), r + 2 (group 1)
-  double cx[2][NB][3];
+  // the first element of the column starts from a zero carry
 #pragma unroll
-  for (int v = 0; v < 2; ++v)
+  for (int k = 0; k < 16 * 3; ++k) carry[k * 64 + lane] = 0.0;
+  __syncthreads();
+  const double* xrow[3];
 #pragma unroll
-    for (int a = 0; a < NB; ++a)
-#pragma unroll
-      for (int r = 1; r < 4; ++r)
-        cx[v][a][r - 1] = kk == 0 ? uT[v][a][r - 1] : ((kk == 1 && r < 3) ? uT[v][a][r + 2] : 0.0);
+  for (int r = 1; r < 4; ++r) xrow[r - 1] = tl + 8 * (kk == 0 ? r - 1 : ((kk == 1 && r < 3) ? r + 2 : NQ));
 
   // S1 A operands: the points of this lane
-  const int rq0 = c16 & 3, rq1 = c16 >> 2;
-  const int ptU = rq0 + NQ * rq1;
+  const int ptU = (c16 & 3) + NQ * (c16 >> 2);
   const bool vrow = c16 < 4 || c16 == 4 || c16 == 8 || c16 == 12 || c16 == 5 || c16 == 9;
   const int vq0 = c16 < 4 ? c16 : 4;
   const int vq1 = c16 < 4 ? 4 : (c16 == 5 ? 3 : (c16 == 9 ? 4 : c16 / 4 - 1));
   const int ptV = vrow ? vq0 + NQ * vq1 : 0;
   const int offU0 = ptU + NQ * NQ * kk, offU1 = ptU + NQ * NQ * (NQ - 1);
   const int offV0 = ptV + NQ * NQ * kk, offV1 = ptV + NQ * NQ * (NQ - 1);
-  const bool okU1 = kk == 0, okV0 = vrow, okV1 = vrow && kk == 0;
-  const double* rec = p.scratch_pt + e * (int64_t)(T3_REC * PS) + (int64_t)I * 27 * PS;
-  double* piece = p.scratch_k + (e * 3 + I) * (int64_t)T3_PIECE + pa * NROW + kk * 4 + pb;
 
+  const int64_t e0 = eu + (int64_t)p.box_n[0] * ev;
   const t3_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
-  double aop[9][4];
-  auto load_ops = [&](int j) {
+  double aop[9][4], t2[2][4];   // operands of the element about to be contracted: Ahat values, raw direction-2 tables
+  auto request = [&](int es) {
+    const int64_t e = e0 + e_step * es;
+    const double* rec = p.scratch_pt + e * (int64_t)(T3_REC * PS) + (int64_t)I * 27 * PS;
 #pragma unroll
     for (int mn = 0; mn < 9; ++mn) {
       const int m = mn / 3, n = mn % 3;
-      const double* f = rec + (int64_t)((m * 3 + j) * 3 + n) * PS;
+      const double* f = rec + (int64_t)((m * 3 + J) * 3 + n) * PS;
+      // every lane loads a real (finite) value: the lanes that carry no point meet a zero B operand (second k-step)
+      // or feed rows of the result that nothing reads
       aop[mn][0] = f[offU0];
-      aop[mn][1] = okU1 ? f[offU1] : 0.0;
-      aop[mn][2] = okV0 ? f[offV0] : 0.0;
-      aop[mn][3] = okV1 ? f[offV1] : 0.0;
+      aop[mn][1] = f[offU1];
+      aop[mn][2] = f[offV0];
+      aop[mn][3] = f[offV1];
+    }
+    const double* B2 = p.tabB[2] + (int64_t)(p.box_begin[2] + es) * NB * NQ;
+    const double* D2 = p.tabD[2] + (int64_t)(p.box_begin[2] + es) * NB * NQ;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int q = s == 0 ? kk : NQ - 1;
+      t2[s][0] = B2[pa2 * NQ + q];
+      t2[s][1] = D2[pa2 * NQ + q];
+      t2[s][2] = B2[pb2 * NQ + q];
+      t2[s][3] = D2[pb2 * NQ + q];
     }
   };
-  load_ops(0);
+  request(0);
+  double* cl = carry + lane;
 #pragma unroll 1
-  for (int j = 0; j < 3; ++j) {
+  for (int es = 0; es < n_seq; ++es) {
+    // S1
+    double bS2[4][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        bS2[v][s] = (s == 0 || kk == 0) ? ((v & 1) ? t2[s][1] : t2[s][0]) * ((v & 2) ? t2[s][3] : t2[s][2]) : 0.0;
     t3_d4 DU[9], DV[9];
 #pragma unroll
     for (int mn = 0; mn < 9; ++mn) {
@@ -315,54 +348,93 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       DU[mn] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[mn][1], bS2[v2][1], DU[mn], 0, 0, 0);
       DV[mn] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[mn][3], bS2[v2][1], DV[mn], 0, 0, 0);
     }
-    // the operands of the next column component travel while this one is contracted
-    if (j + 1 < 3) load_ops(j + 1);
-    double* out = piece + j * 64;
+    // the operands of the next element travel while this one is contracted
+    request(es + 1 < n_seq ? es + 1 : es);   // (the last element once more: no branch in the loop)
+    const int64_t e = e0 + e_step * es;
+    double* piece = p.scratch_k + (e * 3 + I) * (int64_t)T3_PIECE;
+    double* out0 = piece + pa * 192 + J * 64 + kk * 4 + pb;                       // + 4 a1 192 + b1 16
+    // lane groups 1..3 hold one final entry with b2 = 0 (register 4 - kk); lane group 0 none: it stores register 0 twice
+    double* out1 = kk == 0 ? out0 : piece + 3072 + (pa + 16 * (3 - kk)) * 48 + J * 16 + pb;   // + 4 a1 48 + b1 4
 #pragma unroll
     for (int b1 = 0; b1 < NB; ++b1) {
-      // E[g][a1]: points q0 < 4 (Em) and the two partial sums of the plane q0 = 4 (Ex)
-      double Em[4][NB], Ex[4][NB];
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int a1 = 0; a1 < NB; ++a1) Em[g][a1] = Ex[g][a1] = 0.0;
+      __builtin_amdgcn_sched_barrier(0);   // one b1 at a time: interleaved they need more registers than there are
       // (m, n) -> variant of direction 1 (a: m == 1, b: n == 1) and group g of direction 0 (a: m == 0, b: n == 0):
       //   g = 3: (0,0)   g = 1: (0,1) (0,2)   g = 2: (1,0) (2,0)   g = 0: (1,1) (1,2) (2,1) (2,2)
+      // EXTRA 0: the points q0 < 4 (slots q1 = 0..4, wave-uniform coefficients); 1: the plane q0 = 4 (registers 1..3
+      // of tile V, per-lane coefficients; two partial sums in lane groups 0 and 1)
+      t3_d4 Kt[NB];
+      auto s2 = [&](auto extra_tag, double (&E)[4][NB]) {
+        constexpr bool ex = decltype(extra_tag)::value;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const bool ex = s >= NQ;
-        double X[9];
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int mn = 0; mn < 9; ++mn) X[mn] = ex ? DV[mn][ex ? s - NQ + 1 : 0] : (s < 4 ? DU[mn][s < 4 ? s : 0] : DV[mn][0]);
-        const int sx = ex ? s - NQ : 0, sm = ex ? 0 : s;
-        const double cbB = ex ? cx[0][b1][sx] : uT[0][b1][sm], cbD = ex ? cx[1][b1][sx] : uT[1][b1][sm];
-        const double W3 = cbB * X[0];
-        const double W1 = cbD * X[1] + cbB * X[2];
-        const double W2a = cbB * X[3], W2b = cbB * X[6];
-        const double W0a = cbD * X[4] + cbB * X[5], W0b = cbD * X[7] + cbB * X[8];
+          for (int a1 = 0; a1 < NB; ++a1) E[g][a1] = 0.0;
+#pragma unroll
+        for (int s = 0; s < (ex ? 3 : NQ); ++s) {
+          double X[9];
+#pragma unroll
+          for (int mn = 0; mn < 9; ++mn) X[mn] = ex ? DV[mn][s + 1] : (s < 4 ? DU[mn][s < 4 ? s : 0] : DV[mn][0]);
+          const double* row = ex ? xrow[s < 3 ? s : 0] : tl + 8 * s;
+          double cf[2][NB];
+#pragma unroll
+          for (int k = 0; k < 2 * NB; ++k) cf[k / NB][k % NB] = row[k];
+          const double cbB = cf[0][b1], cbD = cf[1][b1];
+          const double W3 = cbB * X[0];
+          const double W1 = cbD * X[1] + cbB * X[2];
+          const double W2a = cbB * X[3], W2b = cbB * X[6];
+          const double W0a = cbD * X[4] + cbB * X[5], W0b = cbD * X[7] + cbB * X[8];
+#pragma unroll
+          for (int a1 = 0; a1 < NB; ++a1) {
+            const double caB = cf[0][a1], caD = cf[1][a1];
+            E[3][a1] += caB * W3;
+            E[1][a1] += caB * W1;
+            E[2][a1] += caD * W2a + caB * W2b;
+            E[0][a1] += caD * W0a + caB * W0b;
+          }
+        }
+      };
+      {
+        double Em[4][NB];
+        s2(std::false_type{}, Em);
 #pragma unroll
         for (int a1 = 0; a1 < NB; ++a1) {
-          const double caB = ex ? cx[0][a1][sx] : uT[0][a1][sm], caD = ex ? cx[1][a1][sx] : uT[1][a1][sm];
-          double (&E)[4][NB] = ex ? Ex : Em;
-          E[3][a1] += caB * W3;
-          E[1][a1] += caB * W1;
-          E[2][a1] += caD * W2a + caB * W2b;
-          E[0][a1] += caD * W0a + caB * W0b;
+          const double* c = cl + (a1 * NB + b1) * 3 * 64;
+          Kt[a1] = zero4;
+          Kt[a1][0] = c[0];
+          Kt[a1][1] = c[64];
+          Kt[a1][2] = c[128];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Em[g][a1], bS0[g], Kt[a1], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      double Ex[4][NB];
+      s2(std::true_type{}, Ex);
 #pragma unroll
       for (int a1 = 0; a1 < NB; ++a1) {
-        t3_d4 Kt = __builtin_amdgcn_mfma_f64_16x16x4f64(Em[0][a1], bS0[0][0], zero4, 0, 0, 0);
+        double* c = cl + (a1 * NB + b1) * 3 * 64;
+        t3_d4 Kt1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t3_low_halves(Ex[0][a1], Ex[1][a1]), bS0x[0], Kt[a1], 0, 0, 0);
+        Kt1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t3_low_halves(Ex[2][a1], Ex[3][a1]), bS0x[1], Kt1, 0, 0, 0);
+        // register r of this lane: (a2 = r, b2 = (r + kk) & 3), column (a0 = pa, b0 = pb).  Final: a2 = 0 or b2 = 0.
+        out0[a1 * 4 * 192 + b1 * 16] = Kt1[0];
+        const double fin = kk == 0 ? Kt1[0] : (kk == 1 ? Kt1[3] : (kk == 2 ? Kt1[2] : Kt1[1]));
+        out1[kk == 0 ? a1 * 4 * 192 + b1 * 16 : a1 * 4 * 48 + b1 * 4] = fin;
+        // the pairs (a2 >= 1, b2 >= 1) go on to the next element as its (a2 - 1, b2 - 1)
 #pragma unroll
-        for (int g = 1; g < 4; ++g) Kt = __builtin_amdgcn_mfma_f64_16x16x4f64(Em[g][a1], bS0[g][0], Kt, 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) Kt = __builtin_amdgcn_mfma_f64_16x16x4f64(Ex[g][a1], bS0[g][1], Kt, 0, 0, 0);
-        // result register r: row (a2 = r, b2 = kk), column (a0 = pa, b0 = pb): 16 lanes of equal pa cover 128 bytes
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[(4 * a1 + 16 * r) * NROW + b1 * 16] = Kt[r];
+        for (int r = 1; r < 4; ++r) c[(r - 1) * 64] = ((r + kk) & 3) ? Kt1[r] : 0.0;
       }
     }
   }
+  // what the last element of the column would have passed on: rows a2 >= 1, b2 >= 1 -> the tail of (column, i)
+  double* tail = p.scratch_tail + ((e0 * 3 + I) * (int64_t)T3_TAIL) + pa * 144 + J * 48 + pb;
+#pragma unroll
+  for (int ab = 0; ab < 16; ++ab)
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      const int b2 = (r + kk) & 3;
+      const double v = cl[(ab * 3 + r - 1) * 64];
+      if (b2) tail[(4 * (ab / NB) + 16 * (r - 1)) * 144 + (ab % NB) * 12 + (b2 - 1) * 4] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -371,7 +443,7 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
 // One wave per (node A of the shard's node box, component i).  WITH_K 0: residual rows only.
 template<int WITH_K>
 __global__ __launch_bounds__(256) void tp3_gather_kernel(TensorArgs p, int64_t n_rows) {
-  constexpr int P = 3, NB = T3_NB, ND = T3_ND, NROW = T3_NROW;
+  constexpr int P = 3, NB = T3_NB, ND = T3_ND;
   constexpr int LMAX = 3 * 343;
   __shared__ double img_all[WITH_K ? 4 : 1][LMAX + 3];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -398,34 +470,75 @@ __global__ __launch_bounds__(256) void tp3_gather_kernel(TensorArgs p, int64_t n
     const int w0 = min(A0 + P, n0 - 1) - lo0 + 1, w1 = min(A1 + P, n1 - 1) - lo1 + 1, w2 = min(A2 + P, n2 - 1) - lo2 + 1;
     const int L = 3 * w0 * w1 * w2;
     for (int t = lane; t < L; t += 64) img[t] = 0.0;
-    // lane = position in a row of a piece: [b1][b2][b0] (the three loads of a row are the components j = 0, 1, 2)
-    const int b0 = lane & 3, b2 = (lane >> 2) & 3, b1 = lane >> 4;
-    const int toff = 3 * (b0 + w0 * (b1 + w1 * b2));
+    // lane = position in a row of a piece.  Rows a2 = 0: [b1][b2][b0] per load, the three loads are j = 0, 1, 2;
+    // rows a2 >= 1: [j][b1][b0] (b2 = 0) in one load; tail rows: [b1][b2 - 1][b0] per load, 48 lanes
+    const int toff_full = 3 * ((lane & 3) + w0 * ((lane >> 4) + w1 * ((lane >> 2) & 3)));
+    const int toff_b20 = 3 * ((lane & 3) + w0 * ((lane >> 2) & 3)) + (lane >> 4);
+    const int toff_tail = 3 * ((lane & 3) + w0 * (lane / 12 + w1 * ((lane >> 2) % 3 + 1)));
+    const int last_ez = bx2 + p.box_n[2] - 1;
     __builtin_amdgcn_wave_barrier();
-    for (int ez = ez_lo; ez <= ez_hi; ++ez)
+    for (int ez = ez_lo; ez <= ez_hi; ++ez) {
+      const int a2 = A2 - ez;
       for (int ey = ey_lo; ey <= ey_hi; ++ey) {
-        const int a12 = NB * ((A1 - ey) + NB * (A2 - ez));
+        const int a12 = NB * (A1 - ey);
         double v[NB][3];
+        const bool tail = a2 > 0 && ez == last_ez;
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
           const int ex = ex_lo + c;
           const bool in = ex <= ex_hi;
-          const double* row = p.scratch_k + (elem(in ? ex : ex_lo, ey, ez) * 3 + I) * (int64_t)T3_PIECE
-                              + ((in ? A0 - ex : 0) + a12) * NROW + lane;
+          const int exx = in ? ex : ex_lo;
+          const double* piece = p.scratch_k + (elem(exx, ey, ez) * 3 + I) * (int64_t)T3_PIECE;
+          const int a01 = (A0 - exx) + a12;
+          if (a2 == 0) {
+            const double* row = piece + a01 * 192 + lane;
 #pragma unroll
-          for (int j = 0; j < 3; ++j) v[c][j] = in ? row[j * 64] : 0.0;
+            for (int j = 0; j < 3; ++j) v[c][j] = in ? row[j * 64] : 0.0;
+          } else {
+            const int ar = a01 + 16 * (a2 - 1);
+            v[c][0] = (in && lane < 48) ? piece[3072 + ar * 48 + lane] : 0.0;
+            v[c][1] = v[c][2] = 0.0;
+          }
         }
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
           const int ex = ex_lo + c;
           if (ex <= ex_hi) {
-            const int t = 3 * ((ex - lo0) + w0 * ((ey - lo1) + w1 * (ez - lo2))) + toff;
+            const int tb = 3 * ((ex - lo0) + w0 * ((ey - lo1) + w1 * (ez - lo2)));
+            if (a2 == 0) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) img[t + j] += v[c][j];
+              for (int j = 0; j < 3; ++j) img[tb + toff_full + j] += v[c][j];
+            } else if (lane < 48) {
+              img[tb + toff_b20] += v[c][0];
+            }
           }
           __builtin_amdgcn_wave_barrier();
         }
+        if (tail) {
+          // the column ends inside the support of A: the pairs (a2 >= 1, b2 >= 1) were kept by its last element
+#pragma unroll
+          for (int c = 0; c < NB; ++c) {
+            const int ex = ex_lo + c;
+            const bool in = ex <= ex_hi && lane < 48;
+            const int exx = ex <= ex_hi ? ex : ex_lo;
+            const int64_t colm = (exx - bx0) + (int64_t)p.box_n[0] * (ey - bx1);
+            const double* row = p.scratch_tail + (colm * 3 + I) * (int64_t)T3_TAIL + ((A0 - exx) + a12 + 16 * (a2 - 1)) * 144 + lane;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[c][j] = in ? row[j * 48] : 0.0;
+          }
+#pragma unroll
+          for (int c = 0; c < NB; ++c) {
+            const int ex = ex_lo + c;
+            if (ex <= ex_hi && lane < 48) {
+              const int tb = 3 * ((ex - lo0) + w0 * ((ey - lo1) + w1 * (ez - lo2)));
+#pragma unroll
+              for (int j = 0; j < 3; ++j) img[tb + toff_tail + j] += v[c][j];
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
       }
+    }
     __builtin_amdgcn_wave_barrier();
     double* dst = p.A + p.rowptr[A * 3 + I];
     for (int t = lane; t < L; t += 64) dst[t] += p.grad_factor * img[t];
@@ -457,11 +570,14 @@ void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {
   const bool closed = kind == MIMI_HIP_MAT_NEOHOOKEAN || kind == MIMI_HIP_MAT_J2;
   h->scratch_r.resize((size_t)h->n_el * 3 * T3_ND);
   a.scratch_r = h->scratch_r.ptr;
+  const int64_t n_cols = (int64_t)a.box_n[0] * a.box_n[1];
   if (grad) {
     h->scratch_pt.resize((size_t)h->n_el * T3_REC * T3_PS);
     h->scratch_k.resize((size_t)h->n_el * 3 * T3_PIECE);
+    h->scratch_tail.resize((size_t)n_cols * 3 * T3_TAIL);
     a.scratch_pt = h->scratch_pt.ptr;
     a.scratch_k = h->scratch_k.ptr;
+    a.scratch_tail = h->scratch_tail.ptr;
   }
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[0], h->stream));
   {
@@ -471,7 +587,7 @@ void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {
     MH_HIP(hipGetLastError());
   }
   if (grad) {
-    hipLaunchKernelGGL(tp3_contract_kernel, dim3((unsigned)((int64_t)h->n_el * 3)), dim3(64), 0, h->stream, a);
+    hipLaunchKernelGGL(tp3_contract_kernel, dim3((unsigned)(n_cols * 9)), dim3(64), (16 * 3 * 64 + 48) * sizeof(double), h->stream, a);
     MH_HIP(hipGetLastError());
   }
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[1], h->stream));
