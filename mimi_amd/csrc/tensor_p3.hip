@@ -366,10 +366,6 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       auto s2 = [&](auto extra_tag, double (&E)[4][NB]) {
         constexpr bool ex = decltype(extra_tag)::value;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int a1 = 0; a1 < NB; ++a1) E[g][a1] = 0.0;
-#pragma unroll
         for (int s = 0; s < (ex ? 3 : NQ); ++s) {
           double X[9];
 #pragma unroll
@@ -386,10 +382,17 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
 #pragma unroll
           for (int a1 = 0; a1 < NB; ++a1) {
             const double caB = cf[0][a1], caD = cf[1][a1];
-            E[3][a1] += caB * W3;
-            E[1][a1] += caB * W1;
-            E[2][a1] += caD * W2a + caB * W2b;
-            E[0][a1] += caD * W0a + caB * W0b;
+            if (s == 0) {   // (no accumulator starts from 0.0: x + 0.0 is an instruction)
+              E[3][a1] = caB * W3;
+              E[1][a1] = caB * W1;
+              E[2][a1] = caD * W2a + caB * W2b;
+              E[0][a1] = caD * W0a + caB * W0b;
+            } else {
+              E[3][a1] += caB * W3;
+              E[1][a1] += caB * W1;
+              E[2][a1] += caD * W2a + caB * W2b;
+              E[0][a1] += caD * W0a + caB * W0b;
+            }
           }
         }
       };
@@ -417,7 +420,10 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
         Kt1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t3_low_halves(Ex[2][a1], Ex[3][a1]), bS0x[1], Kt1, 0, 0, 0);
         // register r of this lane: (a2 = r, b2 = (r + kk) & 3), column (a0 = pa, b0 = pb).  Final: a2 = 0 or b2 = 0.
         out0[a1 * 4 * 192 + b1 * 16] = Kt1[0];
-        const double fin = kk == 0 ? Kt1[0] : (kk == 1 ? Kt1[3] : (kk == 2 ? Kt1[2] : Kt1[1]));
+        double fin = Kt1[1];
+        fin = kk == 2 ? Kt1[2] : fin;
+        fin = kk == 1 ? Kt1[3] : fin;
+        fin = kk == 0 ? Kt1[0] : fin;
         out1[kk == 0 ? a1 * 4 * 192 + b1 * 16 : a1 * 4 * 48 + b1 * 4] = fin;
         // the pairs (a2 >= 1, b2 >= 1) go on to the next element as its (a2 - 1, b2 - 1)
 #pragma unroll
