@@ -41,6 +41,104 @@ constexpr int T3_TAIL = 48 * 144;                  // per (column, i): rows a2 >
 // ------------------------------------------------------------------------------------------------
 // pre-pass
 // ------------------------------------------------------------------------------------------------
+// Closed forms of the pulled-back, weighted tangent Ahat_i[m][j][n] = wd sum_JL Jinv[m][J] dP_iJ/dF_jL Jinv[n][L] for the
+// two materials with a closed-form dP/dF (materials.hpp tangent_of; the same expressions as the p = 2 point wave,
+// kernels_tensor_wgs.hpp), written straight into the record: rec[field * T3_PS], field = i 27 + (m 3 + j) 3 + n.
+//   with G = Jinv F^-1 (G[m][i] = sum_J Jinv[m][J] Finv[J][i]):
+//   neo-Hookean   wd (mu d_ij M[m][n] - c1 G[n][i] G[m][j] + c2 G[n][j] G[m][i]),  M = Jinv Jinv^T
+//   J2            wd J (G[n][j] S_i[m] - G[m][j] S_i[n] + (K - beta 2G/3) G[m][i] Jinv[n][j]
+//                       + beta G (d_ij N[m][n] + G[m][j] Jinv[n][i]) - 2G gamma Ts_i[m] Q[n][j]),
+//                 N = G Jinv^T, Q[n][j] = sum_L s_jL Jinv[n][L], S_i[m] = sum_k sigma_ik G[m][k], Ts_i[m] = sum_k s_ik G[m][k]
+MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult<3>& w, const double* Ji, double wd, double* rec) {
+  constexpr int PS = T3_PS;
+  double G[9];
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double g = 0.0;
+#pragma unroll
+      for (int Jx = 0; Jx < 3; ++Jx) g += Ji[m * 3 + Jx] * w.Finv[Jx + c * 3];
+      G[m * 3 + c] = g;
+    }
+  if (mm.kind == MIMI_HIP_MAT_NEOHOOKEAN) {
+    const double J = w.detF;
+    const double mu_w = wd * mm.mu, c1_w = wd * (mm.lambda * J * (J - 1.) - mm.mu), c2_w = wd * (mm.lambda * (2. * J - 1.) * J);
+    double M[9];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        double v = 0.0;
+#pragma unroll
+        for (int Jx = 0; Jx < 3; ++Jx) v += Ji[m * 3 + Jx] * Ji[n * 3 + Jx];
+        M[m * 3 + n] = v;
+      }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) {
+            double v = c2_w * G[m * 3 + i] * G[n * 3 + j] - c1_w * G[m * 3 + j] * G[n * 3 + i];
+            if (i == j) v += mu_w * M[m * 3 + n];
+            rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS] = v;
+          }
+    return;
+  }
+  double beta = 1.0, gamma = 0.0;
+  if (w.plastic) {
+    const double q = w.q, Gm = mm.G;
+    beta = 1.0 - 3.0 * Gm * w.delta / q;
+    gamma = 3.0 * Gm * (1.5 / q) * (1.0 / ((3.0 * Gm + w.hprime) * q) - w.delta / (q * q));
+  }
+  const double G2 = 2.0 * mm.G;
+  const double wdJ = wd * w.detF, Kc = mm.K - beta * G2 / 3.0, hb = 0.5 * beta * G2, gg = G2 * gamma;
+  double N[9], Q[9];
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      double v = 0.0, t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        v += G[m * 3 + k] * Ji[n * 3 + k];
+        t += w.s_trial[n + k * 3] * Ji[m * 3 + k];   // Q[m][n] = sum_L s_nL Jinv[m][L]
+      }
+      N[m * 3 + n] = v;
+      Q[m * 3 + n] = t;
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double S[3], Ts[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        a += w.sigma[i + k * 3] * G[m * 3 + k];
+        b += w.s_trial[i + k * 3] * G[m * 3 + k];
+      }
+      S[m] = a;
+      Ts[m] = b;
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          double v = G[n * 3 + j] * S[m] - G[m * 3 + j] * S[n];
+          v += Kc * G[m * 3 + i] * Ji[n * 3 + j];
+          v += hb * ((i == j ? N[m * 3 + n] : 0.0) + G[m * 3 + j] * Ji[n * 3 + i]);
+          v -= gg * Ts[m] * Q[n * 3 + j];
+          rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS] = wdJ * v;
+        }
+  }
+}
+
 // FAMILY 0: closed-form materials (materials.hpp), 1: the others (materials_other.hpp).  GRAD 0: residual pieces only.
 template<int FAMILY, int GRAD>
 __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
@@ -114,7 +212,7 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
         for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * Ji[m * 3 + J];
         F[i + J * 3] = sf;
       }
-    double Pk[9], A[GRAD ? 81 : 1];
+    double Pk[9], A[(GRAD && FAMILY == 1) ? 81 : 1];
     int status;
     if constexpr (FAMILY == 1) {
       status = evaluate_other<3>(p.mat, p.dt, p.state, e * NPT + tid, F, Pk, GRAD ? A : nullptr, 1.0);
@@ -123,7 +221,7 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
       status = evaluate_pk1<3>(p.mat, p.dt, p.state, e * NPT + tid, F, w);
 #pragma unroll
       for (int k = 0; k < 9; ++k) Pk[k] = w.P[k];
-      if constexpr (GRAD) tangent_of<3>(p.mat.m, w, A);
+      if constexpr (GRAD) t3_closed_form_record(p.mat.m, w, Ji, wd, p.scratch_pt + e * (int64_t)(T3_REC * PS) + tid);
     }
     if (status) atomicOr(p.status, status);
 #pragma unroll
@@ -135,7 +233,7 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
         for (int J = 0; J < 3; ++J) t += Pk[i + J * 3] * Ji[m * 3 + J];
         PH[(i * 3 + m) * NPT + tid] = wd * t;
       }
-    if constexpr (GRAD) {
+    if constexpr (GRAD && FAMILY == 1) {
       double* rec = p.scratch_pt + e * (int64_t)(T3_REC * PS) + tid;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -485,17 +583,18 @@ __global__ __launch_bounds__(256) void tp3_gather_kernel(TensorArgs p, int64_t n
     __builtin_amdgcn_wave_barrier();
     for (int ez = ez_lo; ez <= ez_hi; ++ez) {
       const int a2 = A2 - ez;
-      for (int ey = ey_lo; ey <= ey_hi; ++ey) {
-        const int a12 = NB * (A1 - ey);
-        double v[NB][3];
-        const bool tail = a2 > 0 && ez == last_ez;
+      const bool tail = a2 > 0 && ez == last_ez;
+      // EYB element rows (ey) x 4 elements (ex) per batch: their loads are in flight together
+      constexpr int EYB = 2;
+      for (int ey0 = ey_lo; ey0 <= ey_hi; ey0 += EYB) {
+        double v[EYB * NB][3];
 #pragma unroll
-        for (int c = 0; c < NB; ++c) {
-          const int ex = ex_lo + c;
-          const bool in = ex <= ex_hi;
-          const int exx = in ? ex : ex_lo;
-          const double* piece = p.scratch_k + (elem(exx, ey, ez) * 3 + I) * (int64_t)T3_PIECE;
-          const int a01 = (A0 - exx) + a12;
+        for (int c = 0; c < EYB * NB; ++c) {
+          const int ex = ex_lo + c % NB, ey = ey0 + c / NB;
+          const bool in = ex <= ex_hi && ey <= ey_hi;
+          const int exx = in ? ex : ex_lo, eyy = in ? ey : ey_lo;
+          const double* piece = p.scratch_k + (elem(exx, eyy, ez) * 3 + I) * (int64_t)T3_PIECE;
+          const int a01 = (A0 - exx) + NB * (A1 - eyy);
           if (a2 == 0) {
             const double* row = piece + a01 * 192 + lane;
 #pragma unroll
@@ -507,9 +606,9 @@ __global__ __launch_bounds__(256) void tp3_gather_kernel(TensorArgs p, int64_t n
           }
         }
 #pragma unroll
-        for (int c = 0; c < NB; ++c) {
-          const int ex = ex_lo + c;
-          if (ex <= ex_hi) {
+        for (int c = 0; c < EYB * NB; ++c) {
+          const int ex = ex_lo + c % NB, ey = ey0 + c / NB;
+          if (ex <= ex_hi && ey <= ey_hi) {
             const int tb = 3 * ((ex - lo0) + w0 * ((ey - lo1) + w1 * (ez - lo2)));
             if (a2 == 0) {
 #pragma unroll
@@ -523,19 +622,20 @@ __global__ __launch_bounds__(256) void tp3_gather_kernel(TensorArgs p, int64_t n
         if (tail) {
           // the column ends inside the support of A: the pairs (a2 >= 1, b2 >= 1) were kept by its last element
 #pragma unroll
-          for (int c = 0; c < NB; ++c) {
-            const int ex = ex_lo + c;
-            const bool in = ex <= ex_hi && lane < 48;
-            const int exx = ex <= ex_hi ? ex : ex_lo;
-            const int64_t colm = (exx - bx0) + (int64_t)p.box_n[0] * (ey - bx1);
-            const double* row = p.scratch_tail + (colm * 3 + I) * (int64_t)T3_TAIL + ((A0 - exx) + a12 + 16 * (a2 - 1)) * 144 + lane;
+          for (int c = 0; c < EYB * NB; ++c) {
+            const int ex = ex_lo + c % NB, ey = ey0 + c / NB;
+            const bool in = ex <= ex_hi && ey <= ey_hi && lane < 48;
+            const int exx = (ex <= ex_hi && ey <= ey_hi) ? ex : ex_lo, eyy = (ex <= ex_hi && ey <= ey_hi) ? ey : ey_lo;
+            const int64_t colm = (exx - bx0) + (int64_t)p.box_n[0] * (eyy - bx1);
+            const double* row = p.scratch_tail + (colm * 3 + I) * (int64_t)T3_TAIL
+                                + ((A0 - exx) + NB * (A1 - eyy) + 16 * (a2 - 1)) * 144 + lane;
 #pragma unroll
             for (int j = 0; j < 3; ++j) v[c][j] = in ? row[j * 48] : 0.0;
           }
 #pragma unroll
-          for (int c = 0; c < NB; ++c) {
-            const int ex = ex_lo + c;
-            if (ex <= ex_hi && lane < 48) {
+          for (int c = 0; c < EYB * NB; ++c) {
+            const int ex = ex_lo + c % NB, ey = ey0 + c / NB;
+            if (ex <= ex_hi && ey <= ey_hi && lane < 48) {
               const int tb = 3 * ((ex - lo0) + w0 * ((ey - lo1) + w1 * (ez - lo2)));
 #pragma unroll
               for (int j = 0; j < 3; ++j) img[tb + toff_tail + j] += v[c][j];
