@@ -10,15 +10,25 @@ target is quoted on; it fits one MI355X).  For N > 1 the SAME mesh is sharded in
 across the ranks (strong scaling) and the shared-dof rows of the residual / Jacobian are
 summed between neighbouring ranks over RCCL inside the timed region.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured with events on the
+`--gpus N` without a launcher (no WORLD_SIZE in the environment): this process never touches a GPU; it checks
+that N devices are visible, starts N fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+127.0.0.1 rendezvous) and relays rank 0's line.  Under torchrun it is a rank.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernels, measured with events on the
 launch stream) and `cpu_baseline` (the restated reference CPU path = oracle, timed on this
 box's host cores on a bounded sample; rank 0, N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+
+# BASELINE.md 2: OMP_PROC_BIND=close for the CPU baseline; the OpenMP runtime reads it when it is loaded (import torch)
+os.environ.setdefault("OMP_PROC_BIND", "close")
 
 import numpy as np
 
@@ -33,7 +43,9 @@ WORKLOADS = {
     "cfg3": ((128, 128, 16), 3, "j2"),
     "northstar_j2": ((128, 128, 16), 2, "j2"),
     "cfg3_neo": ((128, 128, 16), 3, "neohookean"),
-    # the reference's other materials (general kernels, dual-number tangents): measured for DESIGN.md only
+    "cfg3_small": ((32, 32, 16), 3, "j2"),
+    "cfg4_domain": ((96, 96, 12), 2, "neohookean"),
+    # the reference's other materials (tangent-record route): measured for DESIGN.md only
     "cfg2_stvk": ((64, 64, 8), 2, "stvk"),
     "cfg2_j2linear": ((64, 64, 8), 2, "j2linear"),
     "cfg2_j2simo": ((64, 64, 8), 2, "j2simo"),
@@ -43,44 +55,53 @@ WORKLOADS = {
     "northstar_zfirst": ((16, 128, 128), 2, "neohookean"),
 }
 
-# algorithmic bytes / flops per element integration
-def b_alg(dim, p, grad=True, j2=False):
+
+# algorithmic bytes per element integration
+def b_alg(dim, p, grad=True, stateful=False):
     n_dof = (p + 1) ** dim
     n_tdof = n_dof * dim
     n_q = (p + 2) ** dim
     b = 8 * n_tdof + 8 * n_tdof + 4 * n_dof + 8 * n_q * (dim * dim + 1)
     if grad:
         b += 8 * n_tdof * n_tdof
-    if j2:
-        b += 8 * 11 * n_q
+    if stateful:
+        b += 8 * 11 * n_q        # J2 family: 11 state doubles per point
     return b
 
 
-def measured_traffic(workload, world, grad, material):
-    """HBM bytes per step from the committed rocprofv3 PMC passes (profiles/r01_traffic.json: FETCH_SIZE and
-    WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes, calibrated for this
-    kernel's 8-byte accesses by scratch/fetch_calib.hip).  None when no measurement exists for this case."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            t = json.load(f)
-    except OSError:
-        return None
+def kernel_sources_sha():
+    """hash of the kernel sources: recorded PMC numbers are quoted only for the kernels they were measured on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mimi_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_pmc(workload, world, grad, material):
+    """HBM bytes per step and fp64-pipe occupancy from the committed rocprofv3 PMC passes (profiles/*_traffic.json:
+    FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes, calibrated for this
+    kernel's 8-byte accesses by scratch/fetch_calib.hip).  bench.py cannot run the profiler on itself, so these are
+    RECORDED numbers: returned with their source, and dropped (None) when the kernel sources changed since."""
     key = f"{workload}/{material}/{'grad' if grad else 'residual'}/n{world}"
-    return t.get(key, {}).get("bytes_per_step")
-
-
-def measured_traffic_per_kernel(workload, world, grad, material):
-    """(phase 1 bytes, phase 2 bytes) of the same PMC passes, or None"""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            t = json.load(f).get(f"{workload}/{material}/{'grad' if grad else 'residual'}/n{world}")
-        f2 = sum(v for k, v in t["fetch_size_kb_raw"].items() if "p2" in k)
-        w2 = sum(v for k, v in t["write_size_kb"].items() if "p2" in k)
-        f1 = sum(t["fetch_size_kb_raw"].values()) - f2
-        w1 = sum(t["write_size_kb"].values()) - w2
-        return (2 * f1 + w1) * 1024, (2 * f2 + w2) * 1024
-    except (OSError, TypeError, KeyError, AttributeError):
-        return None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f).get(key)
+        except OSError:
+            continue
+        if not t:
+            continue
+        current = kernel_sources_sha()
+        fresh = t.get("kernel_sources_sha") == current
+        return dict(bytes_per_step=t.get("bytes_per_step") if fresh else None,
+                    fp64_pipe_busy_frac=t.get("fp64_pipe_busy_frac") if fresh else None,
+                    traffic_source=f"profiles/{name} ({t.get('source', 'rocprofv3 --pmc')})",
+                    recorded_for_kernel_sources_sha=t.get("kernel_sources_sha"), current_kernel_sources_sha=current,
+                    stale=not fresh)
+    return None
 
 
 def make_material(kind):
@@ -120,6 +141,23 @@ def synthetic_u(patch, scale=0.05, seed=20241008):
     return u
 
 
+def kernel_description(p, material, path):
+    if path != 1:
+        return "general-table kernels: domain_general_kernel (+ general_gather_kernel for 64-node elements)"
+    if p == 3:
+        return ("tp3_point_kernel (material + tangent record + residual pieces) + tp3_contract_kernel (sum-factorised "
+                "contraction on v_mfma_f64_16x16x4, one wave per element column x (i, j)) = phase 1; tp3_gather_kernel "
+                "(row gather) = phase 2")
+    if material == "neohookean":
+        return "tensor_wgsym_kernel (integration, symmetric half) = phase 1; tensor_p2_kernel (row gather) = phase 2"
+    if material == "j2":
+        return "tensor_point_kernel (return mapping) + tensor_wgs_kernel (nine-block integration) = phase 1; tensor_p2_kernel = phase 2"
+    return "tensor_point_kernel (material + tangent record) + tensor_wgs_kernel = phase 1; tensor_p2_kernel = phase 2"
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline
+# ------------------------------------------------------------------------------------------------
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -131,89 +169,171 @@ def _cpu_model():
     return "unknown CPU"
 
 
-def cpu_baseline(p, material, seconds_hint=12.0):
-    """The restated reference CPU path (oracle/ref_path.c: forward-FD element Jacobian,
-    per-thread full-size arrays + reduction pass, OpenMP) on a bounded sample of the workload."""
-    from oracle import iga, ref_path as rp
-    n_el = (32, 32, 8)
-    threads = min(os.cpu_count() or 1, 32)
-    P = iga.Patch.block(n_el, p)
+def physical_cores():
+    """(usable cores, description): distinct (socket, core) pairs of /proc/cpuinfo, clipped to the CPUs this process may
+    run on (affinity mask) and to the cgroup CPU quota -- more OpenMP threads than that only get throttled"""
+    pairs = set()
+    try:
+        with open("/proc/cpuinfo") as f:
+            phys = core = None
+            for line in f:
+                key = line.split(":")[0].strip()
+                if key == "physical id":
+                    phys = line.split(":")[1].strip()
+                elif key == "core id":
+                    core = line.split(":")[1].strip()
+                    pairs.add((phys, core))
+    except OSError:
+        pass
+    physical = len(pairs) or (os.cpu_count() or 1)
+    n, why = physical, f"{physical} physical cores"
+    try:
+        aff = len(os.sched_getaffinity(0))
+        if aff < n:
+            n, why = aff, f"affinity mask of {aff} CPUs ({physical} physical cores)"
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period)))
+            if q < n:
+                n, why = q, f"cgroup CPU quota of {q} CPUs ({physical} physical cores on the host)"
+    except (OSError, ValueError):
+        pass
+    return max(1, n), why
+
+
+def _oracle_material(material):
+    from oracle import ref_path as rp
     if material in ("neohookean", "stvk"):
-        mat = rp.make_material(material, 2100, 0.3)
-    elif material == "j2linear":
-        mat = rp.make_material("j2linear", 2100, 0.3, isotropic_hardening=40.0, kinematic_hardening=25.0, sigma_y=70.0)
-    else:
-        mat = rp.make_material(material, 2100, 0.3, hardening=dict(kind="JohnsonCookTempRate", A=70, B=140, n=0.2835,
-                               m=1.3558, eps0_dot=0.004, reference_temperature=20),
-                               specific_heat=450, initial_temperature=20, melting_temperature=1500)
-    D = rp.DomainOracle(P, mat, n_threads=threads)
+        return rp.make_material(material, 2100, 0.3)
+    if material == "j2linear":
+        return rp.make_material("j2linear", 2100, 0.3, isotropic_hardening=40.0, kinematic_hardening=25.0, sigma_y=70.0)
+    return rp.make_material(material, 2100, 0.3, hardening=dict(kind="JohnsonCookTempRate", A=70, B=140, n=0.2835,
+                            m=1.3558, eps0_dot=0.004, reference_temperature=20),
+                            specific_heat=450, initial_temperature=20, melting_temperature=1500)
+
+
+def _median_time(fn, warmup, calls, budget_s):
+    for _ in range(warmup):
+        fn()
+    ts = []
+    t_begin = time.perf_counter()
+    while len(ts) < calls and (len(ts) < 3 or time.perf_counter() - t_begin < budget_s):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), len(ts)
+
+
+def cpu_baseline(p, material, threads=None, n_el=None, sweep=False):
+    """The restated reference CPU path (oracle/ref_path.c: forward-FD element Jacobian, virtual-call-free material per
+    point, contiguous element chunk per thread, per-thread full-size arrays zeroed per call + reduction pass, OpenMP) on
+    a bounded sample of the workload, by BASELINE.md 2's protocol: threads = physical cores, OMP_PROC_BIND=close,
+    3 warm-up + >= 10 timed assemblies, median."""
+    from oracle import iga, ref_path as rp
+    n_el = tuple(n_el) if n_el else ((64, 64, 8) if p == 2 else (32, 32, 8))
+    cores, cores_why = physical_cores()
+    threads = threads or cores
+    P = iga.Patch.block(n_el, p)
+    D = rp.DomainOracle(P, _oracle_material(material), n_threads=threads)
     D.set_dt(0.5)
     rng = np.random.default_rng(20241008)
     u = 0.05 * rng.standard_normal(P.n_vdofs)
     u.reshape(-1, 3)[P.boundary_nodes(0, 0)] = 0.0
     r = np.zeros(P.n_vdofs)
     A = np.zeros(D.nnz)
-    D.add_domain_residual_and_grad(u, 1.0, r, A, rp.TANGENT_FD)          # warm-up (page faults)
-    reps, t_total = 0, 0.0
-    while t_total < seconds_hint and reps < 64:      # about 12 s of CPU work
-        t0 = time.perf_counter()
-        D.add_domain_residual_and_grad(u, 1.0, r, A, rp.TANGENT_FD)
-        t_total += time.perf_counter() - t0
-        reps += 1
-    # SURVEY 8d: the same path with an ANALYTIC element tangent, so that the GPU/CPU ratio is not credited with the
-    # FD -> analytic change of algorithm (a few seconds more)
-    D.add_domain_residual_and_grad(u, 1.0, r, A, rp.TANGENT_EXACT)
-    reps_a, t_a = 0, 0.0
-    while t_a < 4.0 and reps_a < 256:
-        t0 = time.perf_counter()
-        D.add_domain_residual_and_grad(u, 1.0, r, A, rp.TANGENT_EXACT)
-        t_a += time.perf_counter() - t0
-        reps_a += 1
-    return dict(value=P.n_el * reps / t_total, unit="element-integrations/s", cores=threads, kind="port",
-                sample=f"{'x'.join(map(str, n_el))} p={p} {material} block ({P.n_el} elements), {reps} residual+Jacobian "
-                       f"assemblies, reference forward-FD element Jacobian, OpenMP {threads} threads "
-                       f"(host has {os.cpu_count()} logical cores, {_cpu_model()})",
-                analytic_tangent_value=P.n_el * reps_a / t_a,
-                analytic_tangent_note="same restated path and threads with the oracle's analytic element tangent instead of "
-                                      "the reference's forward differences")
+    # per-thread arrays of the reference design: threads x (n_vdofs + nnz) doubles
+    tl_gb = threads * (P.n_vdofs + D.nnz) * 8 / 1e9
+
+    def timed(mode, nt, budget):
+        D.n_threads = nt
+        return _median_time(lambda: D.add_domain_residual_and_grad(u, 1.0, r, A, mode), 3, 10, budget)
+
+    t_fd, n_fd = timed(rp.TANGENT_FD, threads, 20.0)
+    t_ex, n_ex = timed(rp.TANGENT_EXACT, threads, 8.0)
+    t_none, _ = timed(rp.TANGENT_NONE, threads, 3.0)
+    out = dict(value=P.n_el / t_fd, unit="element-integrations/s", cores=threads, kind="port",
+               sample=f"{'x'.join(map(str, n_el))} p={p} {material} block ({P.n_el} elements, nnz {D.nnz}), median of {n_fd} "
+                      f"residual+Jacobian assemblies after 3 warm-up calls, reference forward-FD element Jacobian, OpenMP "
+                      f"{threads} threads = {cores_why}, OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} "
+                      f"(host: {os.cpu_count()} logical CPUs, {_cpu_model()}); per-thread arrays "
+                      f"{tl_gb:.1f} GB in all",
+               seconds_per_assembly=t_fd,
+               analytic_tangent_value=P.n_el / t_ex,
+               analytic_tangent_note=f"same restated path and threads with the oracle's analytic element tangent instead of the "
+                                     f"reference's forward differences (median of {n_ex})",
+               zero_and_reduce_seconds=t_none,
+               zero_and_reduce_note="the same call with no elements: zeroing the per-thread n_vdofs + nnz arrays and the "
+                                    "reduction pass over all of them (nonlinear_solid.cpp:117-121, nonlinear_base.hpp:112-151) "
+                                    "-- the part of an assembly that grows with the thread count")
+    if sweep:
+        out["thread_sweep"] = {}
+        for nt in sorted({1, 4, 8, 16, 32, 64, 128, threads}):
+            if nt > (os.cpu_count() or 1):
+                continue
+            if nt == 1 and P.n_el > 4096:
+                continue                      # one thread on the full sample takes minutes: see the small-sample sweep
+            tf, _ = timed(rp.TANGENT_FD, nt, 12.0)
+            te, _ = timed(rp.TANGENT_EXACT, nt, 6.0)
+            tn, _ = timed(rp.TANGENT_NONE, nt, 2.0)
+            out["thread_sweep"][str(nt)] = dict(fd=P.n_el / tf, analytic=P.n_el / te, zero_and_reduce_seconds=tn)
+    rp.lib().oracle_release_thread_local()
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=os.environ.get("MIMI_BENCH_WORKLOAD", "northstar"), choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--residual-only", action="store_true", help="time AddDomainResidual instead (not the headline metric)")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------
+# rank launcher
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
+
+def launch_ranks(args):
+    """--gpus N without a launcher: N fresh processes, started before anything in this one touches a GPU."""
+    import torch
+    backend = os.environ.get("MIMI_BENCH_BACKEND", "nccl")
+    visible = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    if backend == "nccl" and visible < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this box shows {visible}; "
+                         f"(MIMI_BENCH_BACKEND=gloo rehearses the N-rank code path on fewer GPUs, timings meaningless)\n")
+        return 2
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for rank in range(args.gpus):
+        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in out0.decode().splitlines():      # (gloo greets on stdout: keep stdout to the one JSON line)
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
+    if any(codes):
+        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------
+def measure(args, workload, rank, world, local_rank, backend, with_extras):
+    """time `args.steps` assemblies of one workload on this rank's slab; returns the result dict (rank 0) or None"""
     import torch
     import torch.distributed as dist
     import mimi_amd
     from mimi_amd.integrators import CSRPattern, NonlinearSolid
     from mimi_amd import parallel
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # MIMI_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (interface rows are
-    # staged through the host, ranks share the visible GPUs); the measured configuration is "nccl" = RCCL
-    backend = os.environ.get("MIMI_BENCH_BACKEND", "nccl")
-    if backend == "gloo":
-        local_rank %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
-    n_el, p, material = WORKLOADS[args.workload]
+    n_el, p, material = WORKLOADS[workload]
     patch = mimi_amd.BSplinePatch.block(n_el, p)
     pattern = CSRPattern.of_bspline_patch(patch, device=local_rank, on_device=True)
     shard = parallel.SlabShard(patch, pattern, rank, world)
@@ -259,16 +379,17 @@ def main():
                 if exchange:
                     exchange.sum_residual_and_grad()
 
-    for _ in range(args.warmup):
+    steps, warmup = args.steps, args.warmup
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     ev[0].record(stream)
-    for k in range(args.steps):
+    for k in range(steps):
         step()
         ev[k + 1].record(stream)
     torch.cuda.synchronize()
@@ -282,92 +403,202 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]))
-    # "also reported per full Newton iteration (= 1 x (R+J) + 2 x (R) assemblies, newton.cpp:142-190)":
-    # the residual-only assembly is timed AFTER the timed region above (N = 1 only; informational)
-    # per-kernel durations, live: events inside the library around phase 1 and phase 2 (after the timed region)
-    phase_ms = None
-    if world == 1 and not args.residual_only and integ.path_ == 1:
-        integ.SetPhaseTiming(True)
-        acc1 = acc2 = 0.0
-        for _ in range(5):
-            integ.AddDomainResidualAndGrad(u, 1.0, r, A)
-            a1, a2 = integ.PhaseMs()
-            acc1 += a1
-            acc2 += a2
-        integ.SetPhaseTiming(False)
-        phase_ms = (acc1 / 5, acc2 / 5)
-    residual_ms = None
-    if world == 1 and not args.residual_only:
+    kernel_ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(steps)]))
+
+    # --check (N > 1): the rows this rank owns after the exchange against a whole-patch assembly on this rank's GPU
+    check = None
+    if args.check and world > 1 and not args.residual_only:
+        r.zero_()
+        A.zero_()
+        step()
+        torch.cuda.synchronize()
+        whole = make_integrator(None)
+        r_w = torch.zeros_like(r)
+        A_w = torch.zeros_like(A)
+        whole.AddDomainResidualAndGrad(u, 1.0, r_w, A_w)
+        whole.Synchronize()
+        torch.cuda.synchronize()
+        planes = torch.tensor(exchange.owned_node_planes(), device=dev)
+        mi_axis = torch.from_numpy(patch.node_multi_index()[shard.axis]).to(dev)
+        nodes = torch.nonzero(torch.isin(mi_axis, planes)).reshape(-1)
+        rows = (nodes[:, None] * 3 + torch.arange(3, device=dev)[None, :]).reshape(-1)
+        rowptr = pattern.rowptr if isinstance(pattern.rowptr, torch.Tensor) else torch.from_numpy(np.asarray(pattern.rowptr)).to(dev)
+        rowptr = rowptr.to(dev)
+        er = float((r[rows] - r_w[rows]).abs().max() / r_w.abs().max())
+        start, stop = rowptr[rows], rowptr[rows + 1]
+        # owned rows are whole node planes: compare row by row through a mask over the value array
+        mask = torch.zeros(pattern.nnz + 1, dtype=torch.int32, device=dev)
+        mask.index_add_(0, start, torch.ones_like(start, dtype=torch.int32))
+        mask.index_add_(0, stop, -torch.ones_like(stop, dtype=torch.int32))
+        owned = torch.cumsum(mask[:-1], 0) > 0
+        eA = float(((A - A_w).abs() * owned).max() / A_w.abs().max())
+        errs = torch.tensor([er, eA], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(errs, op=dist.ReduceOp.MAX)
+        check = dict(residual_rel_err=float(errs[0]), tangent_rel_err=float(errs[1]),
+                     what="owned rows of every rank after the exchange vs a whole-patch assembly on the same GPU (max over ranks)")
+        del whole, r_w, A_w
+
+    phase_ms = residual_ms = None
+    if with_extras and world == 1 and not args.residual_only:
+        # per-kernel durations, live: events inside the library around phase 1 and phase 2 (after the timed region)
+        if integ.path_ == 1:
+            integ.SetPhaseTiming(True)
+            acc1 = acc2 = 0.0
+            for _ in range(5):
+                integ.AddDomainResidualAndGrad(u, 1.0, r, A)
+                a1, a2 = integ.PhaseMs()
+                acc1 += a1
+                acc2 += a2
+            integ.SetPhaseTiming(False)
+            phase_ms = (acc1 / 5, acc2 / 5)
+        # "also reported per full Newton iteration (= 1 x (R+J) + 2 x (R) assemblies, newton.cpp:142-190)"
         for _ in range(3):
             integ.AddDomainResidual(u, r)
         integ.Synchronize()
         t1 = time.perf_counter()
-        for _ in range(20):
+        for _ in range(10):
             integ.AddDomainResidual(u, r)
         integ.Synchronize()
-        residual_ms = (time.perf_counter() - t1) / 20 * 1e3
+        residual_ms = (time.perf_counter() - t1) / 10 * 1e3
 
+    result = None
     if rank == 0:
         n_elements = patch.n_elements
-        value = n_elements * args.steps / elapsed
-        balg = b_alg(patch.dim, p, grad=not args.residual_only, j2=(material == "j2"))
+        grad = not args.residual_only
+        stateful = material not in ("neohookean", "stvk")
+        balg = b_alg(patch.dim, p, grad=grad, stateful=stateful)
         local_elements = integ.n_elements_ + sum(g.n_elements_ for g in boundary)
         achieved = balg * local_elements / (kernel_ms * 1e-3) / 1e9
+        pmc = recorded_pmc(workload, world, grad, material)
+        result = dict(
+            value=n_elements * steps / elapsed, ms_per_step=elapsed / steps * 1e3, n_elements=n_elements,
+            config={"workload": f"{'x'.join(map(str, n_el))} p={p} {material} B-spline block, "
+                                f"{n_elements} elements, n_q={(p + 2) ** patch.dim}, nnz={pattern.nnz}",
+                    "name": workload,
+                    "parallelism": f"element slabs x{world}" + (", interface rows summed on their owner rank" if world > 1 else "")
+                                   + (", exchange overlapped with the interior elements" if boundary else ""),
+                    "kernel_path": "tensor" if integ.path_ == 1 else "general",
+                    "u": "0.05*N(0,1), seed 20241008, face x=0 clamped"},
+            roofline={"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                      "traffic": pmc["bytes_per_step"] if pmc else None,
+                      "traffic_source": None if not pmc else {k: pmc[k] for k in ("traffic_source", "recorded_for_kernel_sources_sha",
+                                                                                   "current_kernel_sources_sha", "stale")},
+                      "kernel": "one step = " + kernel_description(p, material, integ.path_) + "; avg_launch_ms is their sum on "
+                                "rank 0, measured with events on the launch stream",
+                      "algorithmic_bytes_per_element": balg, "elements_per_launch": local_elements,
+                      "avg_launch_ms": kernel_ms,
+                      "phase_ms": None if phase_ms is None else
+                      {"phase1_integration_kernels": phase_ms[0], "phase2_row_gather": phase_ms[1],
+                       "how": "HIP events recorded by the library on the launch stream around the kernels of each phase, "
+                              "mean of 5 assemblies after the timed region"}},
+            check=check)
+        if pmc and pmc.get("fp64_pipe_busy_frac") is not None:
+            result["fp64_pipe"] = {"busy_frac": pmc["fp64_pipe_busy_frac"], "source": pmc["traffic_source"],
+                                   "note": "issued fp64 matrix + vector instruction cycles over the kernel's cycles (PMC), "
+                                           "phase 1; recorded, not live"}
+        if residual_ms is not None:
+            rj = elapsed / steps * 1e3
+            result["per_newton_iteration"] = {"ms": rj + 2.0 * residual_ms, "residual_only_ms": residual_ms,
+                                              "composition": "1 x (residual+Jacobian) + 2 x (residual) assemblies, the line search "
+                                                             "of solvers/newton.cpp:142-190"}
+    # release this workload's device memory before the next one
+    del integ, boundary, exchange, u, r, A, pattern
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    return result
+
+
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # MIMI_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (interface rows are
+    # staged through the host, ranks share the visible GPUs); the measured configuration is "nccl" = RCCL
+    backend = os.environ.get("MIMI_BENCH_BACKEND", "nccl")
+    n_visible = torch.cuda.device_count()
+    if backend == "gloo":
+        local_rank %= max(n_visible, 1)
+    elif local_rank >= n_visible:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_visible} GPUs are visible")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    comm_ranks = 1
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        # one sum over the communicator before anything is timed: every rank is there and the transport works
+        ones = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        comm_ranks = int(ones.item())
+        if comm_ranks != world:
+            raise SystemExit(f"communicator sums to {comm_ranks} ranks, expected {world}")
+
+    main = measure(args, args.workload, rank, world, local_rank, backend, with_extras=True)
+    other = {}
+    if world == 1 and not args.residual_only and not args.no_other_configs and args.workload == "northstar":
+        # BASELINE configuration 3 in the same run (fewer steps: 45 ms each), so that its figure is measured, not copied
+        saved = (args.steps, args.warmup)
+        args.steps, args.warmup = min(args.steps, 5), min(args.warmup, 2)
+        try:
+            c3 = measure(args, "cfg3", rank, world, local_rank, backend, with_extras=True)
+            other["cfg3"] = {k: c3[k] for k in ("value", "ms_per_step", "config", "per_newton_iteration")}
+            other["cfg3"]["steps"] = args.steps
+            other["cfg3"]["roofline"] = {k: c3["roofline"][k] for k in ("achieved", "frac", "algorithmic_bytes_per_element", "phase_ms", "kernel")}
+        except Exception as exc:        # (e.g. a smaller GPU: the scratch of cfg3 needs about 70 GB)
+            other["cfg3"] = {"error": str(exc)}
+        args.steps, args.warmup = saved
+
+    if rank == 0:
         out = {
             "metric": "element-integrations/sec (residual+Jacobian assembly)" if not args.residual_only
                       else "element-integrations/sec (residual-only assembly)",
-            "value": value, "unit": "element-integrations/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "value": main["value"], "unit": "element-integrations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": main["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{'x'.join(map(str, n_el))} p={p} {material} B-spline block, "
-                                   f"{n_elements} elements, n_q={(p + 2) ** patch.dim}, nnz={pattern.nnz}",
-                       "name": args.workload,
-                       "parallelism": f"element slabs x{world}" + (", interface rows summed on their owner rank" if world > 1 else "")
-                                      + (", exchange overlapped with the interior elements" if boundary else ""),
-                       "kernel_path": "tensor" if integ.path_ == 1 else "general",
-                       "u": "0.05*N(0,1), seed 20241008, face x=0 clamped"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0,
-                         "traffic": measured_traffic(args.workload, world, not args.residual_only, material),
-                         "kernel": "one step = tensor_wgsym_kernel (neo-Hookean; J2: tensor_point_kernel + tensor_wgs_kernel) "
-                                   "(integration, phase 1) + tensor_p2_kernel (row gather, phase 2) on rank 0; "
-                                   "avg_launch_ms is their sum, measured with events on the launch stream",
-                         "algorithmic_bytes_per_element": balg, "elements_per_launch": local_elements,
-                         "avg_launch_ms": kernel_ms,
-                         "phase_ms": None if phase_ms is None else
-                         {"phase1_integration_kernels": phase_ms[0], "phase2_row_gather": phase_ms[1],
-                          **({} if measured_traffic_per_kernel(args.workload, world, True, material) is None else
-                             {"phase1_hbm_GB_per_s": measured_traffic_per_kernel(args.workload, world, True, material)[0] / phase_ms[0] / 1e6,
-                              "phase2_hbm_GB_per_s": measured_traffic_per_kernel(args.workload, world, True, material)[1] / phase_ms[1] / 1e6}),
-                          "how": "HIP events recorded by the library on the launch stream around the kernels of each phase, "
-                                 "mean of 5 assemblies after the timed region; phase 1 is fp64-pipe-bound, phase 2 HBM-bound "
-                                 "(DESIGN.md 4.1)"}},
+            "config": main["config"], "roofline": main["roofline"],
+            "communicator": {"backend": "rccl (torch.distributed nccl)" if backend == "nccl" else backend, "ranks": comm_ranks},
         }
-        if not args.residual_only and patch.dim == 3:
-            # second view of the same step (the tangent contraction is fp64-matrix-bound before it is HBM-bound):
-            # the ALGORITHMIC flops of the dense B^T A B form (no symmetry, no sum factorisation) over the step time.  The
-            # kernels execute several times fewer (sum factorisation; symmetric half for hyperelastic materials), so this
-            # ratio may exceed 1 -- it says how far the step is below the 9.7 ms the dense form needs at the matrix peak.
-            n_dof, n_q = (p + 1) ** 3, (p + 2) ** 3
-            f_alg = n_q * (4 * n_dof * 9 + 200 + 2 * (n_dof * 81 + (3 * n_dof) ** 2 * 3))
-            tf = f_alg * local_elements / (kernel_ms * 1e-3) / 1e12
-            out["roofline_fp64"] = {"bound": "mfma", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6,
-                                    "algorithmic_flops_per_element": f_alg,
-                                    "note": "dense-form flops of SURVEY 8d over the same step time; the kernels execute fewer "
-                                            "(sum factorisation, symmetric half): see DESIGN.md 4.1 for the issued fp64 work"}
-        if residual_ms is not None:
-            rj = elapsed / args.steps * 1e3
-            out["per_newton_iteration"] = {"ms": rj + 2.0 * residual_ms, "residual_only_ms": residual_ms,
-                                           "composition": "1 x (residual+Jacobian) + 2 x (residual) assemblies, the line search of "
-                                                          "solvers/newton.cpp:142-190"}
+        for k in ("fp64_pipe", "per_newton_iteration", "check"):
+            if main.get(k) is not None:
+                out[k] = main[k]
+        if other:
+            out["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(p, material)
+            _, p, material = WORKLOADS[args.workload]
+            out["cpu_baseline"] = cpu_baseline(p, material, sweep=args.cpu_sweep)
+            out["cpu_baseline"]["gpu_over_cpu"] = main["value"] / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("MIMI_BENCH_WORKLOAD", "northstar"), choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sweep", action="store_true", help="add a 1/32/64/128-thread sweep of the CPU baseline (minutes)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg3 measurement that follows the north-star one at N = 1")
+    ap.add_argument("--check", action="store_true", help="N > 1: compare the owned rows with a whole-patch assembly after the timed region")
+    ap.add_argument("--residual-only", action="store_true", help="time AddDomainResidual instead (not the headline metric)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -35,7 +35,7 @@
 enum { MAT_NEOHOOKEAN = 0, MAT_J2 = 1, MAT_STVK = 2, MAT_J2LINEAR = 3, MAT_J2SIMO = 4, MAT_J2LOG = 5 };
 enum { HARD_POWERLAW = 0, HARD_VOCE = 1, HARD_JC = 2, HARD_JC_RATE = 3, HARD_JC_TEMP_RATE = 4,
        HARD_JC_CONST_TEMP = 5 };
-enum { TANGENT_FD = 0, TANGENT_EXACT = 1 };
+enum { TANGENT_FD = 0, TANGENT_EXACT = 1, TANGENT_NONE = 2 };   /* NONE: no elements, only the zeroing + reduction passes (timing probe) */
 
 typedef struct {
   int kind;
@@ -957,13 +957,34 @@ int oracle_element_residual_and_grad(const oracle_domain* D, int e, const double
   return element_residual_and_grad_exact(D, e, x_e, R_e, K_e);
 }
 
+/* The reference keeps its per-thread arrays in work_data_ (integrator_utils.hpp:49-50): mfem::Vector::SetSize in
+ * nonlinear_solid.cpp:117-121 allocates on the first call only, later calls just zero them.  Same here: grow-only
+ * buffers, so that a timed call pays the zeroing and the reduction but not the page faults of a fresh allocation. */
+static double* tl_buffer(double** slot, size_t* have, size_t need) {
+  if (need > *have) {
+    free(*slot);
+    *slot = (double*)malloc(sizeof(double) * need);
+    *have = *slot ? need : 0;
+  }
+  return *slot;
+}
+static double* g_tlr = 0;
+static double* g_tlA = 0;
+static size_t g_tlr_n = 0, g_tlA_n = 0;
+void oracle_release_thread_local(void) {
+  free(g_tlr);
+  free(g_tlA);
+  g_tlr = g_tlA = 0;
+  g_tlr_n = g_tlA_n = 0;
+}
+
 /* nonlinear_solid.cpp:78-105 ThreadLocalResidual + nonlinear_base.hpp:90-107
  * AddThreadLocalResidual: per-thread full-size vectors, then a chunked reduction */
 int oracle_add_domain_residual(const oracle_domain* D, const double* u, double* r, int n_threads) {
   const int n_tdof = D->n_dof * D->dim;
   if (n_threads < 1) n_threads = 1;
   if (n_threads > D->n_el) n_threads = D->n_el;
-  double* tl = (double*)malloc(sizeof(double) * (size_t)n_threads * D->n_vdofs);
+  double* tl = tl_buffer(&g_tlr, &g_tlr_n, (size_t)n_threads * D->n_vdofs);
   if (!tl) return -1;
   int status = 0;
 #pragma omp parallel for num_threads(n_threads) reduction(| : status)
@@ -989,7 +1010,6 @@ int oracle_add_domain_residual(const oracle_domain* D, const double* u, double* 
       for (long j = b; j < en; ++j) r[j] += tr[j];
     }
   }
-  free(tl);
   return status;
 }
 
@@ -1002,13 +1022,9 @@ int oracle_add_domain_residual_and_grad(const oracle_domain* D, const double* u,
   const int n_tdof = D->n_dof * D->dim;
   if (n_threads < 1) n_threads = 1;
   if (n_threads > D->n_el) n_threads = D->n_el;
-  double* tlr = (double*)malloc(sizeof(double) * (size_t)n_threads * D->n_vdofs);
-  double* tlA = (double*)malloc(sizeof(double) * (size_t)n_threads * nnz);
-  if (!tlr || !tlA) {
-    free(tlr);
-    free(tlA);
-    return -1;
-  }
+  double* tlr = tl_buffer(&g_tlr, &g_tlr_n, (size_t)n_threads * D->n_vdofs);
+  double* tlA = tl_buffer(&g_tlA, &g_tlA_n, (size_t)n_threads * nnz);
+  if (!tlr || !tlA) return -1;
   int status = 0;
 #pragma omp parallel for num_threads(n_threads) reduction(| : status)
   for (int t = 0; t < n_threads; ++t) {
@@ -1020,6 +1036,7 @@ int oracle_add_domain_residual_and_grad(const oracle_domain* D, const double* u,
     memset(tA, 0, sizeof(double) * nnz);
     double x_e[MAX_TDOF], R_e[MAX_TDOF];
     double* K_e = (double*)malloc(sizeof(double) * n_tdof * n_tdof);
+    if (mode == TANGENT_NONE) en = b;   /* timing probe: the zeroing and the reduction pass alone */
     for (long e = b; e < en; ++e) {
       const int* vd = D->v_dofs + e * n_tdof;
       for (int k = 0; k < n_tdof; ++k) x_e[k] = u[vd[k]];
@@ -1045,8 +1062,6 @@ int oracle_add_domain_residual_and_grad(const oracle_domain* D, const double* u,
       for (long j = gb; j < ge; ++j) A[j] += grad_factor * tA[j];
     }
   }
-  free(tlr);
-  free(tlA);
   return status;
 }
 

@@ -19,7 +19,7 @@ MAT_NEOHOOKEAN, MAT_J2, MAT_STVK, MAT_J2LINEAR, MAT_J2SIMO, MAT_J2LOG = 0, 1, 2,
 MAT_KINDS = dict(neohookean=0, j2=1, stvk=2, j2linear=3, j2simo=4, j2log=5)
 HARD = dict(PowerLaw=0, Voce=1, JohnsonCook=2, JohnsonCookRate=3, JohnsonCookTempRate=4,
             JohnsonCookConstTemp=5)
-TANGENT_FD, TANGENT_EXACT = 0, 1
+TANGENT_FD, TANGENT_EXACT, TANGENT_NONE = 0, 1, 2   # NONE: timing probe, zeroing + reduction passes only
 
 
 def build(force=False):
