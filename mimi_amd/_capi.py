@@ -79,6 +79,17 @@ EXPORTS = [
 ]
 
 
+def _header_abi_version():
+    try:
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "mimi_hip.h")) as f:
+            for line in f:
+                if line.startswith("#define MIMI_HIP_ABI_VERSION"):
+                    return int(line.split()[2])
+    except OSError:
+        pass
+    return None
+
+
 def library_path():
     return _build.LIB
 
@@ -89,6 +100,9 @@ def lib():
     if _lib is not None:
         return _lib
     path = _build.LIB
+    import shutil
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+        _build.build()          # no-op unless a source or the header is newer than the library
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: run `python -m mimi_amd.build` (hipcc --offload-arch=gfx950). "
@@ -102,6 +116,10 @@ def lib():
     except Exception:
         pass
     L = C.CDLL(path)
+    expected = _header_abi_version()
+    if expected is not None and L.mimi_hip_abi_version() != expected:
+        raise RuntimeError(f"{path} has ABI version {L.mimi_hip_abi_version()}, include/mimi_hip.h declares {expected}: "
+                           "rebuild with `python -m mimi_amd.build`")
     L.mimi_hip_last_error.restype = C.c_char_p
     L.mimi_hip_domain_info.restype = C.c_int64
     L.mimi_hip_domain_info.argtypes = [C.c_void_p, C.c_int]
@@ -156,16 +174,37 @@ def check(status):
         raise RuntimeError(lib().mimi_hip_last_error().decode())
 
 
-def ptr(x):
-    """void* of a numpy array (host) or a torch tensor (host or device) or None."""
+def ptr(x, dtype=None):
+    """void* of a numpy array (host) or a torch tensor (host or device) or None.  dtype: what the C side reads
+    ("float64", "int32", "int64"); a buffer of another type raises instead of being reinterpreted."""
     if x is None:
         return None
     if isinstance(x, np.ndarray):
         assert x.flags.c_contiguous
+        if dtype is not None and x.dtype != np.dtype(dtype):
+            raise TypeError(f"expected a {dtype} array, got {x.dtype}")
         return x.ctypes.data_as(C.c_void_p)
     if hasattr(x, "data_ptr"):
         assert x.is_contiguous()
+        if dtype is not None and str(x.dtype).split(".")[-1] != dtype:
+            raise TypeError(f"expected a {dtype} tensor, got {x.dtype}")
         return C.c_void_p(x.data_ptr())
     if isinstance(x, int):
         return C.c_void_p(x)
     raise TypeError(type(x))
+
+
+def fptr(x):
+    """ptr() of a float64 buffer (u, r, CSR values)"""
+    return ptr(x, "float64")
+
+
+def torch_stream_of(*buffers):
+    """cuda_stream of torch's current stream on the device of the first CUDA tensor among `buffers`, else None: a handle
+    that was never given a stream launches on it, so that what torch enqueued on these tensors before the call (zero
+    fills, copies) is ordered before the kernels, and what it enqueues afterwards behind them."""
+    for b in buffers:
+        if b is not None and hasattr(b, "is_cuda") and b.is_cuda:
+            import torch
+            return torch.cuda.current_stream(b.device).cuda_stream
+    return None

@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import check, ptr
+from ._capi import check, fptr, ptr
 
 TANGENT_ANALYTIC = 0
 TANGENT_REFERENCE_FD = 1
@@ -107,8 +107,8 @@ class NonlinearSolid(NonlinearBase):
                 for i in range(3):
                     d.element_begin[i] = b[i]
                     d.element_end[i] = e[i]
-            d.csr_rowptr = ptr(self.pattern_.rowptr).value
-            d.csr_col = ptr(self.pattern_.col).value
+            d.csr_rowptr = ptr(self.pattern_.rowptr, "int64").value
+            d.csr_col = ptr(self.pattern_.col, "int32").value
             check(L.mimi_hip_domain_create_bspline(C.byref(d), C.byref(mat), self.device_, C.byref(h)))
         else:
             t = self.tables_
@@ -123,8 +123,8 @@ class NonlinearSolid(NonlinearBase):
             d.n_nodes = t["n_nodes"]
             assert g.shape == (d.n_elements, d.n_quad, d.dim, d.n_dof)
             d.dofs, d.dN_dX, d.weight_det = dofs.ctypes.data, g.ctypes.data, wd.ctypes.data
-            d.csr_rowptr = ptr(self.pattern_.rowptr).value
-            d.csr_col = ptr(self.pattern_.col).value
+            d.csr_rowptr = ptr(self.pattern_.rowptr, "int64").value
+            d.csr_col = ptr(self.pattern_.col, "int32").value
             check(L.mimi_hip_domain_create(C.byref(d), C.byref(mat), self.device_, C.byref(h)))
         self._h = h
         self.n_elements_ = int(L.mimi_hip_domain_info(h, 0))
@@ -150,7 +150,19 @@ class NonlinearSolid(NonlinearBase):
         check(_capi.lib().mimi_hip_domain_set_tangent_mode(self._handle(), mode))
 
     def SetStream(self, stream):
+        """launch on `stream` (a hipStream_t as an int); 0 / None: back to following torch's current stream for CUDA
+        tensors and the handle's own stream for host buffers"""
+        self._user_stream = bool(stream)
         check(_capi.lib().mimi_hip_domain_set_stream(self._handle(), C.c_void_p(stream) if stream else None))
+
+    def _follow_torch(self, *buffers):
+        # ordering with the caller's torch work (zero fills of r / A, copies of u): see _capi.torch_stream_of
+        if getattr(self, "_user_stream", False):
+            return
+        s = _capi.torch_stream_of(*buffers)
+        if s is not None or getattr(self, "_followed", None):
+            check(_capi.lib().mimi_hip_domain_set_stream(self._handle(), C.c_void_p(s) if s else None))
+            self._followed = s
 
     def Synchronize(self):
         check(_capi.lib().mimi_hip_domain_synchronize(self._handle()))
@@ -158,19 +170,22 @@ class NonlinearSolid(NonlinearBase):
     # -- nonlinear_solid.cpp:151-160 ---------------------------------------------------
     def AddDomainResidual(self, current_u, residual):
         self._push_dt()
-        check(_capi.lib().mimi_hip_domain_add_residual(self._handle(), ptr(current_u), ptr(residual)))
+        self._follow_torch(current_u, residual)
+        check(_capi.lib().mimi_hip_domain_add_residual(self._handle(), fptr(current_u), fptr(residual)))
 
     # -- nonlinear_solid.cpp:162-177 ---------------------------------------------------
     def AddDomainResidualAndGrad(self, current_u, grad_factor, residual, grad_values):
         self._push_dt()
-        check(_capi.lib().mimi_hip_domain_add_residual_and_grad(self._handle(), ptr(current_u), float(grad_factor),
-                                                                ptr(residual), ptr(grad_values)))
+        self._follow_torch(current_u, residual, grad_values)
+        check(_capi.lib().mimi_hip_domain_add_residual_and_grad(self._handle(), fptr(current_u), float(grad_factor),
+                                                                fptr(residual), fptr(grad_values)))
 
     # -- nonlinear_solid.cpp:179-199 ---------------------------------------------------
     def DomainPostTimeAdvance(self, converged_u):
         # the reference's material keeps the dt_ of the latest Add* call (nonlinear_solid.cpp:154,167)
         self._push_dt()
-        check(_capi.lib().mimi_hip_domain_post_time_advance(self._handle(), ptr(converged_u)))
+        self._follow_torch(converged_u)
+        check(_capi.lib().mimi_hip_domain_post_time_advance(self._handle(), fptr(converged_u)))
 
     def AddDomainGrad(self, current_u, grad):
         raise RuntimeError("Currently not implemented, use AddDomainResidualAndGrad")  # nonlinear_solid.hpp:108-113
@@ -368,8 +383,8 @@ class MortarContact(NonlinearBase):
             t.spline = C.cast(C.pointer(self._spline_struct), C.c_void_p)
             if hasattr(body, "_attached"):
                 body._attached.append(self)
-        t.csr_rowptr = ptr(self.pattern_.rowptr).value
-        t.csr_col = ptr(self.pattern_.col).value
+        t.csr_rowptr = ptr(self.pattern_.rowptr, "int64").value
+        t.csr_col = ptr(self.pattern_.col, "int32").value
         h = C.c_void_p()
         check(L.mimi_hip_contact_create(C.byref(t), self.device_, C.byref(h)))
         self._h = h
@@ -395,7 +410,8 @@ class MortarContact(NonlinearBase):
     # -- the two halves of an evaluation, for element slabs on several GPUs (mimi_amd/parallel.py ShardedContact) -----
     def GapArea(self, current_u):
         """pass 1 only: nodal area / gap of this handle's faces"""
-        check(_capi.lib().mimi_hip_contact_gap_area(self._handle(), ptr(current_u)))
+        self._follow_torch(current_u)
+        check(_capi.lib().mimi_hip_contact_gap_area(self._handle(), fptr(current_u)))
 
     def MarkedNodes(self):
         n = C.c_int64(0)
@@ -405,21 +421,33 @@ class MortarContact(NonlinearBase):
         return out
 
     def GetNodal(self, area, gap):
-        check(_capi.lib().mimi_hip_contact_nodal(self._handle(), 0, ptr(area), ptr(gap)))
+        self._follow_torch(area, gap)
+        check(_capi.lib().mimi_hip_contact_nodal(self._handle(), 0, fptr(area), fptr(gap)))
 
     def SetNodal(self, area, gap):
-        check(_capi.lib().mimi_hip_contact_nodal(self._handle(), 1, ptr(area), ptr(gap)))
+        self._follow_torch(area, gap)
+        check(_capi.lib().mimi_hip_contact_nodal(self._handle(), 1, fptr(area), fptr(gap)))
 
     def AddBoundaryResidualFromNodal(self, current_u, grad_factor, residual, grad=None):
         """pressure from the (summed) nodal area / gap, then pass 2"""
-        check(_capi.lib().mimi_hip_contact_add_residual_from_nodal(self._handle(), ptr(current_u), float(grad_factor),
-                                                                   ptr(residual), ptr(grad)))
+        self._follow_torch(current_u, residual, grad)
+        check(_capi.lib().mimi_hip_contact_add_residual_from_nodal(self._handle(), fptr(current_u), float(grad_factor),
+                                                                   fptr(residual), fptr(grad)))
 
     def SetTangentMode(self, mode):
         check(_capi.lib().mimi_hip_contact_set_tangent_mode(self._handle(), mode))
 
     def SetStream(self, stream):
+        self._user_stream = bool(stream)
         check(_capi.lib().mimi_hip_contact_set_stream(self._handle(), C.c_void_p(stream) if stream else None))
+
+    def _follow_torch(self, *buffers):
+        if getattr(self, "_user_stream", False):
+            return
+        s = _capi.torch_stream_of(*buffers)
+        if s is not None or getattr(self, "_followed", None):
+            check(_capi.lib().mimi_hip_contact_set_stream(self._handle(), C.c_void_p(s) if s else None))
+            self._followed = s
 
     def _history(self):
         out = np.zeros(5)
@@ -429,12 +457,14 @@ class MortarContact(NonlinearBase):
 
     # mortar_contact.cpp:297-351
     def AddBoundaryResidual(self, current_u, residual):
-        check(_capi.lib().mimi_hip_contact_add_residual(self._handle(), ptr(current_u), ptr(residual)))
+        self._follow_torch(current_u, residual)
+        check(_capi.lib().mimi_hip_contact_add_residual(self._handle(), fptr(current_u), fptr(residual)))
 
     # mortar_contact.cpp:353-421
     def AddBoundaryResidualAndGrad(self, current_u, grad_factor, residual, grad_values):
-        check(_capi.lib().mimi_hip_contact_add_residual_and_grad(self._handle(), ptr(current_u), float(grad_factor),
-                                                                 ptr(residual), ptr(grad_values)))
+        self._follow_torch(current_u, residual, grad_values)
+        check(_capi.lib().mimi_hip_contact_add_residual_and_grad(self._handle(), fptr(current_u), float(grad_factor),
+                                                                 fptr(residual), fptr(grad_values)))
 
     # mortar_contact.cpp:423-467
     def GapNorm(self, test_u, nthreads=-1):

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import check, ptr
+from ._capi import check, fptr, ptr
 
 
 class LinearSolver:
@@ -26,22 +26,35 @@ class LinearSolver:
         ess = np.ascontiguousarray(essential_dofs if essential_dofs is not None else np.zeros(0), dtype=np.int64)
         self._keep = (pattern.rowptr, pattern.col, ess)   # device arrays are used in place by the library
         h = C.c_void_p()
-        check(_capi.lib().mimi_hip_linear_create(self.n_, ptr(pattern.rowptr), ptr(pattern.col), ptr(ess) if ess.size else None,
+        check(_capi.lib().mimi_hip_linear_create(self.n_, ptr(pattern.rowptr, "int64"), ptr(pattern.col, "int32"),
+                                                 ptr(ess, "int64") if ess.size else None,
                                                  ess.size, device, C.byref(h)))
         self._h = h
         self.final_iter_, self.final_norm_, self.converged_ = 0, 0.0, False
 
     def SetStream(self, stream):
+        self._user_stream = bool(stream)
         check(_capi.lib().mimi_hip_linear_set_stream(self._h, C.c_void_p(stream) if stream else None))
+
+    def _follow_torch(self, *buffers):
+        # a handle that was never given a stream launches on torch's current stream when it gets CUDA tensors
+        if getattr(self, "_user_stream", False):
+            return
+        s = _capi.torch_stream_of(*buffers)
+        if s is not None or getattr(self, "_followed", None):
+            check(_capi.lib().mimi_hip_linear_set_stream(self._h, C.c_void_p(s) if s else None))
+            self._followed = s
 
     def Eliminate(self, r=None, A_values=None):
         """r[ess] = 0; A.EliminateRowCol(ess, DIAG_ONE)"""
-        check(_capi.lib().mimi_hip_linear_eliminate(self._h, ptr(r), ptr(A_values)))
+        self._follow_torch(r, A_values)
+        check(_capi.lib().mimi_hip_linear_eliminate(self._h, fptr(r), fptr(A_values)))
 
     def Mult(self, A_values, b, x):
         """x = A^-1 b to the configured tolerances (x is overwritten: iterative_mode false)"""
         it, conv, nrm = C.c_int32(0), C.c_int32(0), C.c_double(0.0)
-        check(_capi.lib().mimi_hip_linear_gmres(self._h, ptr(A_values), ptr(b), ptr(x), self.rel_tol, self.abs_tol,
+        self._follow_torch(A_values, b, x)
+        check(_capi.lib().mimi_hip_linear_gmres(self._h, fptr(A_values), fptr(b), fptr(x), self.rel_tol, self.abs_tol,
                                                 int(self.max_iter), int(self.kdim), 1 if self.use_jacobi else 0,
                                                 C.byref(it), C.byref(nrm), C.byref(conv)))
         self.final_iter_, self.final_norm_, self.converged_ = it.value, nrm.value, bool(conv.value)
@@ -51,7 +64,8 @@ class LinearSolver:
         """x = A^-1 b by preconditioned conjugate gradients: the mass solve of operators::NonlinearSolid
         (operators/nonlinear_solid.cpp:39-50,155)"""
         it, conv, nrm = C.c_int32(0), C.c_int32(0), C.c_double(0.0)
-        check(_capi.lib().mimi_hip_linear_cg(self._h, ptr(A_values), ptr(b), ptr(x), rel_tol, abs_tol, int(max_iter),
+        self._follow_torch(A_values, b, x)
+        check(_capi.lib().mimi_hip_linear_cg(self._h, fptr(A_values), fptr(b), fptr(x), rel_tol, abs_tol, int(max_iter),
                                              1 if self.use_jacobi else 0, C.byref(it), C.byref(nrm), C.byref(conv)))
         self.final_iter_, self.final_norm_, self.converged_ = it.value, nrm.value, bool(conv.value)
         return x

@@ -129,7 +129,10 @@ class DomainOracle:
     """integrators::NonlinearSolid restated (nonlinear_solid.{hpp,cpp}) over the
     tables of a Patch."""
 
-    def __init__(self, patch, material, quadrature_order=-1, n_threads=1, with_a_ids=True, elements=None):
+    def __init__(self, patch, material, quadrature_order=-1, n_threads=1, with_a_ids=True, elements=None, with_sparsity=True):
+        """elements: integrate only this subset (tables and state of those elements); with_sparsity=False: no CSR pattern at
+        all (element-level calls only: element_residual_and_grad) -- for sampled checks on meshes whose pattern is too big
+        to build on the host"""
         self.patch = patch
         self.n_threads = n_threads
         t = patch.tables(quadrature_order, elements=elements)
@@ -140,10 +143,14 @@ class DomainOracle:
         self.dN_dX = np.ascontiguousarray(np.transpose(t["dN_dX"], (0, 1, 3, 2)))
         self.weight = np.ascontiguousarray(t["weight"])
         self.det = np.ascontiguousarray(t["det"])
-        self.rowptr, self.col = patch.sparsity()
-        self.nnz = int(self.rowptr[-1])
+        if with_sparsity:
+            self.rowptr, self.col = patch.sparsity()
+            self.nnz = int(self.rowptr[-1])
+        else:
+            self.rowptr = self.col = None
+            self.nnz = 0
         self.a_ids = None
-        if with_a_ids:
+        if with_a_ids and with_sparsity:
             ids = patch.a_ids(self.rowptr, self.col)
             if elements is not None:
                 ids = ids[elements]

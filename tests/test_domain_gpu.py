@@ -415,3 +415,32 @@ def test_fallback_kernel_families(env):
            "-k", select]
     res = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_default_stream_follows_torch():
+    """No SetStream: with CUDA tensors the handle launches on torch's CURRENT stream, so torch's zero fills before the
+    call and torch's reads after it are ordered with the kernels without any explicit synchronisation."""
+    import torch
+    from oracle import ref_path as rp
+    P, D, G = make_pair((6, 5, 4), 2, None, "neohook", "bspline")
+    u = synthetic_u(P)
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
+    tu = torch.from_numpy(u).to(dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        tr = torch.full((P.n_vdofs,), 7.0, dtype=torch.float64, device=dev)
+        tA = torch.full((D.nnz,), 7.0, dtype=torch.float64, device=dev)
+        tr.zero_()
+        tA.zero_()
+        G.AddDomainResidualAndGrad(tu, 1.0, tr, tA)
+        r2 = tr * 2.0                      # torch work behind the kernels, same stream, no Synchronize() in between
+        A2 = tA * 2.0
+    side.synchronize()
+    r_o = np.zeros(P.n_vdofs)
+    A_o = np.zeros(D.nnz)
+    D.add_domain_residual_and_grad(u, 1.0, r_o, A_o, rp.TANGENT_EXACT)
+    assert relmax(r2.cpu().numpy(), 2 * r_o) < 1e-12
+    assert relmax(A2.cpu().numpy(), 2 * A_o) < 1e-11
+    with pytest.raises(TypeError):         # a float32 buffer is refused, not reinterpreted
+        G.AddDomainResidual(tu.float(), tr)

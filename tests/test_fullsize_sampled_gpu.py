@@ -1,0 +1,60 @@
+"""VALUES at BASELINE.json's full sizes: complete CSR rows and residual entries of sampled nodes, compared with the
+oracle.  The oracle cannot assemble these meshes in reasonable time, but it can integrate the <= (p+1)^3 elements around
+a node: for ~50 nodes (corners, edges, faces, interior, and the LAST rows of the matrix -- for configuration 5 those lie
+beyond 2^31 in the value array) it computes every element block exactly (oracle/ref_path.c element_residual_and_grad,
+exact tangent), tests/_sampling.py sums the rows of the sampled nodes out of them (that algebra is checked against the
+oracle's own whole assembly in tests/test_sampled_rows_cpu.py) and the rows are compared with the full GPU assembly.
+Bars as everywhere: residual 1e-12, tangent 1e-11 (relative to the largest sampled entry)."""
+import numpy as np
+import pytest
+
+from _sampling import SampledRows, sample_nodes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("workload,n_random", [("northstar", 24), ("cfg3", 4), ("cfg5", 24)])
+def test_sampled_rows_match_the_oracle(workload, n_random):
+    import torch
+    import bench
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    from oracle import iga
+    n_el, p, material = bench.WORKLOADS[workload]
+    dev = torch.device("cuda", 0)
+    patch = mimi_amd.BSplinePatch.block(n_el, p)
+    pattern = CSRPattern.of_bspline_patch(patch, on_device=True)
+    G = NonlinearSolid("domain", bench.make_material(material), pattern, patch=patch).Prepare()
+    G.dt_ = 0.5
+    assert G.path_ == 1
+    u_host = bench.synthetic_u(patch)
+    u = torch.from_numpy(u_host).to(dev)
+    r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
+    A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
+    G.AddDomainResidualAndGrad(u, 1.0, r, A)
+    G.Synchronize()
+
+    P = iga.Patch.block(n_el, p)
+    nodes = sample_nodes(P.n, n_random, seed=5)
+    S = SampledRows(P, bench._oracle_material(material), nodes, u_host)
+    rowptr = pattern.rowptr if isinstance(pattern.rowptr, torch.Tensor) else torch.from_numpy(np.asarray(pattern.rowptr))
+    col = pattern.col if isinstance(pattern.col, torch.Tensor) else torch.from_numpy(np.asarray(pattern.col))
+    scale_r = float(r.abs().max())
+    worst_r = worst_A = scale_A = 0.0
+    beyond_int32 = rows_checked = 0
+    for k, node in enumerate(S.node_ids):
+        for i in range(3):
+            row = node * 3 + i
+            lo, hi = int(rowptr[row]), int(rowptr[row + 1])
+            beyond_int32 += lo > 2 ** 31
+            exp, r_exp = S.row(k, i, col[lo:hi].cpu().numpy())
+            got = A[lo:hi].cpu().numpy()
+            scale_A = max(scale_A, float(np.abs(exp).max()))
+            worst_A = max(worst_A, float(np.abs(got - exp).max()))
+            worst_r = max(worst_r, abs(float(r[row]) - r_exp))
+            rows_checked += 1
+    assert rows_checked >= 3 * 30
+    if pattern.nnz > 2 ** 31:
+        assert beyond_int32 >= 12       # rows whose values start beyond what an int32 offset reaches
+    assert worst_r / scale_r < 1e-12
+    assert worst_A / scale_A < 1e-11
