@@ -199,10 +199,12 @@ def test_element_boxes_add_up_to_the_whole(axis, matname):
     assert relmax(A_g, A_o) < 1e-11
 
 
-def test_element_boxes_p3_general_path():
+def test_element_boxes_p3_general_path(monkeypatch):
     """element boxes on the general path with 64-node elements (store + gather assembly: nodes no element of a box
-    touches are skipped by the gather kernel); the boxes add up to the oracle's whole-patch assembly"""
+    touches are skipped by the gather kernel); the boxes add up to the oracle's whole-patch assembly.  (Structured p = 3
+    patches take the tensor kernels since round 2: MIMI_HIP_FORCE_GENERAL keeps this path covered.)"""
     import mimi_amd
+    monkeypatch.setenv("MIMI_HIP_FORCE_GENERAL", "1")
     from mimi_amd.integrators import CSRPattern, NonlinearSolid
     from oracle import iga, ref_path as rp
     n_el = (3, 5, 2)

@@ -61,7 +61,8 @@ def test_mesh_counts_cpu():
     assert (s.mesh_dim(), s.n_elements(), s.n_vertices(), s.mesh_degrees()) == (2, 1, 4, [1, 1])
     s.elevate_degrees(2)
     s.subdivide(1)
-    assert (s.n_elements(), s.n_vertices(), s.mesh_degrees(), s.n_boundary_elements()) == (4, 9, [3, 3], 8)
+    # n_vertices = control points (py_solid.hpp:132-136: GetNodes()->Size() / dim), as the reference asserts for its degree-3 files
+    assert (s.n_elements(), s.n_vertices(), s.mesh_degrees(), s.n_boundary_elements()) == (4, 25, [3, 3], 8)
     p = s.patch()
     assert p.n_ctrl == [5, 5] and np.allclose(p.control_points.max(axis=0), [5.0, 1.0])
     c = mimi.Solid()
