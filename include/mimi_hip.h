@@ -13,7 +13,10 @@
  *    DEVICE pointer; the library detects which (hipPointerGetAttributes).  Host
  *    buffers are staged through device scratch and the call is synchronous; device
  *    buffers are used in place and the call only enqueues work on the handle's
- *    stream (mimi_hip_*_set_stream / mimi_hip_*_synchronize).
+ *    stream (mimi_hip_*_set_stream / mimi_hip_*_synchronize).  ORDERING: the kernels read and write those buffers
+ *    in stream order on the handle's stream only.  Work the caller has enqueued on them elsewhere (a zero fill of
+ *    r / A, a copy into u) must be ordered before the call, and reads of the results behind it: give the handle the
+ *    stream that work runs on (set_stream), or synchronise.  Several handles adding into one A need one stream.
  *  - u, r: fp64[n_vdofs], byVDIM ordering u[node*dim + c]   (py_nonlinear_solid.cpp:63,74)
  *  - A_values: fp64[nnz] of a CSR matrix with sorted columns whose structure
  *    (rowptr, col) was given at create time and never changes (precomputed.cpp:151-174,
@@ -33,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MIMI_HIP_ABI_VERSION 5
+#define MIMI_HIP_ABI_VERSION 6
 
 /* ---- errors ---------------------------------------------------------------- */
 const char* mimi_hip_last_error(void);
@@ -144,7 +147,9 @@ int mimi_hip_domain_destroy(mimi_hip_domain_t h);
 int mimi_hip_domain_set_dt(mimi_hip_domain_t h, double dt, double first_effective_dt,
                            double second_effective_dt);
 int mimi_hip_domain_set_tangent_mode(mimi_hip_domain_t h, int mode);
-/* stream = hipStream_t as void*; NULL = the handle's own stream */
+/* stream = hipStream_t as void*; NULL = the handle's own (non-blocking) stream; MIMI_HIP_STREAM_NULL = the device's
+ * null stream (hipStream_t 0: what e.g. torch's default stream is) */
+#define MIMI_HIP_STREAM_NULL ((void*)(intptr_t)-1)
 int mimi_hip_domain_set_stream(mimi_hip_domain_t h, void* stream);
 int mimi_hip_domain_synchronize(mimi_hip_domain_t h);
 
@@ -272,6 +277,9 @@ int mimi_hip_linear_set_stream(mimi_hip_linear_t h, void* hip_stream);
 /* forms::Nonlinear::AddMult / AddMultGrad tail (forms/nonlinear.hpp:76-80,112-115): r[ess] = 0 (r may be NULL);
  * A.EliminateRowCol(ess, DIAG_ONE) on the CSR values (A_values may be NULL).  Host or device pointers. */
 int mimi_hip_linear_eliminate(mimi_hip_linear_t h, double* r, double* A_values);
+/* y += alpha A x on the handle's pattern (mfem::SparseMatrix::AddMult: `mass_->Mult(a, y)`, `viscosity_->AddMult(v, y)` of
+ * operators::NonlinearSolid::Mult / ResidualAndGrad, operators/nonlinear_solid.cpp:172-205,240-283).  Host or device. */
+int mimi_hip_linear_add_mult(mimi_hip_linear_t h, const double* A_values, const double* x, double alpha, double* y);
 /* The reference's iterative linear solver (py/py_nonlinear_solid.cpp:329-339: mfem::GMRESSolver + mfem::DSmoother,
  * rel 1e-8, abs 1e-12, 300 iterations; kdim <= 0 = mfem's default 50): x = 0 start, left-preconditioned restarted
  * GMRES, modified Gram-Schmidt, stops when the preconditioned residual estimate <= max(rel_tol * ||M b||, abs_tol).

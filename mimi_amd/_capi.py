@@ -75,6 +75,7 @@ EXPORTS = [
     "mimi_hip_contact_update_body", "mimi_hip_contact_gap_area", "mimi_hip_contact_marked_nodes", "mimi_hip_contact_nodal",
     "mimi_hip_contact_add_residual_from_nodal",
     "mimi_hip_linear_create", "mimi_hip_linear_destroy", "mimi_hip_linear_set_stream", "mimi_hip_linear_eliminate",
+    "mimi_hip_linear_add_mult",
     "mimi_hip_linear_gmres", "mimi_hip_linear_cg",
 ]
 
@@ -159,6 +160,7 @@ def lib():
     L.mimi_hip_linear_destroy.argtypes = [C.c_void_p]
     L.mimi_hip_linear_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.mimi_hip_linear_eliminate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mimi_hip_linear_add_mult.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
     L.mimi_hip_linear_gmres.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
                                         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mimi_hip_linear_cg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int,
@@ -206,5 +208,9 @@ def torch_stream_of(*buffers):
     for b in buffers:
         if b is not None and hasattr(b, "is_cuda") and b.is_cuda:
             import torch
-            return torch.cuda.current_stream(b.device).cuda_stream
+            s = torch.cuda.current_stream(b.device).cuda_stream
+            return s if s else STREAM_NULL       # torch's default stream is the device's null stream (handle 0)
     return None
+
+
+STREAM_NULL = 2 ** 64 - 1        # MIMI_HIP_STREAM_NULL of include/mimi_hip.h

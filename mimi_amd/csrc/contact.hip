@@ -658,7 +658,7 @@ int mimi_hip_contact_set_tangent_mode(mimi_hip_contact_t h, int mode) {
 int mimi_hip_contact_set_stream(mimi_hip_contact_t h, void* stream) {
   return guarded_c([&] {
     if (!h) fail("null handle");
-    h->stream = stream ? reinterpret_cast<hipStream_t>(stream) : h->own_stream;
+    h->stream = stream == MIMI_HIP_STREAM_NULL ? nullptr : (stream ? reinterpret_cast<hipStream_t>(stream) : h->own_stream);
   });
 }
 

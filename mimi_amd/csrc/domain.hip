@@ -682,7 +682,7 @@ int mimi_hip_domain_set_tangent_mode(mimi_hip_domain_t h, int mode) {
 int mimi_hip_domain_set_stream(mimi_hip_domain_t h, void* stream) {
   return guarded([&] {
     if (!h) fail("null handle");
-    h->stream = stream ? reinterpret_cast<hipStream_t>(stream) : h->own_stream;
+    h->stream = stream == MIMI_HIP_STREAM_NULL ? nullptr : (stream ? reinterpret_cast<hipStream_t>(stream) : h->own_stream);
   });
 }
 

@@ -79,6 +79,20 @@ __global__ __launch_bounds__(256) void kr_spmv_kernel(int64_t n, const int64_t* 
   }
 }
 
+// y += alpha A x (mfem::SparseMatrix::AddMult): one wave per row
+__global__ __launch_bounds__(256) void kr_add_mult_kernel(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                          const double* __restrict__ val, const double* __restrict__ x, double alpha,
+                                                          double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t beg = rowptr[row], end = rowptr[row + 1];
+  double s = 0.0;
+  for (int64_t k = beg + lane; k < end; k += 64) s += val[k] * x[col[k]];
+  s = kr_wave_sum(s);
+  if (lane == 0) y[row] += alpha * s;
+}
+
 // dinv[row] = 1 / A(row, row)   (mfem::DSmoother, type 0, scale 1)
 __global__ void kr_diag_kernel(int64_t n, const int64_t* __restrict__ rowptr, const int64_t* __restrict__ diag_pos,
                                const double* __restrict__ val, double* __restrict__ dinv) {
@@ -321,7 +335,7 @@ int mimi_hip_linear_destroy(mimi_hip_linear_t h) {
 int mimi_hip_linear_set_stream(mimi_hip_linear_t h, void* stream) {
   return guarded_k([&] {
     if (!h) fail("null handle");
-    h->stream = stream ? reinterpret_cast<hipStream_t>(stream) : h->own_stream;
+    h->stream = stream == MIMI_HIP_STREAM_NULL ? nullptr : (stream ? reinterpret_cast<hipStream_t>(stream) : h->own_stream);
   });
 }
 
@@ -346,6 +360,22 @@ int mimi_hip_linear_eliminate(mimi_hip_linear_t h, double* r, double* A_values) 
       mA.finish(h->stream);
       if (mA.host) MH_HIP(hipStreamSynchronize(h->stream));
     }
+  });
+}
+
+int mimi_hip_linear_add_mult(mimi_hip_linear_t h, const double* A_values, const double* x, double alpha, double* y) {
+  return guarded_k([&] {
+    if (!h) fail("null handle");
+    if (!A_values || !x || !y) fail("null vector argument");
+    MH_HIP(hipSetDevice(h->device));
+    Mirror<double> mA = Mirror<double>::in(A_values, (size_t)h->nnz, h->stage_val, h->stream);
+    Mirror<double> mx = Mirror<double>::in(x, (size_t)h->n, h->stage_x, h->stream);
+    Mirror<double> my = Mirror<double>::inout(y, (size_t)h->n, h->stage_b, h->stream);
+    hipLaunchKernelGGL(kr_add_mult_kernel, dim3((unsigned)((h->n + 3) / 4)), dim3(256), 0, h->stream, h->n, h->rowptr, h->col, mA.dev,
+                       mx.dev, alpha, my.dev);
+    MH_HIP(hipGetLastError());
+    my.finish(h->stream);
+    if (mA.host || mx.host || my.host) MH_HIP(hipStreamSynchronize(h->stream));
   });
 }
 

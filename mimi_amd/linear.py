@@ -50,6 +50,12 @@ class LinearSolver:
         self._follow_torch(r, A_values)
         check(_capi.lib().mimi_hip_linear_eliminate(self._h, fptr(r), fptr(A_values)))
 
+    def AddMult(self, A_values, x, y, alpha=1.0):
+        """y += alpha A x (mfem::SparseMatrix::AddMult)"""
+        self._follow_torch(A_values, x, y)
+        check(_capi.lib().mimi_hip_linear_add_mult(self._h, fptr(A_values), fptr(x), float(alpha), fptr(y)))
+        return y
+
     def Mult(self, A_values, b, x):
         """x = A^-1 b to the configured tolerances (x is overwritten: iterative_mode false)"""
         it, conv, nrm = C.c_int32(0), C.c_int32(0), C.c_double(0.0)

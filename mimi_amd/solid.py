@@ -187,8 +187,9 @@ class Solid:
         return BSplinePatch(nb.degrees, nb.knots, nb.ctrl, nb.weights if nb.is_rational() else None)
 
 
-def _element_tables(patch, quadrature_order=-1, with_gradients=False):
-    """N[e,q,a] and w*det[e,q] for the mass matrix / body force (affine geometry)."""
+def _element_tables(patch, quadrature_order=-1, with_gradients=False, elements=None):
+    """N[e,q,a], w*det[e,q], conn[e,a] (and dN/dX[e,q,i,a]) for the mass matrix / damping / body force; elements: a slice
+    of the element range (setup walks large meshes in chunks)."""
     dim = patch.dim
     pmax = max(patch.degrees)
     order = 2 * pmax + 3 if quadrature_order < 0 else quadrature_order
@@ -196,6 +197,8 @@ def _element_tables(patch, quadrature_order=-1, with_gradients=False):
     tabs = [splines._tables_1d(patch.knots[d], patch.degrees[d], nq) for d in range(dim)]
     m = [len(t[0]) for t in tabs]
     e = np.arange(int(np.prod(m)))
+    if elements is not None:
+        e = e[elements]
     em = []
     for s in m:
         em.append(e % s)
@@ -281,21 +284,44 @@ class NonlinearSolid(Solid):
             axis, side = self._faces[bid + 1]
             dofs.append(patch.boundary_nodes(axis, side) * dim + comp)
         self.dirichlet_ = np.unique(np.concatenate(dofs)) if dofs else np.zeros(0, dtype=np.int64)
-        # mass (VectorMassIntegrator(rho), FormSystemMatrix(zero_dofs); :155-173) and rhs (:221-283)
-        N, wd, conn = _element_tables(patch)
-        Me = self.material.density * np.einsum("eq,eqa,eqb->eab", wd, N, N)
+        # mass (VectorMassIntegrator(rho), FormSystemMatrix(zero_dofs); :155-173), damping (:176-192:
+        # VectorDiffusionIntegrator(viscosity): C_(a,i),(b,j) = d_ij nu int grad N_a . grad N_b, integrated with the same
+        # rule as the mass matrix -- exact on affine patches; mfem's own default rule for this integrator cannot be read
+        # here and no reference fixture sets a viscosity: parity unpinned) and rhs (:221-283), in chunks of elements
+        nnz = len(col)
         keys = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr)) * n + col
-        mass = np.zeros(len(col))
-        for c in range(dim):
-            r = conn * dim + c
-            pos = np.searchsorted(keys, (r[:, :, None] * n + r[:, None, :]).ravel())
-            np.add.at(mass, pos, Me.ravel())
+        viscosity = getattr(self.material, "viscosity", -1.0)
+        mass = np.zeros(nnz)
+        visc = np.zeros(nnz) if viscosity > 0.0 else None
+        rhs = np.zeros(n)
+        chunk = 8192
+        for e0 in range(0, patch.n_elements, chunk):
+            sl = slice(e0, min(e0 + chunk, patch.n_elements))
+            if visc is not None:
+                N, wd, conn, dN_dX = _element_tables(patch, with_gradients=True, elements=sl)
+                Ce = viscosity * np.einsum("eq,eqia,eqib->eab", wd, dN_dX, dN_dX)
+            else:
+                N, wd, conn = _element_tables(patch, elements=sl)
+            Me = self.material.density * np.einsum("eq,eqa,eqb->eab", wd, N, N)
+            # position of (row a, column b) of component 0; the rows of a node's other components follow it with the same
+            # column pattern: + c (row length) for the row, + c for the column
+            r0 = conn * dim
+            pos0 = np.searchsorted(keys, (r0[:, :, None] * n + r0[:, None, :]).ravel()).reshape(Me.shape)
+            row_len = (rowptr[r0 + 1] - rowptr[r0])[:, :, None]
+            for c in range(dim):
+                pos = (pos0 + c * row_len + c).ravel()
+                np.add.at(mass, pos, Me.ravel())
+                if visc is not None:
+                    np.add.at(visc, pos, Ce.ravel())
+            fe = np.einsum("eq,eqa->ea", wd, N)
+            for comp, value in bc.initial.body_force_.items():
+                np.add.at(rhs, (conn * dim + comp).ravel(), (fe * value).ravel())
+        del keys
         self.mass_ = mass
         _eliminate_row_col(rowptr, col, self.mass_, self.dirichlet_)
-        rhs = np.zeros(n)
-        fe = np.einsum("eq,eqa->ea", wd, N)
-        for comp, value in bc.initial.body_force_.items():
-            np.add.at(rhs, (conn * dim + comp).ravel(), (fe * value).ravel())
+        self.visc_ = visc
+        if visc is not None:
+            _eliminate_row_col(rowptr, col, self.visc_, self.dirichlet_)
         rhs[self.dirichlet_] = 0.0
         self.rhs_ = rhs
         # integrators (py_nonlinear_solid.cpp:197-218, 286-326)
@@ -327,11 +353,11 @@ class NonlinearSolid(Solid):
         gamma = 0.5 + am - af
         self._fac = (0.5 - beta / am, af, af * (1.0 - gamma / am), beta * af / am, gamma * af / am, am)  # ode.cpp:5-14
         self._nstate = 0
-        self._jac = np.zeros_like(self.mass_)
         # linear solver (py_nonlinear_solid.cpp:327-343): "use_iterative_solver" -> GMRES + Jacobi on the device
         # (mimi_amd/linear.py); else a sparse direct solve on the host (UMFPack in the reference, SuperLU here)
         self.linear_ = LinearSolver(self.pattern_, self.dirichlet_, device=self.device)
         self.use_iterative_solver_ = bool(rc.get_int("use_iterative_solver", 0))
+        self._to_device()
 
     def configure_newton(self, name, rel_tol, abs_tol, max_iter, iterative_mode):   # py_solid.cpp:334-346
         self._newton = dict(rel_tol=rel_tol, abs_tol=abs_tol, max_iter=int(max_iter), iterative_mode=bool(iterative_mode))
@@ -340,6 +366,24 @@ class NonlinearSolid(Solid):
         return {"x": self.x, "x_dot": self.x_dot}[component]
 
     # -- operators::NonlinearSolid ----------------------------------------------------------------
+    # ---- device-resident state ---------------------------------------------------------------------
+    # x, v, a, the residual, the mass / viscosity / Jacobian values and the right-hand side live in HBM (torch tensors
+    # as the memory container); the integrators, the eliminations, the matrix-vector products and -- on the iterative
+    # route -- the linear solves use them in place.  The host sees: norms (scalars), the solution after a step
+    # (n_vdofs doubles into the arrays `solution_view` hands out) and, on the reference's default direct-solve route
+    # only, the Jacobian values for the host factorisation.
+    def _to_device(self):
+        import torch
+        self._torch = torch
+        dev = torch.device("cuda", self.device)
+        f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        self.d_mass_, self.d_rhs_ = f(self.mass_), f(self.rhs_)
+        self.d_visc_ = f(self.visc_) if self.visc_ is not None else None
+        self.d_jac_ = torch.zeros_like(self.d_mass_)
+        self.d_dirichlet_ = torch.from_numpy(np.asarray(self.dirichlet_, dtype=np.int64)).to(dev)
+        self.d_x_, self.d_v_ = f(self.x), f(self.x_dot)
+        self.pcie_csr_bytes_ = 0          # CSR values that crossed PCIe since setup (direct-solve route only)
+
     def _csr(self, vals):
         n = len(self.x)
         return sp.csr_matrix((vals, self.pattern_.col, self.pattern_.rowptr), shape=(n, n))
@@ -352,36 +396,59 @@ class NonlinearSolid(Solid):
         self.domain_.AddDomainResidual(xt, y)
         for c in self.contacts_:
             c.AddBoundaryResidual(xt, y)
-        y[self.dirichlet_] = 0.0
+        self.linear_.Eliminate(y, None)               # y[ess] = 0
+
+    def _linear_part(self, a, y):
+        """y = M a [+ C (v_alpha + fac1 a)]   (operators/nonlinear_solid.cpp:177-187,249-255)"""
+        y.zero_()
+        self.linear_.AddMult(self.d_mass_, a, y)
+        if self.d_visc_ is not None:
+            self.linear_.AddMult(self.d_visc_, self._va + self._fac1 * a, y)
 
     def _mult(self, a):                               # operators/nonlinear_solid.cpp:172-205
         xt = self._xa + self._fac0 * a
-        y = self._csr(self.mass_) @ a
+        y = self._torch.empty_like(a)
+        self._linear_part(a, y)
         self._add_mult(xt, y)
-        y -= self.rhs_
-        y[self.dirichlet_] = 0.0
+        y -= self.d_rhs_
+        self.linear_.Eliminate(y, None)
         return y
 
     def _residual_and_grad(self, a):                  # operators/nonlinear_solid.cpp:240-283
         xt = self._xa + self._fac0 * a
-        y = self._csr(self.mass_) @ a
-        self._jac[:] = self.mass_
+        y = self._torch.empty_like(a)
+        self._linear_part(a, y)
+        self.d_jac_.copy_(self.d_mass_)               # std::copy_n(mass_A_, ...)
         self._push(self.domain_)
-        self.domain_.AddDomainResidualAndGrad(xt, self._fac0, y, self._jac)
+        self.domain_.AddDomainResidualAndGrad(xt, self._fac0, y, self.d_jac_)
         for c in self.contacts_:
-            c.AddBoundaryResidualAndGrad(xt, self._fac0, y, self._jac)
-        self.linear_.Eliminate(y, self._jac)          # forms/nonlinear.hpp:76-80,112-115
-        y -= self.rhs_
-        y[self.dirichlet_] = 0.0
-        return y, self._jac
+            c.AddBoundaryResidualAndGrad(xt, self._fac0, y, self.d_jac_)
+        self.linear_.Eliminate(y, self.d_jac_)        # forms/nonlinear.hpp:76-80,112-115
+        if self.d_visc_ is not None:
+            self.d_jac_.add_(self.d_visc_, alpha=self._fac1)     # jacobian_->Add(fac1_, viscosity_->SpMat())
+        y -= self.d_rhs_
+        self.linear_.Eliminate(y, None)
+        return y, self.d_jac_
+
+    def _solve(self, J, r):
+        """the linear solve of a Newton iteration (py_nonlinear_solid.cpp:327-343)"""
+        if self.use_iterative_solver_:
+            return self.linear_.Mult(J, r, self._torch.zeros_like(r))        # GMRES + Jacobi, all in HBM
+        # the reference's default: a sparse direct solve (UMFPack there, SuperLU here) -- on the host
+        Jh = J.cpu().numpy()
+        self.pcie_csr_bytes_ += Jh.nbytes
+        c = spla.splu(self._csr(Jh).tocsc()).solve(r.cpu().numpy())
+        return self._torch.from_numpy(c).to(r.device)
 
     def _newton_solve(self, x0):                      # solvers/newton.cpp:10-218
+        torch = self._torch
         o = self._newton
-        x = x0.copy() if o["iterative_mode"] else np.zeros_like(x0)
+        nrm = lambda t: float(torch.linalg.vector_norm(t))
+        x = x0.clone() if o["iterative_mode"] else torch.zeros_like(x0)
         improved, i_improved = [True] * 5, 0
-        best_res, best_x = np.finfo(float).max, x.copy()
+        best_res, best_x = np.finfo(float).max, x.clone()
         r, J = self._residual_and_grad(x)
-        norm0 = norm = np.linalg.norm(r)
+        norm0 = norm = nrm(r)
         goal = max(o["rel_tol"] * norm, o["abs_tol"])
         it, converged = 0, False
         while True:
@@ -390,18 +457,15 @@ class NonlinearSolid(Solid):
                 break
             if it >= o["max_iter"]:
                 if it != 0:
-                    x = best_x.copy()
+                    x = best_x.clone()
                 break
             if not any(improved):
-                x = best_x.copy()
+                x = best_x.clone()
                 break
-            if self.use_iterative_solver_:
-                c = self.linear_.Mult(J, r, np.zeros_like(r))
-            else:
-                c = spla.splu(self._csr(J).tocsc()).solve(r)
+            c = self._solve(J, r)
             q1 = norm
-            q3 = np.linalg.norm(self._mult(x - c))
-            q2 = np.linalg.norm(self._mult(x - 0.5 * c))
+            q3 = nrm(self._mult(x - c))
+            q2 = nrm(self._mult(x - 0.5 * c))
             den = q1 - 2.0 * q2 + q3
             eps = (3.0 * q1 - 4.0 * q2 + q3) / (4.0 * den) if den != 0 else np.inf
             scale = eps if (den > 0 and 0 < eps < 1) else (1.0 if q3 < q1 else 0.05)
@@ -412,9 +476,9 @@ class NonlinearSolid(Solid):
                 r = self._mult(x)
             else:
                 r, J = self._residual_and_grad(x)
-            norm = np.linalg.norm(r)
+            norm = nrm(r)
             if norm < best_res:
-                best_x, best_res = x.copy(), norm
+                best_x, best_res = x.clone(), norm
                 improved[i_improved % 5] = True
             else:
                 improved[i_improved % 5] = False
@@ -425,27 +489,37 @@ class NonlinearSolid(Solid):
 
     # -- GeneralizedAlpha2::StepTime2 (solvers/ode.cpp:16-79) -------------------------------------
     def step_time2(self):
+        torch = self._torch
         dt = self.time_step_size
         f0, f1, f2, f3, f4, f5 = self._fac
-        x, v = self.x, self.x_dot
+        # what the caller may have written through solution_view since the last step (n_vdofs doubles)
+        self.d_x_.copy_(torch.from_numpy(self.x))
+        self.d_v_.copy_(torch.from_numpy(self.x_dot))
+        x, v = self.d_x_, self.d_v_
         self._fac0, self._fac1 = f3 * dt * dt, f4 * dt
         if self._nstate == 0:
-            z = np.zeros_like(x)                       # operators/nonlinear_solid.cpp:124-156
+            z = torch.zeros_like(x)                    # operators/nonlinear_solid.cpp:124-156
             self._add_mult(x, z)
-            z = -z + self.rhs_
-            self._a = spla.splu(self._csr(self.mass_).tocsc()).solve(z)
-            self._aa = np.zeros_like(x)
+            if self.d_visc_ is not None:
+                self.linear_.AddMult(self.d_visc_, v, z)
+            z = self.d_rhs_ - z
+            if self.use_iterative_solver_:
+                # mass_inv_: mfem::CGSolver + DSmoother (operators/nonlinear_solid.cpp:39-50,155)
+                self._a = self.linear_.MultCG(self.d_mass_, z, torch.zeros_like(z))
+            else:
+                self._a = torch.from_numpy(spla.splu(self._csr(self.mass_).tocsc()).solve(z.cpu().numpy())).to(x.device)
+            self._aa = torch.zeros_like(x)
             self._nstate = 1
         a = self._a
         self._xa = x + (v + f0 * dt * a) * (f1 * dt)
-        va = v + f2 * dt * a
+        self._va = v + f2 * dt * a
         self._aa = self._newton_solve(self._aa)
         aa = self._aa
         xa = self._xa + self._fac0 * aa
-        va = va + self._fac1 * aa
+        va = self._va + self._fac1 * aa
         prev = 1.0 - 1.0 / f1
-        x[:] = x * prev + xa / f1
-        v[:] = v * prev + va / f1
+        x.mul_(prev).add_(xa, alpha=1.0 / f1)
+        v.mul_(prev).add_(va, alpha=1.0 / f1)
         self._a = a * prev + aa / f5
         # PostTimeAdvance (operators/nonlinear_solid.cpp:285-292)
         self._push(self.domain_)
@@ -453,6 +527,10 @@ class NonlinearSolid(Solid):
         for c in self.contacts_:
             c.BoundaryPostTimeAdvance(x)
         self.current_time += dt
+        # the arrays solution_view handed out (zero-copy views of the reference: py_solid.cpp:379-388)
+        self.x[:] = x.cpu().numpy()
+        self.x_dot[:] = v.cpu().numpy()
+        x, v = self.x, self.x_dot
         # PySolid::StepTime2 (py_solid.cpp:433-440): save cadence, in the reference's (MFEM's) dof numbering
         rc = self.runtime_communication
         if rc is not None:

@@ -39,6 +39,25 @@ def assemble_mass(patch, tables, density, rowptr, col):
     return vals
 
 
+def assemble_viscosity(patch, tables, viscosity, rowptr, col):
+    """VectorDiffusionIntegrator(viscosity) on the same pattern (py_nonlinear_solid.cpp:176-192): nu * int grad N_a . grad N_b
+    per component, with the quadrature rule of the tables (exact on affine patches).  PARITY UNPINNED: no reference fixture
+    sets a viscosity, and MFEM's default rule for this integrator is not visible without MFEM."""
+    dim = patch.dim
+    wd = tables["weight"] * tables["det"]
+    g = tables["dN_dX"]                                   # [e, q, a, J]
+    Ce = viscosity * np.einsum("eq,eqaJ,eqbJ->eab", wd, g, g)
+    conn = tables["conn"].astype(np.int64)
+    n = patch.n_vdofs
+    keys = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr)) * n + col
+    vals = np.zeros(len(col))
+    for c in range(dim):
+        r = conn * dim + c
+        pos = np.searchsorted(keys, (r[:, :, None] * n + r[:, None, :]).ravel())
+        np.add.at(vals, pos, Ce.ravel())
+    return vals
+
+
 def assemble_body_force(patch, tables, b):
     """VectorDomainLFIntegrator with a constant vector coefficient
     (py_nonlinear_solid.cpp:221-240): no density factor."""
@@ -67,8 +86,12 @@ def eliminate_row_col(rowptr, col, vals, dofs):
 class Operator:
     """operators::NonlinearSolid for one domain integrator (+ optional contact)."""
 
-    def __init__(self, integ, rowptr, col, mass_vals, rhs, dirichlet, contact=None):
+    def __init__(self, integ, rowptr, col, mass_vals, rhs, dirichlet, contact=None, visc_vals=None):
         self.integ, self.contact = integ, contact
+        self.visc = None
+        if visc_vals is not None:                      # FormSystemMatrix(zero_dofs) (py_nonlinear_solid.cpp:191)
+            self.visc = visc_vals.copy()
+            eliminate_row_col(rowptr, col, self.visc, np.asarray(dirichlet, dtype=np.int64))
         self.rowptr, self.col = rowptr, col
         self.n = len(rowptr) - 1
         self.dirichlet = np.asarray(dirichlet, dtype=np.int64)
@@ -100,6 +123,8 @@ class Operator:
         if self.contact is not None:
             self.contact.add_boundary_residual(x, z)
         z[self.dirichlet] = 0.0
+        if self.visc is not None:                          # viscosity_->AddMult(dx_dt, z)
+            z += self._csr(self.visc) @ self.v0
         z = -z + self.rhs
         return spla.splu(self._csr(self.mass).tocsc()).solve(z)
 
@@ -109,6 +134,8 @@ class Operator:
         xt = self.x + self.fac0 * a
         y = self._csr(self.mass) @ a
         self.integ.add_domain_residual(xt, y)
+        if self.visc is not None:
+            y += self._csr(self.visc) @ (self.v + self.fac1 * a)
         if self.contact is not None:
             self.contact.add_boundary_residual(xt, y)
         y[self.dirichlet] = 0.0
@@ -121,12 +148,16 @@ class Operator:
         self.n_resgrad += 1
         xt = self.x + self.fac0 * a
         y = self._csr(self.mass) @ a
+        if self.visc is not None:
+            y += self._csr(self.visc) @ (self.v + self.fac1 * a)
         self.jac[:] = self.mass
         self.integ.add_domain_residual_and_grad(xt, self.fac0, y, self.jac, self.tangent_mode)
         if self.contact is not None:
             self.contact.add_boundary_residual_and_grad(xt, self.fac0, y, self.jac, self.tangent_mode)
         y[self.dirichlet] = 0.0
         eliminate_row_col(self.rowptr, self.col, self.jac, self.dirichlet)
+        if self.visc is not None:                          # jacobian_->Add(fac1_, viscosity_->SpMat())
+            self.jac += self.fac1 * self.visc
         y -= self.rhs
         y[self.dirichlet] = 0.0
         return y, self.jac
@@ -213,6 +244,7 @@ class GeneralizedAlpha2:
         op = self.op
         op.dt = dt
         if self.nstate == 0:
+            op.v0 = v
             self.a = op.explicit_accel(x)
             self.nstate = 1
             self.aa = np.zeros_like(x)

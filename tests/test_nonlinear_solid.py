@@ -317,3 +317,53 @@ def test_contact_with_rigid_spline_through_the_facade():
     c.AddBoundaryResidual(nl.x, r)
     c.BoundaryPostTimeAdvance(nl.x)
     assert abs(c.last_force_[1]) > 2.0 * f0
+
+
+@pytest.mark.gpu
+def test_viscosity_term():
+    """material.viscosity > 0: the damping form of py_nonlinear_solid.cpp:176-192 (C v in the residual, fac1 C in the
+    Jacobian).  No reference fixture sets a viscosity (parity unpinned): the facade is compared with the oracle's
+    restatement of the same operator, and the damped series must differ from the undamped one."""
+    import mimi_amd as mimi
+    from oracle import harness as hz, iga, ref_path as rp
+    from _cases import oracle_material
+    series = {}
+    for nu in (-1.0, 40.0):
+        nl = balken(1, 2)
+        mat = mimi.CompressibleOgdenNeoHookean()
+        mat.density = 1
+        mat.viscosity = nu
+        mat.set_young_poisson(2100, 0.3)
+        nl.set_material(mat)
+        rc = mimi.RuntimeCommunication()
+        rc.set_real("ode_coefficient", 0.5)
+        nl.runtime_communication = rc
+        bc = mimi.BoundaryConditions()
+        bc.initial.dirichlet(2, 0).dirichlet(2, 1)
+        bc.initial.body_force(1, -5)
+        nl.boundary_condition = bc
+        nl.setup(1)
+        nl.configure_newton("nonlinear_solid", 1e-12, 1e-8, 10, False)
+        nl.time_step_size = 0.05
+        out = []
+        for _ in range(4):
+            nl.step_time2()
+            out.append(nl.solution_view("displacement", "x").ravel().copy())
+        series[nu] = np.array(out)
+    assert np.abs(series[40.0] - series[-1.0]).max() > 1e-3
+    # oracle: same operator with the damping matrix
+    P = iga.Patch.block((2, 2), 3, [5.0, 1.0])
+    D = rp.DomainOracle(P, oracle_material("neohook"), n_threads=1)
+    mass = hz.assemble_mass(P, D.tables, 1.0, D.rowptr, D.col)
+    visc = hz.assemble_viscosity(P, D.tables, 40.0, D.rowptr, D.col)
+    rhs = hz.assemble_body_force(P, D.tables, [0.0, -5.0])
+    nodes = P.boundary_nodes(0, 0)
+    dirichlet = np.sort(np.concatenate([nodes * 2, nodes * 2 + 1]))
+    op = hz.Operator(D, D.rowptr, D.col, mass, rhs, dirichlet, visc_vals=visc)
+    op.tangent_mode = rp.TANGENT_EXACT
+    ode = hz.GeneralizedAlpha2(op, 0.5, dict(rel_tol=1e-12, abs_tol=1e-8, max_iter=10, iterative_mode=False))
+    x, v, t = np.zeros(P.n_vdofs), np.zeros(P.n_vdofs), 0.0
+    for i in range(4):
+        op.dt = 0.05
+        t = ode.step(x, v, t, 0.05)
+        assert np.abs(x - series[40.0][i]).max() < 1e-8, (i, np.abs(x - series[40.0][i]).max())
