@@ -256,13 +256,14 @@ static GeneralArgs general_args(mimi_hip_domain_s* h, const double* u, double* r
   return a;
 }
 
-// two-phase general path (64-node elements): element blocks densely into scratch_k, then general_gather_kernel.  Needs
-// n_el * 192^2 doubles (77 GB at 128 x 128 x 16 p = 3) and the node -> element adjacency; falls back to the atomics when
-// the scratch does not fit (MIMI_HIP_GENERAL_NO_TWO_PHASE=1 forces that)
-static bool ensure_general_two_phase(mimi_hip_domain_s* h) {
+// two-phase general path: element blocks / residual vectors densely into scratch_k / scratch_r, then
+// general_gather_kernel.  Needs n_el * n_tdof^2 doubles (77 GB at 128 x 128 x 16 p = 3) and the node -> element adjacency;
+// falls back to the atomics when the scratch does not fit (MIMI_HIP_GENERAL_NO_TWO_PHASE=1 forces that)
+static bool ensure_general_two_phase(mimi_hip_domain_s* h, bool with_k) {
   static const bool off = getenv("MIMI_HIP_GENERAL_NO_TWO_PHASE") && getenv("MIMI_HIP_GENERAL_NO_TWO_PHASE")[0] == '1';
   if (off || h->general_two_phase_failed) return false;
-  const size_t need = (size_t)h->n_el * 192 * 192;
+  const size_t n_tdof = (size_t)h->n_dof * h->dim;
+  const size_t need = with_k ? (size_t)h->n_el * n_tdof * n_tdof : 0;
   if (h->scratch_k.count < need) {
     size_t free_b = 0, total_b = 0;
     MH_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -273,26 +274,28 @@ static bool ensure_general_two_phase(mimi_hip_domain_s* h) {
     }
     h->scratch_k.resize(need);
   }
+  h->scratch_r.resize((size_t)h->n_el * n_tdof);
   if (!h->adj_ptr.ptr) {
-    // the gather kernel keeps one CSR row in LDS: rows longer than its image (not the structured p = 3 pattern) -> atomics
+    // the gather kernel keeps one CSR row in LDS: rows longer than its image -> atomics
     std::vector<int64_t> rp((size_t)h->n_vdofs + 1);
     MH_HIP(hipMemcpy(rp.data(), h->rowptr, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
     int64_t longest = 0;
     for (int64_t v = 0; v < h->n_vdofs; ++v) longest = std::max(longest, rp[v + 1] - rp[v]);
-    if (longest > GG_MAX_ROW) {
+    if (longest > GG_MAX_ROW || h->n_dof > 64) {
       h->general_two_phase_failed = true;
       return false;
     }
-    const size_t n = (size_t)h->n_el * 64;
+    const size_t n = (size_t)h->n_el * h->n_dof;
     std::vector<int32_t> dofs(n);
     MH_HIP(hipMemcpy(dofs.data(), h->dofs.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    const int64_t n_nodes = h->n_vdofs / 3;
+    const int64_t n_nodes = h->n_vdofs / h->dim;
     std::vector<int64_t> ptr(n_nodes + 1, 0);
     for (size_t k = 0; k < n; ++k) ++ptr[dofs[k] + 1];
     for (int64_t v = 0; v < n_nodes; ++v) ptr[v + 1] += ptr[v];
     std::vector<int32_t> adj(n);
     std::vector<int64_t> fill(ptr.begin(), ptr.end() - 1);
-    for (size_t k = 0; k < n; ++k) adj[fill[dofs[k]]++] = (int32_t)k;   // k = e * 64 + a
+    for (size_t k = 0; k < n; ++k)    // entry = (element << 6) | local node
+      adj[fill[dofs[k]]++] = (int32_t)(((k / h->n_dof) << 6) | (k % h->n_dof));
     h->adj_ptr.assign(ptr.data(), ptr.size(), h->stream);
     h->adj.assign(adj.data(), adj.size(), h->stream);
   }
@@ -307,13 +310,18 @@ template<int DIM>
 static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a_in) {
   GeneralArgs a = a_in;
   static const bool no_mfma_env = getenv("MIMI_HIP_GENERAL_NO_MFMA") && getenv("MIMI_HIP_GENERAL_NO_MFMA")[0] == '1';
-  const bool two_phase = grad == 1 && DIM == 3 && h->n_dof == 64 && !no_mfma_env && ensure_general_two_phase(h);
-  a.scratch_k = two_phase ? h->scratch_k.ptr : nullptr;
+  (void)no_mfma_env;
+  const bool two_phase = ensure_general_two_phase(h, grad != 0);
+  a.scratch_k = (two_phase && grad) ? h->scratch_k.ptr : nullptr;
+  a.scratch_r = two_phase ? h->scratch_r.ptr : nullptr;
+  // (called after the element kernel of every route below)
   auto gather = [&]() {
     if (!two_phase) return;
     const int64_t n_rows = h->n_vdofs;
-    hipLaunchKernelGGL(general_gather_kernel, dim3((unsigned)((n_rows + GG_WAVES - 1) / GG_WAVES)), dim3(64 * GG_WAVES), 0, h->stream,
-                       n_rows, h->rowptr, h->adj_ptr.ptr, h->adj.ptr, h->pair_pos.ptr, h->scratch_k.ptr, a.grad_factor, a.A);
+    auto kernel = grad ? general_gather_kernel<DIM, 1> : general_gather_kernel<DIM, 0>;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)((n_rows + GG_WAVES - 1) / GG_WAVES)), dim3(64 * GG_WAVES), 0, h->stream, n_rows,
+                       h->n_dof, h->rowptr, h->adj_ptr.ptr, h->adj.ptr, h->pair_pos.ptr, h->scratch_k.ptr, h->scratch_r.ptr,
+                       a.grad_factor, a.A, a.r);
     MH_HIP(hipGetLastError());
   };
   size_t lds = general_lds_bytes(DIM, h->n_dof, h->n_q, grad);
@@ -333,6 +341,7 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a_
     const bool other = !material_closed_form(h->mat.m.kind);
     if (grad == 0) { if (other) gow(domain_general_kernel<DIM, 0, 3, 256, 1, 0, 1>); else gow(domain_general_kernel<DIM, 0, 3, 256, 0, 0, 1>); }
     else { if (other) gow(domain_general_kernel<DIM, 1, 3, 256, 1, 0, 1>); else gow(domain_general_kernel<DIM, 1, 3, 256, 0, 0, 1>); }
+    gather();
     return;
   }
   auto go = [&](auto kernel, int threads = 256) {
@@ -346,17 +355,19 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a_
   if (!material_closed_form(h->mat.m.kind)) {
     // the other materials: same kernel, stress and tangent from materials_other.hpp
     if (grad == 0) go(domain_general_kernel<DIM, 0, 3, 256, 1>);
-    else if (grad == 1 && DIM == 3 && h->n_dof == 64 && !no_mfma) { go(domain_general_kernel<3, 1, GEN_BIG_PP, GEN_BIG_THREADS, 1, 1>, GEN_BIG_THREADS); gather(); }
+    else if (grad == 1 && DIM == 3 && h->n_dof == 64 && !no_mfma) go(domain_general_kernel<3, 1, GEN_BIG_PP, GEN_BIG_THREADS, 1, 1>, GEN_BIG_THREADS);
     else if (grad == 1 && h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, GEN_BIG_PP, GEN_BIG_THREADS, 1>, GEN_BIG_THREADS);
     else if (grad == 1) go(domain_general_kernel<DIM, 1, 3, 256, 1>);
     else go(domain_general_kernel<DIM, 2, 3, 256, 1>);
+    gather();
     return;
   }
   if (grad == 0) go(domain_general_kernel<DIM, 0>);
-  else if (grad == 1 && DIM == 3 && h->n_dof == 64 && !no_mfma) { go(domain_general_kernel<3, 1, GEN_BIG_PP, GEN_BIG_THREADS, 0, 1>, GEN_BIG_THREADS); gather(); }
+  else if (grad == 1 && DIM == 3 && h->n_dof == 64 && !no_mfma) go(domain_general_kernel<3, 1, GEN_BIG_PP, GEN_BIG_THREADS, 0, 1>, GEN_BIG_THREADS);
   else if (grad == 1 && h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, GEN_BIG_PP, GEN_BIG_THREADS>, GEN_BIG_THREADS);
   else if (grad == 1) go(domain_general_kernel<DIM, 1, 3>);
   else go(domain_general_kernel<DIM, 2>);
+  gather();
 }
 
 static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double* A, double gf, bool with_grad) {

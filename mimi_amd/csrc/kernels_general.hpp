@@ -4,8 +4,11 @@
 //   NonlinearSolid::ElementResidual / ElementResidualAndGrad / ThreadLocalResidual[AndGrad]
 //   (integrators/nonlinear_solid.hpp:65-87, nonlinear_solid.cpp:48-149)
 //   and the AddThreadLocal* reductions (integrators/nonlinear_base.hpp:90-151):
-// instead of per-thread global copies + a reduction pass, element contributions go
-// straight into r / CSR values with fp64 hardware atomics.
+// instead of per-thread global copies + a reduction pass, element contributions go out as dense element blocks / element
+// residual vectors, and general_gather_kernel (one wave per CSR row, node -> element adjacency built at setup, fixed
+// summation order) adds them into r / the CSR values: no atomics, bitwise reproducible.  (Only when the blocks do not fit
+// in device memory, or a CSR row is longer than the gather kernel's LDS image, do the contributions go straight into
+// r / A with fp64 hardware atomics.)
 //
 // Work split inside a workgroup (256 threads = 4 waves):
 //   phase 0  gather u_e = u[dofs] into LDS (integrator_utils.cpp:44-51)
@@ -40,7 +43,8 @@ struct GeneralArgs {
   StateView state;
   int* status;
   int lds_per_element;      // WPE kernels: bytes of LDS per element (general_lds_bytes rounded up to 16)
-  double* scratch_k;        // MF kernels: dense element blocks [n_el][(a, i)][(b, j)] instead of atomics (then gathered)
+  double* scratch_k;        // dense element blocks [n_el][(a, i)][(j, b)] instead of atomics (then gathered); nullptr: atomics
+  double* scratch_r;        // element residual vectors [n_el][i][a] instead of atomics (then gathered); nullptr: atomics
 };
 
 MH_DEV void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
@@ -190,7 +194,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
       for (int J = 0; J < DIM; ++J) s += g[J * n_dof + a] * Pw[q * DD + i + J * DIM];
     }
     if constexpr (GRAD == 2) R_e[t] = s;
-    atomic_add_f64(&p.r[(int64_t)node[a] * DIM + i], s);
+    if (p.scratch_r) p.scratch_r[(int64_t)e * n_tdof + t] = s;
+    else atomic_add_f64(&p.r[(int64_t)node[a] * DIM + i], s);
   }
 
   if constexpr (GRAD == 1 && MF == 1) {
@@ -343,7 +348,13 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
 #pragma unroll
         for (int k = 0; k < PP; ++k) {
           const int a = ag * PP + k;
-          if (a < n_dof) {
+          if (a < n_dof && p.scratch_k) {
+            double* Ke = p.scratch_k + (int64_t)e * (n_tdof * n_tdof);
+#pragma unroll
+            for (int i = 0; i < DIM; ++i)
+#pragma unroll
+              for (int j = 0; j < DIM; ++j) Ke[(a * DIM + i) * n_tdof + j * n_dof + b] = acc[k][i * DIM + j];
+          } else if (a < n_dof) {
             const int64_t rowA = (int64_t)node[a] * DIM;
             const int32_t off = pp_tab[a * n_dof + b];
 #pragma unroll
@@ -400,7 +411,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
         }
         const double k_entry = (s - R_e[t]) * step_inv;
         const int64_t rowA = (int64_t)node[a] * DIM + i;
-        atomic_add_f64(p.A + p.rowptr[rowA] + pp[a * n_dof + b] + j, p.grad_factor * k_entry);
+        if (p.scratch_k) p.scratch_k[(int64_t)e * (n_tdof * n_tdof) + (a * DIM + i) * n_tdof + j * n_dof + b] = k_entry;
+        else atomic_add_f64(p.A + p.rowptr[rowA] + pp[a * n_dof + b] + j, p.grad_factor * k_entry);
       }
     }
   }
@@ -439,37 +451,52 @@ __global__ __launch_bounds__(256) void post_time_advance_general_kernel(GeneralA
 // to the caller's values in one coalesced pass: no atomics, a fixed summation order.
 constexpr int GG_WAVES = 4;
 constexpr int GG_MAX_ROW = 1056;   // (2 p + 1)^3 neighbours x 3 at p = 3 is 1029
-__global__ __launch_bounds__(64 * GG_WAVES) void general_gather_kernel(int64_t n_rows, const int64_t* __restrict__ rowptr,
+// adjacency entries are (element << 6) | local node (n_dof <= 64).  WITH_K 0: residual rows only.
+template<int DIM, int WITH_K>
+__global__ __launch_bounds__(64 * GG_WAVES) void general_gather_kernel(int64_t n_rows, int n_dof, const int64_t* __restrict__ rowptr,
                                                                        const int64_t* __restrict__ adj_ptr, const int32_t* __restrict__ adj,
                                                                        const int32_t* __restrict__ pair_pos, const double* __restrict__ scratch_k,
-                                                                       double grad_factor, double* __restrict__ A) {
-  constexpr int DIM = 3, ND = 64, NT = ND * DIM;
-  __shared__ double img_all[GG_WAVES][GG_MAX_ROW];
+                                                                       const double* __restrict__ scratch_r, double grad_factor,
+                                                                       double* __restrict__ A, double* __restrict__ r) {
+  __shared__ double img_all[WITH_K ? GG_WAVES : 1][GG_MAX_ROW];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * GG_WAVES + wave;
   if (row >= n_rows) return;
-  double* img = img_all[wave];
   const int64_t node = row / DIM;
   const int i = (int)(row % DIM);
-  if (adj_ptr[node] == adj_ptr[node + 1]) return;   // no element of this handle touches the node (element slabs)
-  const int64_t beg = rowptr[row];
-  const int len = (int)(rowptr[row + 1] - beg);
-  for (int k = lane; k < len; k += 64) img[k] = 0.0;
-  __builtin_amdgcn_wave_barrier();
-  for (int64_t t = adj_ptr[node]; t < adj_ptr[node + 1]; ++t) {
-    const int32_t ea = adj[t];
-    const int64_t e = ea >> 6;
-    const int a = ea & 63;
-    const double* Kr = scratch_k + (e * NT + (a * DIM + i)) * (int64_t)NT + lane;   // row (a, i): [j][b], lane = b
-    const int32_t off = pair_pos[(e * ND + a) * ND + lane];
-    const double v0 = Kr[0], v1 = Kr[ND], v2 = Kr[2 * ND];
-    img[off] += v0;
-    img[off + 1] += v1;
-    img[off + 2] += v2;
+  const int64_t a_beg = adj_ptr[node], a_end = adj_ptr[node + 1];
+  if (a_beg == a_end) return;   // no element of this handle touches the node (element slabs)
+  const int NT = n_dof * DIM;
+  if constexpr (WITH_K) {
+    double* img = img_all[wave];
+    const int64_t beg = rowptr[row];
+    const int len = (int)(rowptr[row + 1] - beg);
+    for (int k = lane; k < len; k += 64) img[k] = 0.0;
     __builtin_amdgcn_wave_barrier();
+    for (int64_t t = a_beg; t < a_end; ++t) {
+      const int32_t ea = adj[t];
+      const int64_t e = ea >> 6;
+      const int a = ea & 63;
+      const double* Kr = scratch_k + (e * NT + (a * DIM + i)) * (int64_t)NT;   // row (a, i): [j][b]
+      for (int b = lane; b < n_dof; b += 64) {    // (distinct b: distinct positions within an instruction)
+        const int32_t off = pair_pos[(e * n_dof + a) * n_dof + b];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) img[off + j] += Kr[j * n_dof + b];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < len; k += 64) A[beg + k] += grad_factor * img[k];
   }
-  __builtin_amdgcn_wave_barrier();
-  for (int k = lane; k < len; k += 64) A[beg + k] += grad_factor * img[k];
+  // residual entry: the incident elements in adjacency order over the lanes, then a fixed-shape tree
+  double rs = 0.0;
+  for (int64_t t = a_beg + lane; t < a_end; t += 64) {
+    const int32_t ea = adj[t];
+    rs += scratch_r[(int64_t)(ea >> 6) * NT + i * n_dof + (ea & 63)];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) rs += __shfl_down(rs, off, 64);
+  if (lane == 0) r[row] += rs;
 }
 
 inline size_t general_lds_bytes(int dim, int n_dof, int n_q, int grad) {
