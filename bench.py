@@ -97,7 +97,7 @@ def recorded_pmc(workload, world, grad, material):
         current = kernel_sources_sha()
         fresh = t.get("kernel_sources_sha") == current
         return dict(bytes_per_step=t.get("bytes_per_step") if fresh else None,
-                    fp64_pipe_busy_frac=t.get("fp64_pipe_busy_frac") if fresh else None,
+                    pipe=t.get("pipe") if fresh else None,
                     traffic_source=f"profiles/{name} ({t.get('source', 'rocprofv3 --pmc')})",
                     recorded_for_kernel_sources_sha=t.get("kernel_sources_sha"), current_kernel_sources_sha=current,
                     stale=not fresh)
@@ -492,10 +492,12 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras):
                        "how": "HIP events recorded by the library on the launch stream around the kernels of each phase, "
                               "mean of 5 assemblies after the timed region"}},
             check=check)
-        if pmc and pmc.get("fp64_pipe_busy_frac") is not None:
-            result["fp64_pipe"] = {"busy_frac": pmc["fp64_pipe_busy_frac"], "source": pmc["traffic_source"],
-                                   "note": "issued fp64 matrix + vector instruction cycles over the kernel's cycles (PMC), "
-                                           "phase 1; recorded, not live"}
+        if pmc and pmc.get("pipe"):
+            result["fp64_pipe"] = {"per_kernel": pmc["pipe"], "source": pmc["traffic_source"],
+                                   "note": "rocprofv3 PMC per kernel (recorded, not live): mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES over "
+                                           "the kernel's cycles per SIMD (the fp64 matrix and vector instructions share one pipe on "
+                                           "gfx950: DESIGN.md 4.1), instruction counts per element, and where the wave-cycles go "
+                                           "(issuing / issue stalls / waitcnt)"}
         if residual_ms is not None:
             rj = elapsed / steps * 1e3
             result["per_newton_iteration"] = {"ms": rj + 2.0 * residual_ms, "residual_only_ms": residual_ms,

@@ -13,7 +13,7 @@ from _sampling import SampledRows, sample_nodes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("workload,n_random", [("northstar", 24), ("cfg3", 4), ("cfg5", 24)])
+@pytest.mark.parametrize("workload,n_random", [("northstar", 24), ("cfg3", 4), ("cfg4_domain", 24), ("cfg5", 24)])
 def test_sampled_rows_match_the_oracle(workload, n_random):
     import torch
     import bench
@@ -58,3 +58,32 @@ def test_sampled_rows_match_the_oracle(workload, n_random):
         assert beyond_int32 >= 12       # rows whose values start beyond what an int32 offset reaches
     assert worst_r / scale_r < 1e-12
     assert worst_A / scale_A < 1e-11
+
+
+def test_contact_at_cfg4_size_matches_the_oracle():
+    """BASELINE configuration 4's contact face at full size (96 x 96 x 12 p = 2: 9 216 faces on the top face, rigid sphere
+    of SURVEY 8d): the face integrals are cheap enough for the oracle to do ALL of them, so residual, nodal pressures and
+    the complete frozen-pressure tangent are compared (the CSR pattern comes from the library: positions are checked by the
+    oracle's own column search).  PARITY UNPINNED like every contact check (oracle/contact_path.c)."""
+    import bench
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, MortarContact, RigidSphere
+    from oracle import iga, ref_path as rp
+    from test_contact import sphere_over_top
+    n_el, p, _ = bench.WORKLOADS["cfg4_domain"]
+    patch = mimi_amd.BSplinePatch.block(n_el, p)
+    pattern = CSRPattern.of_bspline_patch(patch)              # host arrays
+    rowptr, col = np.asarray(pattern.rowptr), np.asarray(pattern.col)
+    P = iga.Patch.block(n_el, p)
+    body = sphere_over_top(P, 2)
+    Cn = rp.ContactOracle(P, 2, 1, body, penalty=1e4, rowptr=rowptr, col=col)
+    G = MortarContact(RigidSphere(body["center"], body["radius"], 1e4), "contact", pattern, patch, 2, 1).Prepare()
+    u = bench.synthetic_u(patch, scale=0.05)
+    r_o, r_g = np.zeros(P.n_vdofs), np.zeros(P.n_vdofs)
+    A_o, A_g = np.zeros(pattern.nnz), np.zeros(pattern.nnz)
+    Cn.add_boundary_residual_and_grad(u, 1.0, r_o, A_o, rp.TANGENT_EXACT)
+    G.AddBoundaryResidualAndGrad(u, 1.0, r_g, A_g)
+    assert np.abs(r_o).max() > 0 and np.count_nonzero(Cn.pressure) > 100        # the sphere does press on the face
+    assert np.abs(r_g - r_o).max() / np.abs(r_o).max() < 1e-12
+    assert np.allclose(G.AveragePressure(), Cn.pressure, rtol=1e-12, atol=1e-12)
+    assert np.abs(A_g - A_o).max() / np.abs(A_o).max() < 1e-11
