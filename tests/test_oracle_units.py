@@ -151,3 +151,36 @@ def test_assembly_fd_matches_dense_reference_sum():
     r2 = np.zeros(n)
     D.add_domain_residual(u, r2)
     assert np.allclose(r2, rr, rtol=1e-13, atol=1e-12)
+
+
+@pytest.mark.parametrize("n_el,p,matname", [((2, 2, 1), 2, "neohook"), ((2, 1, 1), 3, "neohook"), ((2, 2, 1), 2, "j2")])
+def test_3d_assembled_tangent_is_the_derivative_of_the_assembled_residual(n_el, p, matname):
+    """The 3-D ASSEMBLY map of the oracle (v_dofs, A_ids, CSR positions: what the full-size GPU checks lean on), checked
+    without the oracle's exact tangent formulas: column c of the assembled CSR matrix must be the Richardson-extrapolated
+    central difference of the assembled residual with respect to u_c.  (No reference fixture is 3-D: SURVEY 8c.)"""
+    from oracle import iga, ref_path as rp
+    P = iga.Patch.block(n_el, p)
+    D = rp.DomainOracle(P, oracle_material(matname), n_threads=2)
+    D.set_dt(0.5)
+    u = synthetic_u(P, scale=0.03)
+    r = np.zeros(P.n_vdofs)
+    A = np.zeros(D.nnz)
+    D.add_domain_residual_and_grad(u, 1.0, r, A, rp.TANGENT_EXACT)
+    import scipy.sparse as sp
+    K = sp.csr_matrix((A, D.col, D.rowptr), shape=(P.n_vdofs, P.n_vdofs)).toarray()
+
+    def R(v):
+        out = np.zeros(P.n_vdofs)
+        D.add_domain_residual(v, out)
+        return out
+
+    rng = np.random.default_rng(0)
+    cols = rng.choice(P.n_vdofs, size=12, replace=False)
+    h = 1e-4
+    for c in cols:
+        e = np.zeros(P.n_vdofs)
+        e[c] = 1.0
+        d1 = (R(u + h * e) - R(u - h * e)) / (2 * h)
+        d2 = (R(u + 0.5 * h * e) - R(u - 0.5 * h * e)) / h
+        col = (4 * d2 - d1) / 3
+        assert np.abs(K[:, c] - col).max() < 2e-7 * np.abs(K).max(), (c, np.abs(K[:, c] - col).max(), np.abs(K).max())
