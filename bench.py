@@ -27,6 +27,12 @@ import subprocess
 import sys
 import time
 
+# the CPUs this process may use, read BEFORE any OpenMP runtime is loaded: with OMP_PROC_BIND the runtime pins the
+# initial thread to one place, after which the affinity mask says "1 CPU"
+try:
+    _AFFINITY_AT_START = len(os.sched_getaffinity(0))
+except (AttributeError, OSError):
+    _AFFINITY_AT_START = os.cpu_count() or 1
 # OMP_PROC_BIND=close for the CPU baseline; the OpenMP runtime reads it when it is loaded (import torch)
 os.environ.setdefault("OMP_PROC_BIND", "close")
 
@@ -187,12 +193,9 @@ def physical_cores():
         pass
     physical = len(pairs) or (os.cpu_count() or 1)
     n, why = physical, f"{physical} physical cores"
-    try:
-        aff = len(os.sched_getaffinity(0))
-        if aff < n:
-            n, why = aff, f"affinity mask of {aff} CPUs ({physical} physical cores)"
-    except (AttributeError, OSError):
-        pass
+    aff = _AFFINITY_AT_START
+    if aff < n:
+        n, why = aff, f"affinity mask of {aff} CPUs ({physical} physical cores)"
     try:
         with open("/sys/fs/cgroup/cpu.max") as f:
             quota, period = f.read().split()
@@ -252,6 +255,8 @@ def cpu_baseline(p, material, threads=None, n_el=None, sweep=False):
         D.n_threads = nt
         return _median_time(lambda: D.add_domain_residual_and_grad(u, 1.0, r, A, mode), 3, 10, budget)
 
+    sys.stderr.write(f"bench.py: CPU baseline on {threads} threads ({'x'.join(map(str, n_el))} sample) ...\n")
+    sys.stderr.flush()
     t_fd, n_fd = timed(rp.TANGENT_FD, threads, 20.0)
     t_ex, n_ex = timed(rp.TANGENT_EXACT, threads, 8.0)
     t_none, _ = timed(rp.TANGENT_NONE, threads, 3.0)
@@ -271,9 +276,11 @@ def cpu_baseline(p, material, threads=None, n_el=None, sweep=False):
                                     "-- the part of an assembly that grows with the thread count")
     if sweep:
         out["thread_sweep"] = {}
-        for nt in sorted({1, 4, 8, 16, 32, 64, 128, threads}):
+        for nt in sorted({1, 4, 8, 16, 32, 128, threads}):
             if nt > (os.cpu_count() or 1):
                 continue
+            sys.stderr.write(f"bench.py: CPU baseline sweep, {nt} threads ...\n")
+            sys.stderr.flush()
             if nt == 1 and P.n_el > 4096:
                 continue                      # one thread on the full sample takes minutes: see the small-sample sweep
             tf, _ = timed(rp.TANGENT_FD, nt, 12.0)

@@ -618,7 +618,10 @@ __global__ __launch_bounds__(256) void tp3_gather_kernel(TensorArgs p, int64_t n
       const int a2 = A2 - ez;
       const bool tail = a2 > 0 && ez == last_ez;
       // EYB element rows (ey) x 4 elements (ex) per batch: their loads are in flight together
-      constexpr int EYB = 2;
+#ifndef T3_EYB
+#define T3_EYB 1
+#endif
+      constexpr int EYB = T3_EYB;
       for (int ey0 = ey_lo; ey0 <= ey_hi; ey0 += EYB) {
         double v[EYB * NB][3];
 #pragma unroll
