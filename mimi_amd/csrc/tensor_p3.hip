@@ -617,45 +617,57 @@ __global__ __launch_bounds__(256) void tp3_gather_kernel(TensorArgs p, int64_t n
     for (int ez = ez_lo; ez <= ez_hi; ++ez) {
       const int a2 = A2 - ez;
       const bool tail = a2 > 0 && ez == last_ez;
-      // EYB element rows (ey) x 4 elements (ex) per batch: their loads are in flight together
-#ifndef T3_EYB
-#define T3_EYB 1
-#endif
-      constexpr int EYB = T3_EYB;
-      for (int ey0 = ey_lo; ey0 <= ey_hi; ey0 += EYB) {
-        double v[EYB * NB][3];
+      if (a2 == 0) {
+        // whole rows (192 values = three loads per element): the four elements along x of one ey in flight together
+        // (more in flight costs registers, i.e. resident waves: measured 11.1 / 12.2 / 14.8 ms for 1 / 2 / 4 element rows)
+        for (int ey = ey_lo; ey <= ey_hi; ++ey) {
+          double v[NB][3];
 #pragma unroll
-        for (int c = 0; c < EYB * NB; ++c) {
-          const int ex = ex_lo + c % NB, ey = ey0 + c / NB;
+          for (int c = 0; c < NB; ++c) {
+            const int ex = ex_lo + c;
+            const bool in = ex <= ex_hi;
+            const int exx = in ? ex : ex_lo;
+            const double* row = p.scratch_k + (elem(exx, ey, ez) * 3 + I) * (int64_t)T3_PIECE + ((A0 - exx) + NB * (A1 - ey)) * 192 + lane;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[c][j] = in ? row[j * 64] : 0.0;
+          }
+#pragma unroll
+          for (int c = 0; c < NB; ++c) {
+            const int ex = ex_lo + c;
+            if (ex <= ex_hi) {
+              const int tb = 3 * ((ex - lo0) + w0 * ((ey - lo1) + w1 * (ez - lo2)));
+#pragma unroll
+              for (int j = 0; j < 3; ++j) img[tb + toff_full + j] += v[c][j];
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      } else {
+        // the 48 values at b2 = 0 (one load per element): all 16 elements of this ez in flight together
+        double v[NB * NB];
+#pragma unroll
+        for (int c = 0; c < NB * NB; ++c) {
+          const int ex = ex_lo + c % NB, ey = ey_lo + c / NB;
           const bool in = ex <= ex_hi && ey <= ey_hi;
           const int exx = in ? ex : ex_lo, eyy = in ? ey : ey_lo;
           const double* piece = p.scratch_k + (elem(exx, eyy, ez) * 3 + I) * (int64_t)T3_PIECE;
-          const int a01 = (A0 - exx) + NB * (A1 - eyy);
-          if (a2 == 0) {
-            const double* row = piece + a01 * 192 + lane;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) v[c][j] = in ? row[j * 64] : 0.0;
-          } else {
-            const int ar = a01 + 16 * (a2 - 1);
-            v[c][0] = (in && lane < 48) ? piece[3072 + ar * 48 + lane] : 0.0;
-            v[c][1] = v[c][2] = 0.0;
-          }
+          const int ar = (A0 - exx) + NB * (A1 - eyy) + 16 * (a2 - 1);
+          v[c] = (in && lane < 48) ? piece[3072 + ar * 48 + lane] : 0.0;
         }
 #pragma unroll
-        for (int c = 0; c < EYB * NB; ++c) {
-          const int ex = ex_lo + c % NB, ey = ey0 + c / NB;
-          if (ex <= ex_hi && ey <= ey_hi) {
+        for (int c = 0; c < NB * NB; ++c) {
+          const int ex = ex_lo + c % NB, ey = ey_lo + c / NB;
+          if (ex <= ex_hi && ey <= ey_hi && lane < 48) {
             const int tb = 3 * ((ex - lo0) + w0 * ((ey - lo1) + w1 * (ez - lo2)));
-            if (a2 == 0) {
-#pragma unroll
-              for (int j = 0; j < 3; ++j) img[tb + toff_full + j] += v[c][j];
-            } else if (lane < 48) {
-              img[tb + toff_b20] += v[c][0];
-            }
+            img[tb + toff_b20] += v[c];
           }
           __builtin_amdgcn_wave_barrier();
         }
-        if (tail) {
+      }
+      constexpr int EYB = 1;
+      for (int ey0 = ey_lo; tail && ey0 <= ey_hi; ey0 += EYB) {
+        double v[EYB * NB][3];
+        {
           // the column ends inside the support of A: the pairs (a2 >= 1, b2 >= 1) were kept by its last element
 #pragma unroll
           for (int c = 0; c < EYB * NB; ++c) {
