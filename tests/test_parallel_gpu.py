@@ -9,6 +9,31 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _run_ranks(ctx, procs, q, world):
+    """start the ranks, collect one result each; whatever happens, no rank is left holding the GPU"""
+    for pr in procs:
+        pr.start()
+    try:
+        results = [q.get(timeout=300) for _ in range(world)]
+        for pr in procs:
+            pr.join(timeout=60)
+        assert all(pr.exitcode == 0 for pr in procs), [pr.exitcode for pr in procs]
+        return results
+    finally:
+        for pr in procs:
+            if pr.is_alive():
+                pr.terminate()
+                pr.join(timeout=10)
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -97,13 +122,9 @@ def test_slabs_on_one_gpu(world, n_el, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_el, mode, q)) for r in range(world)]
-    for pr in procs:
-        pr.start()
-    results = [q.get(timeout=300) for _ in range(world)]
-    for pr in procs:
-        pr.join(timeout=60)
+    results = _run_ranks(ctx, procs, q, world)
     assert all(ok is True for _, ok, _ in results), results
     if mode.startswith("owner"):
         assert sum(n for _, _, n in results) == int(np.prod([n + 2 for n in n_el]))
@@ -178,11 +199,7 @@ def test_sharded_contact_on_one_gpu(world, n_el):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31700 + (os.getpid() % 2000)
+    port = _free_port()
     procs = [ctx.Process(target=_contact_worker, args=(r, world, port, n_el, q)) for r in range(world)]
-    for pr in procs:
-        pr.start()
-    results = [q.get(timeout=300) for _ in range(world)]
-    for pr in procs:
-        pr.join(timeout=60)
+    results = _run_ranks(ctx, procs, q, world)
     assert all(ok is True for _, ok, _ in results), results
