@@ -169,8 +169,12 @@ static void ensure_pair_pos(mimi_hip_domain_s* h) {
     hipLaunchKernelGGL(structured_col_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, h->stream, S, n_rows, h->rowptr,
                        col.ptr, 0, h->status_dev);
   } else {
-    hipLaunchKernelGGL(permuted_col_kernel, dim3((unsigned)((h->n_nodes + 3) / 4)), dim3(256), 0, h->stream, S, (int64_t)h->n_nodes,
-                       h->node_ids.ptr, h->rowptr, h->nbr_pos.ptr, col.ptr);
+    if (h->degree[0] == 3)
+      hipLaunchKernelGGL((permuted_col_kernel<uint16_t, 343>), dim3((unsigned)((h->n_nodes + 3) / 4)), dim3(256), 0, h->stream, S,
+                         (int64_t)h->n_nodes, h->node_ids.ptr, h->rowptr, h->nbr_pos16.ptr, col.ptr);
+    else
+      hipLaunchKernelGGL((permuted_col_kernel<unsigned char, 125>), dim3((unsigned)((h->n_nodes + 3) / 4)), dim3(256), 0, h->stream, S,
+                         (int64_t)h->n_nodes, h->node_ids.ptr, h->rowptr, h->nbr_pos.ptr, col.ptr);
   }
   MH_HIP(hipGetLastError());
   build_pair_pos(h, col.ptr);
@@ -629,7 +633,8 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
     }
     // permuted numbering (node_ids given): is the caller's CSR the permuted structured pattern?
     h->structured_perm = false;
-    if (p->node_ids && dim == 3 && h->degree[0] <= 2 && h->degree[1] <= 2 && h->degree[2] <= 2 &&
+    const bool degree3 = dim == 3 && h->degree[0] == 3 && h->degree[1] == 3 && h->degree[2] == 3;
+    if (p->node_ids && dim == 3 && ((h->degree[0] <= 2 && h->degree[1] <= 2 && h->degree[2] <= 2) || degree3) &&
         !(getenv("MIMI_HIP_NO_STRUCTURED") && getenv("MIMI_HIP_NO_STRUCTURED")[0] == '1')) {
       SparsityDev S{};
       S.dim = dim;
@@ -644,10 +649,16 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
         col_tmp.assign(p->csr_col, h->nnz, h->stream);
         col_dev = col_tmp.ptr;
       }
-      h->nbr_pos.resize((size_t)n_nodes * 125);
       MH_HIP(hipMemsetAsync(h->status_dev, 0, sizeof(int), h->stream));
-      hipLaunchKernelGGL(permuted_window_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, h->stream, S, (int64_t)n_nodes,
-                         h->node_ids.ptr, h->rowptr, col_dev, h->nbr_pos.ptr, h->status_dev);
+      if (degree3) {
+        h->nbr_pos16.resize((size_t)n_nodes * 343);
+        hipLaunchKernelGGL((permuted_window_kernel<uint16_t, 343>), dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, h->stream, S,
+                           (int64_t)n_nodes, h->node_ids.ptr, h->rowptr, col_dev, h->nbr_pos16.ptr, h->status_dev);
+      } else {
+        h->nbr_pos.resize((size_t)n_nodes * 125);
+        hipLaunchKernelGGL((permuted_window_kernel<unsigned char, 125>), dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, h->stream, S,
+                           (int64_t)n_nodes, h->node_ids.ptr, h->rowptr, col_dev, h->nbr_pos.ptr, h->status_dev);
+      }
       MH_HIP(hipGetLastError());
       MH_HIP(hipMemcpyAsync(h->status_host, h->status_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
       MH_HIP(hipStreamSynchronize(h->stream));

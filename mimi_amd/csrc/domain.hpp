@@ -37,7 +37,8 @@ struct mimi_hip_domain_s {
   mimi_hip::DeviceBuffer<int64_t> node_ids;  // lexicographic -> global, empty = identity
   bool structured_csr = false;               // CSR positions computable arithmetically
   bool structured_perm = false;              // permuted numbering whose CSR rows are the permuted structured pattern
-  mimi_hip::DeviceBuffer<unsigned char> nbr_pos;  // [n_nodes][125] rank of each window neighbour inside the row (structured_perm)
+  mimi_hip::DeviceBuffer<unsigned char> nbr_pos;  // [n_nodes][125] rank of each window neighbour inside the row (structured_perm, p <= 2)
+  mimi_hip::DeviceBuffer<uint16_t> nbr_pos16;     // [n_nodes][343] the same for degree 3
   bool first_is_identity = false;            // span e's first basis function is e (no repeated interior knots)
   mimi_hip::DeviceBuffer<double> scratch_k, scratch_r, scratch_pt, scratch_tail;  // two-phase tangent path
 

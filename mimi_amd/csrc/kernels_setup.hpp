@@ -223,11 +223,13 @@ __global__ void structured_col_kernel(SparsityDev S, int64_t n_rows, const int64
 // Permuted numbering (node_ids = lexicographic -> caller's node id, e.g. MFEM's NURBS dof map): the CSR row of
 // node perm[A] holds the columns perm[B] of A's (2p+1)^3 window in ascending order of perm[B].  One wave per
 // lexicographic node A: nbr_pos[A][t] = rank of perm[B_t] inside the window (t = lexicographic window index),
-// and a check that the caller's CSR is exactly that pattern.  3-D, p <= 2 (window <= 125 entries, uint8 ranks).
+// and a check that the caller's CSR is exactly that pattern.  3-D; RankT / WMAX: uint8 ranks in windows of <= 125 = 5^3
+// entries (p <= 2), uint16 ranks in windows of <= 343 = 7^3 (p = 3).
+template<typename RankT, int WMAX>
 __global__ void permuted_window_kernel(SparsityDev S, int64_t n_nodes, const int64_t* __restrict__ perm,
                                        const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                       unsigned char* __restrict__ nbr_pos, int* __restrict__ mismatch) {
-  __shared__ int64_t vals_all[4][128];
+                                       RankT* __restrict__ nbr_pos, int* __restrict__ mismatch) {
+  __shared__ int64_t vals_all[4][(WMAX + 7) / 8 * 8];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t A = (int64_t)blockIdx.x * 4 + wave;
   if (A >= n_nodes) return;
@@ -251,7 +253,7 @@ __global__ void permuted_window_kernel(SparsityDev S, int64_t n_nodes, const int
     const int64_t v = vals[t];
     int rank = 0;
     for (int s2 = 0; s2 < nw; ++s2) rank += vals[s2] < v ? 1 : 0;
-    nbr_pos[A * 125 + t] = (unsigned char)rank;
+    nbr_pos[A * WMAX + t] = (RankT)rank;
     for (int i = 0; i < 3; ++i) {
       const int64_t row = gA * 3 + i;
       const int64_t start = rowptr[row];
@@ -267,8 +269,9 @@ __global__ void permuted_window_kernel(SparsityDev S, int64_t n_nodes, const int
 
 // Columns of the permuted structured pattern from the window ranks (the inverse of permuted_window_kernel's check):
 // one wave per lexicographic node A, col[rowptr[perm[A] 3 + i] + 3 rank(t) + j] = perm[B_t] 3 + j.
+template<typename RankT, int WMAX>
 __global__ void permuted_col_kernel(SparsityDev S, int64_t n_nodes, const int64_t* __restrict__ perm,
-                                    const int64_t* __restrict__ rowptr, const unsigned char* __restrict__ nbr_pos,
+                                    const int64_t* __restrict__ rowptr, const RankT* __restrict__ nbr_pos,
                                     int32_t* __restrict__ col) {
   const int lane = threadIdx.x & 63;
   const int64_t A = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -285,7 +288,7 @@ __global__ void permuted_col_kernel(SparsityDev S, int64_t n_nodes, const int64_
     const int t0 = t % w[0], t1 = (t / w[0]) % w[1], t2 = t / (w[0] * w[1]);
     const int64_t B = (lo[0] + t0) + (int64_t)S.n[0] * ((lo[1] + t1) + (int64_t)S.n[1] * (lo[2] + t2));
     const int64_t v = perm[B];
-    const int rank = nbr_pos[A * 125 + t];
+    const int rank = nbr_pos[A * WMAX + t];
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) col[rowptr[gA * 3 + i] + 3 * rank + j] = (int32_t)(v * 3 + j);
   }

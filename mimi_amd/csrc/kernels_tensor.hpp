@@ -64,6 +64,7 @@ struct TensorArgs {
   int seg_len;               // elements per unit along the walked direction (box_n[2] = whole columns); phase 2: an
                              // element at the end of a unit holds the carried rows (third part of its pieces)
   const unsigned char* nbr_pos;  // two-phase path, permuted numbering: [n_nodes][125] positions inside a CSR row
+  const uint16_t* nbr_pos16; // p = 3 two-phase path, permuted numbering: [n_nodes][343] positions inside a CSR row
   double* scratch_tail;      // p = 3 two-phase path: [column][3][48*144] carried rows of the last element of a column
 };
 
@@ -768,6 +769,7 @@ inline TensorArgs tensor_args(mimi_hip_domain_s* h, const double* u, double* r, 
   a.prof = h->prof_dev;
   a.perm = h->structured_perm ? h->node_ids.ptr : nullptr;
   a.nbr_pos = h->structured_perm ? h->nbr_pos.ptr : nullptr;
+  a.nbr_pos16 = h->structured_perm ? h->nbr_pos16.ptr : nullptr;
   return a;
 }
 

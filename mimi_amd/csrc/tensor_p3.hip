@@ -694,8 +694,15 @@ __global__ __launch_bounds__(256) void tp3_gather_kernel(TensorArgs p, int64_t n
       }
     }
     __builtin_amdgcn_wave_barrier();
-    double* dst = p.A + p.rowptr[A * 3 + I];
-    for (int t = lane; t < L; t += 64) dst[t] += p.grad_factor * img[t];
+    // u, r and the CSR may live in the caller's node numbering (perm: lexicographic -> caller's id, e.g. MFEM's NURBS dof
+    // map): row perm[A], and entry t of the lexicographic window at the rank of its permuted column inside that row
+    double* dst = p.A + p.rowptr[(p.perm ? p.perm[A] : A) * 3 + I];
+    if (p.perm) {
+      const uint16_t* pos = p.nbr_pos16 + A * 343;
+      for (int t = lane; t < L; t += 64) dst[3 * (int)pos[t / 3] + t % 3] += p.grad_factor * img[t];
+    } else {
+      for (int t = lane; t < L; t += 64) dst[t] += p.grad_factor * img[t];
+    }
   }
   // residual row: lane = element (dz, dy, dx) of the 4 x 4 x 4 neighbourhood, fixed-shape tree sum
   {
@@ -707,16 +714,16 @@ __global__ __launch_bounds__(256) void tp3_gather_kernel(TensorArgs p, int64_t n
     double rs = in ? p.scratch_r[(el * 3 + I) * ND + a] : 0.0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) rs += __shfl_down(rs, off, 64);
-    if (lane == 0) p.r[A * 3 + I] += rs;
+    if (lane == 0) p.r[(p.perm ? p.perm[A] : A) * 3 + I] += rs;
   }
 }
 
 }  // namespace
 
 bool tensor_p3_ready(const mimi_hip_domain_s* h) {
-  // lexicographic numbering with the structured pattern, no repeated interior knots
+  // the structured pattern (lexicographic numbering, or a permuted one with its window ranks), no repeated interior knots
   return h->dim == 3 && h->degree[0] == 3 && h->degree[1] == 3 && h->degree[2] == 3 && h->nq1[0] == 5 &&
-         h->structured_csr && h->first_is_identity;
+         (h->structured_csr || h->structured_perm) && h->first_is_identity;
 }
 
 void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {

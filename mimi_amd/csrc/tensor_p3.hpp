@@ -5,8 +5,8 @@
 
 namespace mimi_hip {
 
-// lexicographic numbering with the structured CSR pattern, uniform degree 3, 5 Gauss points per direction,
-// no repeated interior knots
+// the structured CSR pattern in lexicographic or permuted (node_ids) numbering, uniform degree 3, 5 Gauss points per
+// direction, no repeated interior knots
 bool tensor_p3_ready(const mimi_hip_domain_s* h);
 // grad 0: r += R(u); 1: also A += grad_factor K(u)
 void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a);

@@ -226,16 +226,17 @@ def test_element_boxes_p3_general_path(monkeypatch):
 
 
 @pytest.mark.parametrize("matname", ["neohook", "j2"])
-def test_permuted_node_numbering(matname):
+@pytest.mark.parametrize("p", [2, 3])
+def test_permuted_node_numbering(matname, p):
     """node_ids = lexicographic -> caller's node id (what MFEM's NURBS dof map is for the reference): u, r and
-    the CSR live in the caller's numbering; the two-phase kernels must still be taken (info 6 == 2)."""
+    the CSR live in the caller's numbering; the two-phase kernels (degree 2 and degree 3) must still be taken (info 6 == 2)."""
     import scipy.sparse as sp
     import mimi_amd
     from mimi_amd import _capi
     from mimi_amd.integrators import CSRPattern, NonlinearSolid
     from oracle import iga, ref_path as rp
-    n_el = (5, 4, 4)
-    P = iga.Patch.block(n_el, 2)
+    n_el = (5, 4, 4) if p == 2 else (4, 3, 5)
+    P = iga.Patch.block(n_el, p)
     D = rp.DomainOracle(P, oracle_material(matname), n_threads=2)
     D.set_dt(0.5)
     u = synthetic_u(P, scale=0.05 if matname == "neohook" else 0.02)
@@ -251,7 +252,7 @@ def test_permuted_node_numbering(matname):
     dst = np.empty(D.nnz, dtype=np.int64)
     dst[(S.data - 1).astype(np.int64)] = np.arange(D.nnz)
     pattern = CSRPattern(S.indptr.astype(np.int64), S.indices.astype(np.int32), D.nnz)
-    patch = mimi_amd.BSplinePatch.block(n_el, 2)
+    patch = mimi_amd.BSplinePatch.block(n_el, p)
     G = NonlinearSolid("domain", product_material(matname), pattern, patch=patch, node_ids=perm).Prepare()
     assert G.path_ == 1
     assert _capi.lib().mimi_hip_domain_info(G._h, 6) == 2
