@@ -12,6 +12,7 @@
 #include "kernels_tensor_wgs.hpp"
 #include "kernels_tensor_wgsym.hpp"
 #include "kernels_tensor_residual.hpp"
+#include "kernels_tensor_small.hpp"
 #include "tensor_dispatch.hpp"
 
 #include <algorithm>
@@ -374,6 +375,56 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a_
   gather();
 }
 
+// small elements on the tensor path (kernels_tensor_small.hpp): element kernel from the 1-D tables, then the general
+// path's gather (adjacency, pair positions).  mode 0 residual, 1 residual + tangent, 2 post time advance
+template<int DIM, int P>
+static void launch_tensor_small_dp(mimi_hip_domain_s* h, int mode, TensorArgs a) {
+  using S = SmallShape<DIM, P>;
+  const bool other = !material_closed_form(h->mat.m.kind);
+  const size_t lds = (size_t)4 * (mode == 1 ? S::total1 : S::total0) * sizeof(double);
+  const unsigned blocks = (unsigned)((h->n_el + 3) / 4);
+  auto go = [&](auto kernel) {
+    if (lds > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), lds, h->stream, a, (int)h->n_el);
+    MH_HIP(hipGetLastError());
+  };
+  if (mode == 0) { if (other) go(tensor_small_kernel<DIM, P, 1, 0>); else go(tensor_small_kernel<DIM, P, 0, 0>); }
+  else if (mode == 1) { if (other) go(tensor_small_kernel<DIM, P, 1, 1>); else go(tensor_small_kernel<DIM, P, 0, 1>); }
+  else { if (other) go(tensor_small_kernel<DIM, P, 1, 2>); else go(tensor_small_kernel<DIM, P, 0, 2>); }
+}
+
+static bool launch_tensor_small(mimi_hip_domain_s* h, int mode, const double* u, double* r, double* A, double gf) {
+  TensorArgs a = tensor_args(h, u, r, A, gf);
+  if (mode != 2) {
+    ensure_pair_pos(h);
+    if (!ensure_general_two_phase(h, mode == 1)) return false;     // (blocks do not fit: the caller takes the general kernels)
+    a.scratch_k = h->scratch_k.ptr;
+    a.scratch_r = h->scratch_r.ptr;
+  }
+  const int p = h->degree[0];
+  if (h->dim == 2) {
+    if (p == 1) launch_tensor_small_dp<2, 1>(h, mode, a);
+    else if (p == 2) launch_tensor_small_dp<2, 2>(h, mode, a);
+    else launch_tensor_small_dp<2, 3>(h, mode, a);
+  } else {
+    launch_tensor_small_dp<3, 1>(h, mode, a);
+  }
+  if (mode == 2) return true;
+  const int64_t n_rows = h->n_vdofs;
+  const unsigned gblocks = (unsigned)((n_rows + GG_WAVES - 1) / GG_WAVES);
+  if (h->dim == 2) {
+    auto kernel = mode == 1 ? general_gather_kernel<2, 1> : general_gather_kernel<2, 0>;
+    hipLaunchKernelGGL(kernel, dim3(gblocks), dim3(64 * GG_WAVES), 0, h->stream, n_rows, h->n_dof, h->rowptr, h->adj_ptr.ptr, h->adj.ptr,
+                       h->pair_pos.ptr, h->scratch_k.ptr, h->scratch_r.ptr, gf, A, r);
+  } else {
+    auto kernel = mode == 1 ? general_gather_kernel<3, 1> : general_gather_kernel<3, 0>;
+    hipLaunchKernelGGL(kernel, dim3(gblocks), dim3(64 * GG_WAVES), 0, h->stream, n_rows, h->n_dof, h->rowptr, h->adj_ptr.ptr, h->adj.ptr,
+                       h->pair_pos.ptr, h->scratch_k.ptr, h->scratch_r.ptr, gf, A, r);
+  }
+  MH_HIP(hipGetLastError());
+  return true;
+}
+
 static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double* A, double gf, bool with_grad) {
   MH_HIP(hipSetDevice(h->device));
   if (!u || !r || (with_grad && !A)) fail("null vector argument");
@@ -384,7 +435,9 @@ static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double*
   const int grad = !with_grad ? 0 : (h->tangent_mode == MIMI_HIP_TANGENT_REFERENCE_FD ? 2 : 1);
   // (the colour-partitioned tensor kernel, the fallback when the CSR is not the structured pattern, has closed-form
   // materials only: the other materials then take the general kernels)
-  if (tensor_usable(h) && grad != 2 && (material_closed_form(h->mat.m.kind) || two_phase_supported(h))) {
+  if (tensor_small(h) && grad != 2 && launch_tensor_small(h, grad, mu.dev, mr.dev, mA.dev, gf)) {
+    // (2-D, degree 1: element kernel from the 1-D tables + the general gather)
+  } else if (tensor_usable(h) && !tensor_small(h) && grad != 2 && (material_closed_form(h->mat.m.kind) || two_phase_supported(h))) {
     launch_tensor(h, grad, mu.dev, mr.dev, mA.dev, gf);
   } else {
     ensure_general_tables(h);
@@ -668,7 +721,7 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
     // degree 3 has the two-phase tensor kernels only: anything else about the handle (numbering, pattern) -> general path
     if (h->path == 1 && !tensor_usable(h.get())) h->path = 0;
     // pair positions now unless this handle will run the two-phase kernels (then on demand, ensure_pair_pos)
-    if (!(tensor_usable(h.get()) && two_phase_supported(h.get()))) build_pair_pos(h.get(), p->csr_col);
+    if (!(tensor_usable(h.get()) && two_phase_supported(h.get())) || tensor_small(h.get())) build_pair_pos(h.get(), p->csr_col);
     init_state(h.get());
     MH_HIP(hipStreamSynchronize(h->stream));
     *out = h.release();
@@ -737,7 +790,9 @@ int mimi_hip_domain_post_time_advance(mimi_hip_domain_t h, const double* u) {
     if (!material_has_state(h->mat.m.kind)) return;  // has_states_ == false (nonlinear_solid.cpp:182-183)
     MH_HIP(hipSetDevice(h->device));
     Mirror<double> mu = Mirror<double>::in(u, h->n_vdofs, h->stage_u, h->stream);
-    if (h->path == 1) {
+    if (tensor_small(h)) {
+      launch_tensor_small(h, 2, mu.dev, nullptr, nullptr, 0.0);
+    } else if (h->path == 1) {
       launch_tensor_post(h, mu.dev);
     } else {
       ensure_general_tables(h);

@@ -727,10 +727,13 @@ __global__ __launch_bounds__(256) void tensor_post_kernel(TensorArgs p, int n_el
 }
 
 inline bool tensor_supported(int dim, const int* degree, int nq) {
-  if (dim != 3) return false;
-  if (degree[0] != degree[1] || degree[1] != degree[2]) return false;
-  if (degree[0] != 2 && degree[0] != 3) return false;   // p = 3: tensor_p3.hip
-  return nq == degree[0] + 2;
+  // 3-D degree 2 (kernels_tensor_wgs*.hpp), 3-D degree 3 (tensor_p3.hip); 2-D degree 1..3 and 3-D degree 1
+  // (kernels_tensor_small.hpp)
+  for (int d = 1; d < dim; ++d)
+    if (degree[d] != degree[0]) return false;
+  if (nq != degree[0] + 2) return false;
+  if (dim == 3) return degree[0] >= 1 && degree[0] <= 3;
+  return dim == 2 && degree[0] >= 1 && degree[0] <= 3;
 }
 
 inline TensorArgs tensor_args(mimi_hip_domain_s* h, const double* u, double* r, double* A, double gf) {

@@ -2,6 +2,7 @@
 #pragma once
 
 #include "kernels_tensor.hpp"
+#include "kernels_tensor_small.hpp"
 #include "tensor_p3.hpp"
 
 namespace mimi_hip {
@@ -13,7 +14,9 @@ inline void launch_tensor_residual(mimi_hip_domain_s* h, TensorArgs a);         
 static void ensure_pair_pos(mimi_hip_domain_s* h);                                // domain.hip
 
 // can this handle's assembly run on the tensor kernels?  (p = 3 has the two-phase kernels only)
-inline bool tensor_usable(const mimi_hip_domain_s* h) { return h->path == 1 && (h->degree[0] != 3 || tensor_p3_ready(h)); }
+inline bool tensor_usable(const mimi_hip_domain_s* h) {
+  return h->path == 1 && (tensor_small_shape(h->dim, h->degree, h->nq1[0]) || h->degree[0] != 3 || tensor_p3_ready(h));
+}
 
 inline void launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, double* r, double* A, double gf) {
   TensorArgs a = tensor_args(h, u, r, A, gf);

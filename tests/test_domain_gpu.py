@@ -75,8 +75,8 @@ def test_residual_and_tangent_parity(case, matname, creator):
     from oracle import ref_path as rp
     n_el, p, lengths = case
     P, D, G = make_pair(n_el, p, lengths, matname, creator)
-    # structured 3-D p=2 and p=3 patches must take the sum-factorised (tensor) kernels
-    assert G.path_ == (1 if (creator == "bspline" and len(n_el) == 3 and p in (2, 3)) else 0)
+    # B-spline patches (2-D and 3-D, degree <= 3) must take the sum-factorised (tensor) kernels, flat tables the general ones
+    assert G.path_ == (1 if creator == "bspline" else 0)
     dt = 0.5
     D.set_dt(dt)
     G.dt_ = dt
@@ -382,7 +382,7 @@ def test_tensor_product_nurbs_weights(n_el, p, matname):
     patch = mimi_amd.BSplinePatch(P.p, P.knots, ctrl, weights)
     G = NonlinearSolid("domain", product_material(matname), pattern, patch=patch).Prepare()
     G.dt_ = 0.5
-    assert G.path_ == (1 if (len(n_el) == 3 and p in (2, 3)) else 0)
+    assert G.path_ == 1
     u = synthetic_u(P, scale=0.03)
     r_o, A_o = np.zeros(P.n_vdofs), np.zeros(D.nnz)
     r_g, A_g = np.zeros(P.n_vdofs), np.zeros(D.nnz)
@@ -449,15 +449,19 @@ def test_default_stream_follows_torch():
         G.AddDomainResidual(tu.float(), tr)
 
 
-@pytest.mark.parametrize("case", [((40, 30), 2), ((24, 20), 3), ((12, 10, 8), 1)], ids=["2d-p2", "2d-p3", "3d-p1"])
-def test_general_path_is_bitwise_reproducible(case):
-    """the general kernels (every 2-D mesh, p = 1, flat tables: what the reference's own examples are) store element blocks
-    and gather them per CSR row: no atomics, so two assemblies of the same input agree bit for bit -- in both tangent modes
-    and for the residual-only call -- and match the oracle"""
+@pytest.mark.parametrize("path", ["general", "tensor"])
+@pytest.mark.parametrize("case", [((40, 30), 2), ((24, 20), 3), ((12, 10, 8), 1), ((9, 7), 1)], ids=["2d-p2", "2d-p3", "3d-p1", "2d-p1"])
+def test_small_elements_are_bitwise_reproducible(case, path, monkeypatch):
+    """2-D meshes and degree 1 (what the reference's own examples are): on the general kernels (flat tables) and on the
+    small-element tensor kernel (1-D tables, sum factorisation) alike the element blocks are stored and gathered per CSR
+    row: no atomics, so two assemblies of the same input agree bit for bit -- in both tangent modes and for the residual-only
+    call -- and match the oracle"""
     from oracle import ref_path as rp
     n_el, p = case
+    if path == "general":
+        monkeypatch.setenv("MIMI_HIP_FORCE_GENERAL", "1")
     P, D, G = make_pair(n_el, p, None, "neohook", "bspline")
-    assert G.path_ == 0
+    assert G.path_ == (0 if path == "general" else 1)
     u = synthetic_u(P)
     outs = []
     for rep in range(3):

@@ -23,7 +23,7 @@ def test_other_materials_parity(matname, block):
     n_el, p, lengths = block
     P, D, G = make_pair(n_el, p, lengths, matname, "bspline")
     # 3-D p = 2: the two-phase tensor kernels through the tangent record of the material pre-pass; else general kernels
-    assert G.path_ == (1 if (len(n_el) == 3 and p in (2, 3)) else 0)     # 3-D p = 2, 3: tensor kernels through the tangent record
+    assert G.path_ == 1     # tensor kernels (3-D p = 2, 3 through the tangent record; 2-D: the small-element kernel)
     D.set_dt(0.5)
     G.dt_ = 0.5
     u = synthetic_u(P, scale=0.04)
