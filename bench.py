@@ -51,6 +51,9 @@ WORKLOADS = {
     "cfg3_neo": ((128, 128, 16), 3, "neohookean"),
     "cfg3_small": ((32, 32, 16), 3, "j2"),
     "cfg4_domain": ((96, 96, 12), 2, "neohookean"),
+    # BASELINE configuration 4: the same block with the rigid sphere of SURVEY 8d pressing on its top face (the step is the
+    # domain residual+Jacobian plus the contact residual+Jacobian; for N > 1 the contact faces follow their element slab)
+    "cfg4": ((96, 96, 12), 2, "neohookean"),
     # the reference's other materials (tangent-record route): measured for DESIGN.md only
     "cfg2_stvk": ((64, 64, 8), 2, "stvk"),
     "cfg2_j2linear": ((64, 64, 8), 2, "j2linear"),
@@ -361,10 +364,25 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras):
     integ = make_integrator(interior_box)
     boundary = [make_integrator(b) for b in boundary_boxes]
 
-    u = torch.from_numpy(synthetic_u(patch)).to(dev)
+    u = torch.from_numpy(synthetic_u(patch, scale=0.01 if workload == "cfg4" else 0.05)).to(dev)
     r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
     A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
     exchange = parallel.InterfaceExchange(shard, r, A, dev, mode="owner") if world > 1 else None
+    contact = None
+    if workload == "cfg4":
+        from mimi_amd.integrators import RigidSphere
+        L = patch.control_points.max(axis=0)
+        R = 0.25 * L[0]
+        c = 0.5 * L
+        c[2] = L[2] + 0.9 * R
+        body = RigidSphere(list(c), R, 1e4)
+        if world > 1:
+            contact = parallel.ShardedContact(shard, body, pattern, 2, 1, device=local_rank)
+        else:
+            from mimi_amd.integrators import MortarContact
+            contact = MortarContact(body, "contact", pattern, patch, 2, 1, device=local_rank).Prepare()
+            contact.body_ = body
+        contact.SetStream(stream.cuda_stream)
 
     def step():
         if exchange:
@@ -378,11 +396,15 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras):
             if boundary:
                 for g in boundary:
                     g.AddDomainResidualAndGrad(u, 1.0, r, A)
+                if contact:          # (its rows on shared node planes must be in before they go on the wire)
+                    contact.AddBoundaryResidualAndGrad(u, 1.0, r, A)
                 exchange.start(True)
                 integ.AddDomainResidualAndGrad(u, 1.0, r, A)
                 exchange.finish()
             else:
                 integ.AddDomainResidualAndGrad(u, 1.0, r, A)
+                if contact:
+                    contact.AddBoundaryResidualAndGrad(u, 1.0, r, A)
                 if exchange:
                     exchange.sum_residual_and_grad()
 
@@ -423,6 +445,12 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras):
         r_w = torch.zeros_like(r)
         A_w = torch.zeros_like(A)
         whole.AddDomainResidualAndGrad(u, 1.0, r_w, A_w)
+        if contact:
+            from mimi_amd.integrators import MortarContact
+            whole_c = MortarContact(contact.body_, "contact", pattern, patch, 2, 1, device=local_rank).Prepare()
+            whole_c.SetStream(stream.cuda_stream)
+            whole_c.AddBoundaryResidualAndGrad(u, 1.0, r_w, A_w)
+            whole_c.Synchronize()
         whole.Synchronize()
         torch.cuda.synchronize()
         planes = torch.tensor(exchange.owned_node_planes(), device=dev)
@@ -511,7 +539,7 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras):
                                               "composition": "1 x (residual+Jacobian) + 2 x (residual) assemblies, the line search "
                                                              "of solvers/newton.cpp:142-190"}
     # release this workload's device memory before the next one
-    del integ, boundary, exchange, u, r, A, pattern
+    del integ, boundary, exchange, u, r, A, pattern, contact
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     return result

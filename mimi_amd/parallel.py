@@ -235,6 +235,7 @@ class ShardedContact:
         from .integrators import MortarContact
         self.torch, self.dist = torch, dist
         self.shard = shard
+        self.body_ = body
         patch = shard.patch
         self.contact = None
         try:
