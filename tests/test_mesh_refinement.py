@@ -131,3 +131,69 @@ def test_runtime_communication_npz(tmp_path):
     assert np.array_equal(npz["x_4"], np.full(7, 4.0)) and np.array_equal(npz["gap_history"], [0.5, 0.25])
     assert np.array_equal(rc.latest_vector("x_"), np.full(7, 4.0))
     assert rc.get_real_history_at("gap", 1) == 0.25
+
+
+def _write_mfem_nurbs(path, nb):
+    """a NurbsPatch as an 'MFEM NURBS mesh v1.0' file in MFEM's dof order (what SaveMesh of the reference writes)"""
+    dim = nb.dim
+    order = nb.mfem_order()
+    quad_edges = [(0, 0, 1), (0, 3, 2), (1, 0, 3), (1, 1, 2)]
+    hex_edges = [(0, 0, 1), (0, 3, 2), (0, 4, 5), (0, 7, 6), (1, 0, 3), (1, 1, 2), (1, 4, 7), (1, 5, 6), (2, 0, 4), (2, 1, 5),
+                 (2, 2, 6), (2, 3, 7)]
+    edges = quad_edges if dim == 2 else hex_edges
+    lines = ["MFEM NURBS mesh v1.0", "", "dimension", str(dim), "", "elements", "1",
+             "1 3 0 1 2 3" if dim == 2 else "1 5 0 1 2 3 4 5 6 7", "", "boundary"]
+    if dim == 2:
+        lines += ["4", "1 1 0 1", "2 1 2 3", "3 1 3 0", "4 1 1 2"]
+    else:
+        lines += ["6", "1 3 3 2 1 0", "2 3 4 5 6 7", "3 3 0 1 5 4", "4 3 1 2 6 5", "5 3 2 3 7 6", "6 3 3 0 4 7"]
+    lines += ["", "edges", str(len(edges))] + [" ".join(map(str, e)) for e in edges]
+    lines += ["", "vertices", str(2 ** dim), "", "knotvectors", str(dim)]
+    for k, p in zip(nb.knots, nb.degrees):
+        lines.append(f"{p} {len(k) - p - 1} " + " ".join(repr(float(x)) for x in k))
+    lines += ["", "weights"] + [repr(float(nb.weights[n])) for n in order]
+    lines += ["", "FiniteElementSpace", f"FiniteElementCollection: NURBS{nb.degrees[0]}", f"VDim: {dim}", "Ordering: 1", ""]
+    lines += [" ".join(repr(float(x)) for x in nb.ctrl[n]) for n in order]
+    open(path, "w").write("\n".join(lines) + "\n")
+
+
+@pytest.mark.parametrize("name,elev,sub", [("sqn.mesh", 2, 1), ("cube-nurbs.mesh", 1, 1), ("cube-nurbs-3.mesh", 0, 1)])
+def test_refined_rational_patch_survives_a_file_round_trip(tmp_path, name, elev, sub):
+    """a curved, rational, multi-span patch of degree > 1 written in MFEM's dof order and read back: same knots, control
+    net and weights (the reader's renumbering is the inverse of the writer's), and the same geometry as before refinement"""
+    from mimi_amd import nurbs_mesh as nm
+    s = solid(name)
+    nb = s._nurbs
+    rng = np.random.default_rng(3)
+    nb.ctrl = nb.ctrl + 0.05 * rng.standard_normal(nb.ctrl.shape)           # a skewed cell
+    nb.weights = nb.weights * (1.0 + 0.3 * rng.random(nb.weights.shape))    # truly rational
+    coarse = nm.NurbsPatch(nb.degrees, nb.knots, nb.ctrl.copy(), nb.weights.copy(), nb.faces, nb.edges, nb.element_vertices)
+    fine = coarse.elevate(elev) if elev else coarse
+    for _ in range(sub):
+        fine = fine.refine()
+    f = tmp_path / "patch.mesh"
+    _write_mfem_nurbs(f, fine)
+    back = nm.read_mfem_nurbs(str(f))
+    assert back.degrees == fine.degrees
+    for a, b in zip(back.knots, fine.knots):
+        assert np.allclose(a, b, atol=1e-15)
+    assert np.allclose(back.ctrl, fine.ctrl, atol=1e-13) and np.allclose(back.weights, fine.weights, atol=1e-13)
+    assert back.faces == fine.faces
+
+    def point(pt, xi):
+        rows = [nm.basis_row(k, p, x) for k, p, x in zip(pt.knots, pt.degrees, xi)]
+        n = pt.n_ctrl
+        num, den = np.zeros(pt.dim), 0.0
+        for idx in np.ndindex(*[p + 1 for p in pt.degrees]):
+            node, stride, b = 0, 1, 1.0
+            for d in range(pt.dim):
+                node += (rows[d][0] + idx[d]) * stride
+                stride *= n[d]
+                b *= rows[d][1][idx[d]]
+            b *= pt.weights[node]
+            num += b * pt.ctrl[node]
+            den += b
+        return num / den
+
+    for xi in rng.random((10, coarse.dim)):
+        assert np.allclose(point(coarse, xi), point(back, xi), atol=1e-12)
