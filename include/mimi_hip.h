@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MIMI_HIP_ABI_VERSION 6
+#define MIMI_HIP_ABI_VERSION 7
 
 /* ---- errors ---------------------------------------------------------------- */
 const char* mimi_hip_last_error(void);
@@ -183,6 +183,13 @@ int64_t mimi_hip_domain_info(mimi_hip_domain_t h, int what);
  * nnz, then again with col ([nnz], device or host). */
 int mimi_hip_bspline_sparsity(int32_t dim, const int32_t n_nodes_dir[3], const int32_t degree[3],
                               int device, int64_t* rowptr, int32_t* col, int64_t* nnz);
+/* Row slice of the same pattern, for a rank that owns a box of nodes (one slab of the patch): rowptr keeps its full
+ * length [n_vdofs+1], rows of nodes outside [node_begin, node_end) get zero length, and col / the value array hold
+ * only the slice (nnz = the slice's entries).  A domain handle accepts such a pattern when the box covers every node
+ * its elements touch: the integration kernels only ever write rows of those nodes.  Column indices stay global. */
+int mimi_hip_bspline_sparsity_rows(int32_t dim, const int32_t n_nodes_dir[3], const int32_t degree[3],
+                                   const int32_t node_begin[3], const int32_t node_end[3], int device,
+                                   int64_t* rowptr, int32_t* col, int64_t* nnz);
 
 /* ---- contact integrator: integrators::MortarContact ------------------------------ */
 typedef struct mimi_hip_contact_s* mimi_hip_contact_t;

@@ -667,7 +667,11 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
         std::vector<int64_t> pre(S.n[d] + 1, 0);
         prefix[d].assign(pre.data(), pre.size(), h->stream);  // unused by the check kernel
         S.prefix[d] = prefix[d].ptr;
+        // a row-sliced pattern must hold the rows of every node this handle's elements touch
+        S.req_lo[d] = t1[d].first[h->el_begin[d]];
+        S.req_hi[d] = t1[d].first[h->el_end[d] - 1] + h->degree[d] + 1;
       }
+      S.partial = 1;
       DeviceBuffer<int32_t> col_tmp;
       const int32_t* col_dev = p->csr_col;
       if (!is_device_pointer(p->csr_col)) {
@@ -896,10 +900,14 @@ int64_t mimi_hip_domain_info(mimi_hip_domain_t h, int what) {
   }
 }
 
-int mimi_hip_bspline_sparsity(int32_t dim, const int32_t n_nodes_dir[3], const int32_t degree[3], int device,
-                              int64_t* rowptr, int32_t* col, int64_t* nnz_out) {
+}  // extern "C"
+
+// node_begin / node_end == nullptr: every row; else only the rows of the nodes in that box (others get zero length)
+static int bspline_sparsity(int32_t dim, const int32_t n_nodes_dir[3], const int32_t degree[3], const int32_t* node_begin,
+                            const int32_t* node_end, int device, int64_t* rowptr, int32_t* col, int64_t* nnz_out) {
   return guarded([&] {
     if (dim != 2 && dim != 3) fail("Unsupported Dim: %d", dim);
+    if ((node_begin == nullptr) != (node_end == nullptr)) fail("node_begin and node_end go together");
     if (!rowptr || !nnz_out) fail("null argument");
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0) fail("libmimi_hip: no HIP device visible");
@@ -935,6 +943,25 @@ int mimi_hip_bspline_sparsity(int32_t dim, const int32_t n_nodes_dir[3], const i
       MH_HIP(hipGetLastError());
     }
     int64_t nnz = 0;
+    if (node_begin) {
+      // keep the lengths of the box's rows, drop the others; the scan runs on the host (n_rows + 1 integers, set-up only)
+      for (int d = 0; d < dim; ++d)
+        if (node_begin[d] < 0 || node_end[d] > S.n[d] || node_begin[d] >= node_end[d])
+          fail("node box [%d,%d) invalid in direction %d (%d nodes)", node_begin[d], node_end[d], d, S.n[d]);
+      std::vector<int64_t> full(n_rows + 1), local(n_rows + 1);
+      MH_HIP(hipMemcpy(full.data(), rp_dev, (n_rows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+      local[0] = 0;
+      for (int64_t A = 0; A < n_nodes; ++A) {
+        const int Am[3] = {(int)(A % S.n[0]), (int)((A / S.n[0]) % S.n[1]), (int)(A / ((int64_t)S.n[0] * S.n[1]))};
+        bool in = true;
+        for (int d = 0; d < dim; ++d) in = in && Am[d] >= node_begin[d] && Am[d] < node_end[d];
+        for (int i = 0; i < dim; ++i) {
+          const int64_t r = A * dim + i;
+          local[r + 1] = local[r] + (in ? full[r + 1] - full[r] : 0);
+        }
+      }
+      MH_HIP(hipMemcpy(rp_dev, local.data(), (n_rows + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
     MH_HIP(hipMemcpy(&nnz, rp_dev + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost));
     *nnz_out = nnz;
     if (rp_host) MH_HIP(hipMemcpy(rowptr, rp_dev, (n_rows + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -956,6 +983,20 @@ int mimi_hip_bspline_sparsity(int32_t dim, const int32_t n_nodes_dir[3], const i
     }
     MH_HIP(hipDeviceSynchronize());
   });
+}
+
+extern "C" {
+
+int mimi_hip_bspline_sparsity(int32_t dim, const int32_t n_nodes_dir[3], const int32_t degree[3], int device,
+                              int64_t* rowptr, int32_t* col, int64_t* nnz_out) {
+  return bspline_sparsity(dim, n_nodes_dir, degree, nullptr, nullptr, device, rowptr, col, nnz_out);
+}
+
+int mimi_hip_bspline_sparsity_rows(int32_t dim, const int32_t n_nodes_dir[3], const int32_t degree[3],
+                                   const int32_t node_begin[3], const int32_t node_end[3], int device, int64_t* rowptr,
+                                   int32_t* col, int64_t* nnz_out) {
+  if (!node_begin || !node_end) return guarded([&] { fail("node_begin / node_end must be given"); });
+  return bspline_sparsity(dim, n_nodes_dir, degree, node_begin, node_end, device, rowptr, col, nnz_out);
 }
 
 }  // extern "C"

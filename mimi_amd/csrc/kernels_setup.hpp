@@ -152,6 +152,10 @@ struct SparsityDev {
   int dim;
   int n[3], p[3];
   const int64_t* prefix[3];  // [n_d + 1] exclusive prefix sums of the 1-D stencil widths
+  // row-sliced patterns (mimi_hip_bspline_sparsity_rows): rows of nodes outside [req_lo, req_hi) may be absent
+  // (zero length); partial == 0: every row must be there
+  int partial;
+  int req_lo[3], req_hi[3];
 };
 
 MH_DEV int width_1d(int A, int n, int p) {
@@ -199,7 +203,18 @@ __global__ void structured_col_kernel(SparsityDev S, int64_t n_rows, const int64
   }
   const int64_t start = rowptr[row];
   const int len = dim * w[0] * w[1] * w[2];
-  if (check_only && rowptr[row + 1] - start != len) {
+  const int64_t have = rowptr[row + 1] - start;
+  if (have == 0) {
+    // a row this (row-sliced) pattern does not hold: fine unless the handle's elements touch it
+    bool required = check_only && !S.partial;
+    if (check_only && S.partial) {
+      required = true;
+      for (int d = 0; d < dim; ++d) required = required && Am[d] >= S.req_lo[d] && Am[d] < S.req_hi[d];
+    }
+    if (required && lane == 0) atomicOr(mismatch, 1);
+    return;
+  }
+  if (check_only && have != len) {
     if (lane == 0) atomicOr(mismatch, 1);
     return;
   }

@@ -25,25 +25,40 @@ class CSRPattern:
         self.rowptr, self.col, self.nnz = rowptr, col, int(nnz)
 
     @classmethod
-    def of_bspline_patch(cls, patch, device=0, on_device=False):
-        """Structured pattern of a lexicographically numbered patch, built on the GPU."""
+    def of_bspline_patch(cls, patch, device=0, on_device=False, node_box=None):
+        """Structured pattern of a lexicographically numbered patch, built on the GPU.
+
+        node_box = (begin[dim], end[dim]): the row slice of a rank that owns that box of nodes -- rowptr keeps its full
+        length, rows of other nodes are empty, col and the value array hold only the slice (mimi_hip.h:
+        mimi_hip_bspline_sparsity_rows)."""
         L = _capi.lib()
         n = (C.c_int32 * 3)(*(patch.n_ctrl + [1] * (3 - patch.dim)))
         p = (C.c_int32 * 3)(*(patch.degrees + [0] * (3 - patch.dim)))
         nnz = C.c_int64(0)
         nrows = patch.n_vdofs
+        if node_box is None:
+            def build(rowptr, col):
+                check(L.mimi_hip_bspline_sparsity(patch.dim, n, p, device, ptr(rowptr), ptr(col) if col is not None else None,
+                                                  C.byref(nnz)))
+        else:
+            lo = (C.c_int32 * 3)(*(list(node_box[0]) + [0] * (3 - patch.dim)))
+            hi = (C.c_int32 * 3)(*(list(node_box[1]) + [1] * (3 - patch.dim)))
+
+            def build(rowptr, col):
+                check(L.mimi_hip_bspline_sparsity_rows(patch.dim, n, p, lo, hi, device, ptr(rowptr),
+                                                       ptr(col) if col is not None else None, C.byref(nnz)))
         if on_device:
             import torch
             dev = torch.device("cuda", device)
             rowptr = torch.empty(nrows + 1, dtype=torch.int64, device=dev)
-            check(L.mimi_hip_bspline_sparsity(patch.dim, n, p, device, ptr(rowptr), None, C.byref(nnz)))
+            build(rowptr, None)
             col = torch.empty(nnz.value, dtype=torch.int32, device=dev)
-            check(L.mimi_hip_bspline_sparsity(patch.dim, n, p, device, ptr(rowptr), ptr(col), C.byref(nnz)))
+            build(rowptr, col)
         else:
             rowptr = np.empty(nrows + 1, dtype=np.int64)
-            check(L.mimi_hip_bspline_sparsity(patch.dim, n, p, device, ptr(rowptr), None, C.byref(nnz)))
+            build(rowptr, None)
             col = np.empty(nnz.value, dtype=np.int32)
-            check(L.mimi_hip_bspline_sparsity(patch.dim, n, p, device, ptr(rowptr), ptr(col), C.byref(nnz)))
+            build(rowptr, col)
         return cls(rowptr, col, nnz.value)
 
 

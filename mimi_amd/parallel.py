@@ -15,7 +15,10 @@ import numpy as np
 
 class SlabShard:
     """Contiguous element slabs along one axis (the longest; ties -> the slowest-varying
-    one, whose node planes are contiguous in the lexicographic numbering)."""
+    one, whose node planes are contiguous in the lexicographic numbering).
+
+    `pattern`: the CSR pattern this rank assembles into -- the whole patch's, or the row slice of node_box() (then
+    the value array holds only this rank's rows; pass None here and set `.pattern` once node_box() is known)."""
 
     def __init__(self, patch, pattern, rank, world_size, axis=None):
         self.patch, self.pattern = patch, pattern
@@ -39,6 +42,13 @@ class SlabShard:
         begin[axis], end[axis] = int(starts[rank]), int(starts[rank + 1])
         self.element_box = (begin, end)
         self.n_local_elements = int(np.prod([end[d] - begin[d] for d in range(patch.dim)]))
+
+    def node_box(self):
+        """(begin, end) of the nodes this slab's elements touch: the rows a rank has to hold
+        (CSRPattern.of_bspline_patch(..., node_box=...) builds exactly that row slice of the pattern)."""
+        b, e = self.element_box
+        dim = self.patch.dim
+        return [int(b[d]) for d in range(dim)], [int(e[d]) + int(self.patch.degrees[d]) for d in range(dim)]
 
     def overlap_boxes(self, layers=None):
         """Split of this slab for overlapping the exchange with compute: (boundary boxes, interior box).

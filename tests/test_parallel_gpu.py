@@ -51,13 +51,18 @@ def _worker(rank, world, port, n_el, mode, q):
         from mimi_amd.integrators import CSRPattern, NonlinearSolid
         dev = torch.device("cuda", 0)
         patch = mimi_amd.BSplinePatch.block(n_el, 2)
-        pattern = CSRPattern.of_bspline_patch(patch, on_device=True)
-        shard = parallel.SlabShard(patch, pattern, rank, world)
+        full = CSRPattern.of_bspline_patch(patch, on_device=True)
+        shard = parallel.SlabShard(patch, None, rank, world)
+        # "+slice": this rank's value array holds only the rows of the nodes its slab touches (as bench.py does)
+        pattern = CSRPattern.of_bspline_patch(patch, on_device=True, node_box=shard.node_box()) if "+slice" in mode else full
+        shard.pattern = pattern
+        if "+slice" in mode:
+            assert pattern.nnz < full.nnz
         # the library enqueues on the stream it is given: the same (non-default: a null handle means "the
         # handle's own stream") one the exchange's torch ops use, as in bench.py
         stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(stream)
-        overlap = mode.endswith("+overlap")
+        overlap = "+overlap" in mode
         mode = mode.split("+")[0]
         boundary_boxes, interior_box = shard.overlap_boxes() if overlap else ([], shard.element_box)
         handles = []
@@ -83,9 +88,9 @@ def _worker(rank, world, port, n_el, mode, q):
                 ex.sum_residual_and_grad()
         for g in handles:
             g.Synchronize()
-        Gf = NonlinearSolid("domain", bench.make_material("neohookean"), pattern, patch=patch).Prepare()
+        Gf = NonlinearSolid("domain", bench.make_material("neohookean"), full, patch=patch).Prepare()
         rf = torch.zeros_like(r)
-        Af = torch.zeros_like(A)
+        Af = torch.zeros(full.nnz, dtype=torch.float64, device=dev)
         Gf.AddDomainResidualAndGrad(u, 1.0, rf, Af)
         Gf.Synchronize()
         # rows of the owned node planes that are interface planes hold one step's sum; interior rows two steps'
@@ -95,7 +100,8 @@ def _worker(rank, world, port, n_el, mode, q):
         for nb in (rank - 1, rank + 1):
             if 0 <= nb < world:
                 shared_planes.update(shard.interface_node_planes(nb))
-        rowptr = pattern.rowptr.cpu().numpy() if hasattr(pattern.rowptr, "cpu") else np.asarray(pattern.rowptr)
+        rowptr, rowptr_f = pattern.rowptr.cpu().numpy(), full.rowptr.cpu().numpy()
+        col, col_f = pattern.col.cpu().numpy(), full.col.cpu().numpy()
         r_h, A_h, rf_h, Af_h = r.cpu().numpy(), A.cpu().numpy(), rf.cpu().numpy(), Af.cpu().numpy()
         ok = True
         worst = [0.0, 0.0, 0.0, 0.0]   # r / A error on shared planes, on interior planes
@@ -105,8 +111,10 @@ def _worker(rank, world, port, n_el, mode, q):
             for i in range(3):
                 row = node * 3 + i
                 s, t = rowptr[row], rowptr[row + 1]
+                sf, tf = rowptr_f[row], rowptr_f[row + 1]
+                assert np.array_equal(col[s:t], col_f[sf:tf])
                 worst[0 if shared else 2] = max(worst[0 if shared else 2], abs(r_h[row] - mult * rf_h[row]))
-                worst[1 if shared else 3] = max(worst[1 if shared else 3], np.abs(A_h[s:t] - mult * Af_h[s:t]).max())
+                worst[1 if shared else 3] = max(worst[1 if shared else 3], np.abs(A_h[s:t] - mult * Af_h[sf:tf]).max())
         scale_r, scale_A = np.abs(rf_h).max(), np.abs(Af_h).max()
         ok = worst[0] < 1e-12 * scale_r and worst[2] < 1e-12 * scale_r and worst[1] < 1e-12 * scale_A and worst[3] < 1e-12 * scale_A
         q.put((rank, bool(ok), len(owned) if ok else repr(worst)))
@@ -117,7 +125,9 @@ def _worker(rank, world, port, n_el, mode, q):
 
 
 @pytest.mark.parametrize("world,n_el,mode", [(2, (4, 6, 3), "owner"), (3, (3, 4, 9), "owner"), (2, (5, 4, 3), "replicate"),
-                                             (3, (3, 4, 15), "owner+overlap"), (2, (4, 10, 3), "owner+overlap")])
+                                             (3, (3, 4, 15), "owner+overlap"), (2, (4, 10, 3), "owner+overlap"),
+                                             (3, (3, 4, 15), "owner+overlap+slice"), (2, (4, 10, 3), "owner+slice"),
+                                             (2, (3, 4, 6), "replicate+slice")])
 def test_slabs_on_one_gpu(world, n_el, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -130,7 +140,7 @@ def test_slabs_on_one_gpu(world, n_el, mode):
         assert sum(n for _, _, n in results) == int(np.prod([n + 2 for n in n_el]))
 
 
-def _contact_worker(rank, world, port, n_el, q):
+def _contact_worker(rank, world, port, n_el, sliced, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -144,8 +154,10 @@ def _contact_worker(rank, world, port, n_el, q):
         from mimi_amd.integrators import CSRPattern, MortarContact, RigidSphere
         dev = torch.device("cuda", 0)
         patch = mimi_amd.BSplinePatch.block(n_el, 2)
-        pattern = CSRPattern.of_bspline_patch(patch, on_device=True)
-        shard = parallel.SlabShard(patch, pattern, rank, world)
+        full = CSRPattern.of_bspline_patch(patch, on_device=True)
+        shard = parallel.SlabShard(patch, None, rank, world)
+        pattern = CSRPattern.of_bspline_patch(patch, on_device=True, node_box=shard.node_box()) if sliced else full
+        shard.pattern = pattern
         L = patch.control_points.max(axis=0)
         R = 0.25 * L[0]
         centre = 0.5 * L
@@ -166,23 +178,24 @@ def _contact_worker(rank, world, port, n_el, q):
         ex.sum_residual_and_grad()
         stream.synchronize()
         # the whole face on one handle
-        Gf = MortarContact(body, "contact", pattern, patch, 2, 1).Prepare()
-        rf, Af = torch.zeros_like(r), torch.zeros_like(A)
+        Gf = MortarContact(body, "contact", full, patch, 2, 1).Prepare()
+        rf, Af = torch.zeros_like(r), torch.zeros(full.nnz, dtype=torch.float64, device=dev)
         Gf.AddBoundaryResidualAndGrad(u, 0.7, rf, Af)
         Gf.Synchronize()
         # after the replicate exchange this rank holds the complete rows of every node its elements touch
         b, e = shard.element_box
         mi_axis = patch.node_multi_index()[shard.axis]
         mine = np.nonzero((mi_axis >= b[shard.axis]) & (mi_axis < e[shard.axis] + 2))[0]
-        rowptr = pattern.rowptr.cpu().numpy()
+        rowptr, rowptr_f = pattern.rowptr.cpu().numpy(), full.rowptr.cpu().numpy()
         r_h, A_h, rf_h, Af_h = r.cpu().numpy(), A.cpu().numpy(), rf.cpu().numpy(), Af.cpu().numpy()
         er = eA = 0.0
         for node in mine:
             for i in range(3):
                 row = node * 3 + i
                 s, t = rowptr[row], rowptr[row + 1]
+                sf, tf = rowptr_f[row], rowptr_f[row + 1]
                 er = max(er, abs(r_h[row] - rf_h[row]))
-                eA = max(eA, np.abs(A_h[s:t] - Af_h[s:t]).max())
+                eA = max(eA, np.abs(A_h[s:t] - Af_h[sf:tf]).max())
         ok = np.abs(rf_h).max() > 0 and er < 1e-11 * np.abs(rf_h).max() and eA < 1e-11 * np.abs(Af_h).max()
         q.put((rank, bool(ok), (er, eA, float(np.abs(rf_h).max()))))
     except Exception as exc:  # pragma: no cover
@@ -192,14 +205,33 @@ def _contact_worker(rank, world, port, n_el, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_el", [(2, (4, 6, 2)), (3, (3, 9, 2))])
-def test_sharded_contact_on_one_gpu(world, n_el):
+@pytest.mark.parametrize("world,n_el,sliced", [(2, (4, 6, 2), False), (3, (3, 9, 2), False), (2, (4, 6, 2), True)])
+def test_sharded_contact_on_one_gpu(world, n_el, sliced):
     """cfg4 in miniature: contact faces follow their element slab; the nodal area / gap of the nodes shared between
     slabs are summed over the ranks before the pressure is formed; rows then travel with the interface exchange."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_contact_worker, args=(r, world, port, n_el, q)) for r in range(world)]
+    procs = [ctx.Process(target=_contact_worker, args=(r, world, port, n_el, sliced, q)) for r in range(world)]
     results = _run_ranks(ctx, procs, q, world)
     assert all(ok is True for _, ok, _ in results), results
+
+
+def test_row_slice_must_cover_the_handles_nodes():
+    """a handle whose elements touch a node the sliced pattern does not hold is refused at create time"""
+    import mimi_amd
+    import bench
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    patch = mimi_amd.BSplinePatch.block((3, 3, 6), 2)
+    full = CSRPattern.of_bspline_patch(patch, on_device=True)
+    part = CSRPattern.of_bspline_patch(patch, on_device=True, node_box=([0, 0, 0], [5, 5, 5]))   # element layers 0..2 in z
+    assert 0 < part.nnz < full.nnz
+    lens_f = (full.rowptr[1:] - full.rowptr[:-1]).cpu().numpy()
+    lens_p = (part.rowptr[1:] - part.rowptr[:-1]).cpu().numpy()
+    inside = np.repeat(patch.node_multi_index()[2] < 5, 3)
+    assert np.array_equal(lens_p[inside], lens_f[inside]) and not lens_p[~inside].any()
+    ok = NonlinearSolid("domain", bench.make_material("neohookean"), part, patch=patch, element_box=([0, 0, 0], [3, 3, 3])).Prepare()
+    assert ok.path_ == 1
+    with pytest.raises(RuntimeError):
+        NonlinearSolid("domain", bench.make_material("neohookean"), part, patch=patch, element_box=([0, 0, 0], [3, 3, 4])).Prepare()
