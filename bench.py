@@ -334,7 +334,7 @@ def launch_ranks(args):
 # ------------------------------------------------------------------------------------------------
 # one rank
 # ------------------------------------------------------------------------------------------------
-def measure(args, workload, rank, world, local_rank, backend, with_extras):
+def measure(args, workload, rank, world, local_rank, backend, with_extras, loopback=False):
     """time `args.steps` assemblies of one workload on this rank's slab; returns the result dict (rank 0) or None"""
     import torch
     import torch.distributed as dist
@@ -370,7 +370,7 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras):
     u = torch.from_numpy(synthetic_u(patch, scale=0.01 if workload == "cfg4" else 0.05)).to(dev)
     r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
     A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
-    exchange = parallel.InterfaceExchange(shard, r, A, dev, mode="owner") if world > 1 else None
+    exchange = parallel.InterfaceExchange(shard, r, A, dev, mode="owner", loopback=loopback) if world > 1 else None
     contact = None
     if workload == "cfg4":
         from mimi_amd.integrators import RigidSphere
@@ -439,7 +439,7 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras):
 
     # --check (N > 1): the rows this rank owns after the exchange against a whole-patch assembly on this rank's GPU
     check = None
-    if args.check and world > 1 and not args.residual_only:
+    if args.check and world > 1 and not args.residual_only and not loopback:
         r.zero_()
         A.zero_()
         step()
@@ -506,7 +506,7 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras):
         residual_ms = (time.perf_counter() - t1) / 10 * 1e3
 
     result = None
-    if rank == 0:
+    if rank == 0 or loopback:
         n_elements = patch.n_elements
         grad = not args.residual_only
         stateful = material not in ("neohookean", "stvk")
@@ -554,7 +554,17 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras):
     return result
 
 
+def _emit(fd, obj):
+    """the ONE JSON line, on the process's original stdout"""
+    os.write(fd, (json.dumps(obj) + "\n").encode())
+
+
 def run_rank(args):
+    # stdout carries one JSON line and nothing else: RCCL prints a version banner on the stdout of rank 0 when its
+    # communicator comes up, so everything but that line is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -586,6 +596,26 @@ def run_rank(args):
         comm_ranks = int(ones.item())
         if comm_ranks != world:
             raise SystemExit(f"communicator sums to {comm_ranks} ranks, expected {world}")
+
+    if args.rehearse_rccl:
+        # one slab of an N-rank job on this one GPU, exchange over a one-rank RCCL communicator (sends to itself)
+        if world != 1 or args.workload == "cfg4":
+            raise SystemExit("--rehearse-rccl: one process, domain workloads only")
+        n_fake = args.rehearse_rccl
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        res = measure(args, args.workload, n_fake // 2, n_fake, local_rank, "nccl", with_extras=False, loopback=True)
+        out = {"rehearsal": f"rank {n_fake // 2} of {n_fake} alone on one GPU: its slab, its boundary / interior split, pack, "
+                            "RCCL send / recv (to itself: device-local copies, not xGMI), unpack; `value` is the whole job's "
+                            "rate IF every rank took this long -- not a measurement of an N-GPU run",
+               "value": res["value"], "unit": "element-integrations/s", "n_gpus": 1, "ranks_rehearsed": n_fake,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "config": res["config"],
+               "elements_on_this_rank": res["roofline"]["elements_per_launch"]}
+        _emit(json_fd, out)
+        dist.destroy_process_group()
+        return
 
     main = measure(args, args.workload, rank, world, local_rank, backend, with_extras=True)
     other = {}
@@ -623,7 +653,7 @@ def run_rank(args):
             out["cpu_baseline"]["gpu_over_cpu"] = main["value"] / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        _emit(json_fd, out)
     if world > 1:
         dist.destroy_process_group()
 
@@ -633,6 +663,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rehearse-rccl", type=int, default=0, metavar="N",
+                    help="time the step of the middle rank of an N-rank job on this one GPU, exchange over RCCL to itself")
     ap.add_argument("--workload", default=os.environ.get("MIMI_BENCH_WORKLOAD", "northstar"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sweep", action="store_true", help="add a 1/32/64/128-thread sweep of the CPU baseline (minutes)")

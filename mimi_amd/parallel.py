@@ -108,7 +108,10 @@ class InterfaceExchange:
     first p//2 belong to k and the rest to k+1; each rank sends only the rows the neighbour owns and
     adds what it receives into the rows it owns -- half the traffic of "replicate"."""
 
-    def __init__(self, shard, r, A, device=None, mode="replicate"):
+    def __init__(self, shard, r, A, device=None, mode="replicate", loopback=False):
+        """loopback: every message goes to this process itself (send and receive on the caller's own rank of the
+        communicator) -- a transport check on one GPU: what a neighbour would have received is added into the rows
+        this rank would have received into (tests/test_rccl_loopback_gpu.py)."""
         import torch
         import torch.distributed as dist
         if mode not in ("replicate", "owner"):
@@ -147,7 +150,7 @@ class InterfaceExchange:
                 send_planes, recv_planes = (upper, lower) if nb > shard.rank else (lower, upper)
             srows, sidx = row_sets(send_planes)
             rrows, ridx = row_sets(recv_planes)
-            self.sides.append(dict(peer=nb, srows=srows, sidx=sidx, rrows=rrows, ridx=ridx,
+            self.sides.append(dict(peer=dist.get_rank() if loopback else nb, srows=srows, sidx=sidx, rrows=rrows, ridx=ridx,
                                    send=torch.empty(srows.numel() + sidx.numel(), dtype=r.dtype, device=device),
                                    recv=torch.empty(rrows.numel() + ridx.numel(), dtype=r.dtype, device=device)))
         # all shared rows / values of this rank in one index set each (zero_interface: two kernels per step)
