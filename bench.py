@@ -366,6 +366,12 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
     boundary_boxes, interior_box = shard.overlap_boxes() if (world > 1 and not args.residual_only) else ([], shard.element_box)
     integ = make_integrator(interior_box)
     boundary = [make_integrator(b) for b in boundary_boxes]
+    # the two boundary boxes of a middle rank are a few hundred element columns each -- half of the chip's workgroup slots:
+    # they share no node, so the second one runs beside the first on its own stream
+    side_stream = None
+    if len(boundary) == 2 and shard.boxes_share_no_node(boundary_boxes):
+        side_stream = torch.cuda.Stream(device=dev)
+        boundary[1].SetStream(side_stream.cuda_stream)
 
     u = torch.from_numpy(synthetic_u(patch, scale=0.01 if workload == "cfg4" else 0.05)).to(dev)
     r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
@@ -397,12 +403,20 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
                 exchange.sum_residual()
         else:
             if boundary:
+                if side_stream:
+                    side_stream.wait_stream(stream)
                 for g in boundary:
                     g.AddDomainResidualAndGrad(u, 1.0, r, A)
+                if side_stream:
+                    stream.wait_stream(side_stream)
                 if contact:          # (its rows on shared node planes must be in before they go on the wire)
                     contact.AddBoundaryResidualAndGrad(u, 1.0, r, A)
-                exchange.start(True)
+                # the interior kernels are enqueued BEFORE the host issues the sends: packing and the sends run on the
+                # exchange's stream behind `ready`, beside the interior, and the GPU does not idle while the host talks to RCCL
+                ready = torch.cuda.Event()
+                ready.record(stream)
                 integ.AddDomainResidualAndGrad(u, 1.0, r, A)
+                exchange.start(True, ready=ready)
                 exchange.finish()
             else:
                 integ.AddDomainResidualAndGrad(u, 1.0, r, A)
@@ -554,6 +568,16 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
     return result
 
 
+def _rccl_options():
+    """RCCL's stream at high priority: streams of equal priority share a few hardware queues, and a send / recv kernel
+    queued behind the interior kernels of the compute stream would not overlap with them at all (seen in the kernel
+    trace of `--rehearse-rccl`); high-priority streams have queues of their own"""
+    import torch.distributed as dist
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = True
+    return opts
+
+
 def _emit(fd, obj):
     """the ONE JSON line, on the process's original stdout"""
     os.write(fd, (json.dumps(obj) + "\n").encode())
@@ -587,7 +611,7 @@ def run_rank(args):
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, pg_options=_rccl_options())
         else:
             dist.init_process_group(backend)
         # one sum over the communicator before anything is timed: every rank is there and the transport works
@@ -605,7 +629,7 @@ def run_rank(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=_rccl_options())
         res = measure(args, args.workload, n_fake // 2, n_fake, local_rank, "nccl", with_extras=False, loopback=True)
         out = {"rehearsal": f"rank {n_fake // 2} of {n_fake} alone on one GPU: its slab, its boundary / interior split, pack, "
                             "RCCL send / recv (to itself: device-local copies, not xGMI), unpack; `value` is the whole job's "

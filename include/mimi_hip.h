@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MIMI_HIP_ABI_VERSION 7
+#define MIMI_HIP_ABI_VERSION 8
 
 /* ---- errors ---------------------------------------------------------------- */
 const char* mimi_hip_last_error(void);
@@ -190,6 +190,19 @@ int mimi_hip_bspline_sparsity(int32_t dim, const int32_t n_nodes_dir[3], const i
 int mimi_hip_bspline_sparsity_rows(int32_t dim, const int32_t n_nodes_dir[3], const int32_t degree[3],
                                    const int32_t node_begin[3], const int32_t node_end[3], int device,
                                    int64_t* rowptr, int32_t* col, int64_t* nnz);
+
+/* ---- exchange step of a sharded assembly (no reference counterpart beyond the in-process reduction of
+ * integrators/nonlinear_base.hpp:90-151) ----
+ * The rows `rows[0..n_rows)` (distinct, device int64) of the residual `r` and of the CSR value array travel as one
+ * message: [n_rows residual entries][the rows' values, row after row]; offsets[k] (device int64) = position of row k's
+ * values in the message (n_rows + the lengths of the rows before it).  A_values == NULL: residual entries only.
+ * All pointers are device pointers; the kernels are enqueued on `stream` (NULL or MIMI_HIP_STREAM_NULL: the null stream)
+ * of the current device and return at once. */
+int mimi_hip_rows_zero(void* stream, const int64_t* rowptr, const int64_t* rows, int64_t n_rows, double* r, double* A_values);
+int mimi_hip_rows_pack(void* stream, const int64_t* rowptr, const int64_t* rows, const int64_t* offsets, int64_t n_rows,
+                       const double* r, const double* A_values, double* message);
+int mimi_hip_rows_unpack_add(void* stream, const int64_t* rowptr, const int64_t* rows, const int64_t* offsets, int64_t n_rows,
+                             const double* message, double* r, double* A_values);
 
 /* ---- contact integrator: integrators::MortarContact ------------------------------ */
 typedef struct mimi_hip_contact_s* mimi_hip_contact_t;

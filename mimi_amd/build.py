@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmimi_hip.so")
-SOURCES = ["domain.hip", "tensor_p3.hip", "contact.hip", "krylov.hip"]
+SOURCES = ["domain.hip", "tensor_p3.hip", "contact.hip", "krylov.hip", "exchange.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
          "-Wno-unused-result"]
 

@@ -81,6 +81,13 @@ class SlabShard:
             boundary.append(box(hi - p, hi))
         return boundary, box(lo + (p if has_lower else 0), hi - (p if has_upper else 0))
 
+    def boxes_share_no_node(self, boxes):
+        """True when no node is touched by the elements of two of `boxes` (element boxes that differ along the sharding
+        axis only): their handles may then assemble into the same `r` / `A` concurrently, on different streams."""
+        p = self.patch.degrees[self.axis]
+        spans = sorted((b[self.axis], e[self.axis] + p) for b, e in boxes)      # node planes [begin, end) of each box
+        return all(spans[k][1] <= spans[k + 1][0] for k in range(len(spans) - 1))
+
     def interface_node_planes(self, neighbour):
         """Node-plane indices along `axis` shared with rank `neighbour` (= rank +- 1)."""
         p = self.patch.degrees[self.axis]
@@ -96,6 +103,16 @@ class SlabShard:
         planes = self.interface_node_planes(neighbour)
         mi = self.patch.node_multi_index()
         return np.nonzero(np.isin(mi[self.axis], planes))[0]
+
+
+class _RowRuns:
+    """the values of a set of rows inside a message: how many there are and where each row's run starts"""
+
+    def __init__(self, total, offsets):
+        self.total, self.offsets = int(total), offsets
+
+    def numel(self):
+        return self.total
 
 
 class InterfaceExchange:
@@ -126,14 +143,23 @@ class InterfaceExchange:
         dim = shard.patch.dim
         mi_axis = shard.patch.node_multi_index()[shard.axis]
 
+        # device tensors: the library's row kernels pack / unpack / zero (one wave per row, no per-value index array);
+        # host tensors (the gloo tests on oracle data): torch index ops over precomputed positions
+        self._hip = bool(r.is_cuda)
+        self._rowptr = rowptr
+        self._comm_stream = None
+
         def row_sets(planes):
             nodes = torch.from_numpy(np.nonzero(np.isin(mi_axis, planes))[0]).to(device)
-            rows = (nodes[:, None] * dim + torch.arange(dim, device=device)[None, :]).reshape(-1)
+            rows = (nodes[:, None] * dim + torch.arange(dim, device=device)[None, :]).reshape(-1).contiguous()
             start = rowptr[rows]
             length = rowptr[rows + 1] - start
             total = int(length.sum().item()) if rows.numel() else 0
-            # positions of all values of those rows, row after row
             offs = torch.cumsum(length, 0) - length
+            if self._hip:
+                # message layout: [rows.numel() residual entries][values row after row]
+                return rows, _RowRuns(total, (offs + rows.numel()).contiguous())
+            # positions of all values of those rows, row after row
             idx = torch.repeat_interleave(start - offs, length) + torch.arange(total, device=device)
             return rows, idx
 
@@ -153,14 +179,31 @@ class InterfaceExchange:
             self.sides.append(dict(peer=dist.get_rank() if loopback else nb, srows=srows, sidx=sidx, rrows=rrows, ridx=ridx,
                                    send=torch.empty(srows.numel() + sidx.numel(), dtype=r.dtype, device=device),
                                    recv=torch.empty(rrows.numel() + ridx.numel(), dtype=r.dtype, device=device)))
-        # all shared rows / values of this rank in one index set each (zero_interface: two kernels per step)
+        # all shared rows / values of this rank in one index set each (zero_interface: one or two kernels per step)
         if self.sides:
             if mode == "replicate":
                 self._zero_rows = torch.cat([s["srows"] for s in self.sides])
-                self._zero_idx = torch.cat([s["sidx"] for s in self.sides])
+                parts = [s["sidx"] for s in self.sides]
             else:
                 self._zero_rows = torch.cat([t for s in self.sides for t in (s["srows"], s["rrows"])])
-                self._zero_idx = torch.cat([t for s in self.sides for t in (s["sidx"], s["ridx"])])
+                parts = [t for s in self.sides for t in (s["sidx"], s["ridx"])]
+            self._zero_idx = None if self._hip else torch.cat(parts)
+
+    def _stream(self):
+        from ._capi import torch_stream_of
+        return torch_stream_of(self.r)
+
+    def _pack(self, s, with_grad):
+        from ._capi import check, lib, ptr
+        check(lib().mimi_hip_rows_pack(self._stream(), ptr(self._rowptr, "int64"), ptr(s["srows"], "int64"),
+                                       ptr(s["sidx"].offsets, "int64"), s["srows"].numel(), ptr(self.r, "float64"),
+                                       ptr(self.A, "float64") if with_grad else None, ptr(s["send"], "float64")))
+
+    def _unpack_add(self, s, with_grad):
+        from ._capi import check, lib, ptr
+        check(lib().mimi_hip_rows_unpack_add(self._stream(), ptr(self._rowptr, "int64"), ptr(s["rrows"], "int64"),
+                                             ptr(s["ridx"].offsets, "int64"), s["rrows"].numel(), ptr(s["recv"], "float64"),
+                                             ptr(self.r, "float64"), ptr(self.A, "float64") if with_grad else None))
 
     def owned_node_planes(self):
         """Node planes along the sharding axis whose rows are complete on this rank after an exchange."""
@@ -173,8 +216,30 @@ class InterfaceExchange:
         hi = int(sh.starts[sh.rank + 1]) + p // 2 if sh.rank < sh.world_size - 1 else n_planes
         return list(range(lo, hi))
 
-    def start(self, with_grad):
-        """Pack the rows the neighbours need and put them on the wire (asynchronous with "nccl")."""
+    def start(self, with_grad, ready=None):
+        """Pack the rows the neighbours need and put them on the wire (asynchronous with "nccl").
+
+        Device tensors: packing and the sends run on the exchange's own stream, ordered behind `ready` -- an event the
+        caller recorded when the interface rows were complete (default: everything enqueued on the current stream so
+        far).  A caller that records `ready`, enqueues its interior kernels and only then calls start() keeps the GPU
+        busy while the host issues the sends (bench.py)."""
+        torch, dist = self.torch, self.dist
+        if not self._hip:
+            self._start(with_grad)
+            return
+        if self._comm_stream is None:
+            # high priority: its own hardware queue (streams of equal priority share a few queues round-robin, and a
+            # pack kernel queued behind the interior kernels of the caller's stream would wait for them), and the small
+            # pack kernels get workgroup slots as soon as any free up
+            self._comm_stream = torch.cuda.Stream(device=self.r.device, priority=-1)
+        if ready is None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.r.device))
+        self._comm_stream.wait_event(ready)
+        with torch.cuda.stream(self._comm_stream):
+            self._start(with_grad)
+
+    def _start(self, with_grad):
         torch, dist = self.torch, self.dist
         staged = self.r.is_cuda and dist.get_backend() == "gloo"
         ops = []
@@ -182,7 +247,9 @@ class InterfaceExchange:
             ns, nr = s["srows"].numel(), s["rrows"].numel()
             n_send = ns + (s["sidx"].numel() if with_grad else 0)
             n_recv = nr + (s["ridx"].numel() if with_grad else 0)
-            if ns:
+            if ns and self._hip:
+                self._pack(s, with_grad)
+            elif ns:
                 torch.index_select(self.r, 0, s["srows"], out=s["send"][:ns])
                 if with_grad:
                     torch.index_select(self.A, 0, s["sidx"], out=s["send"][ns:n_send])
@@ -213,6 +280,9 @@ class InterfaceExchange:
                 continue
             if staged:
                 s["recv"][:s["recv_host"].numel()] = s["recv_host"].to(self.r.device)
+            if self._hip:
+                self._unpack_add(s, with_grad)
+                continue
             self.r.index_add_(0, s["rrows"], s["recv"][:nr])          # the indices are unique
             if with_grad:
                 self.A.index_add_(0, s["ridx"], s["recv"][nr:nr + s["ridx"].numel()])
@@ -224,6 +294,12 @@ class InterfaceExchange:
     def zero_interface(self, with_grad=True):
         """Zero the rows of all shared node planes (sent and received ones)."""
         if not self.sides:
+            return
+        if self._hip:
+            from ._capi import check, lib, ptr
+            check(lib().mimi_hip_rows_zero(self._stream(), ptr(self._rowptr, "int64"), ptr(self._zero_rows, "int64"),
+                                           self._zero_rows.numel(), ptr(self.r, "float64"),
+                                           ptr(self.A, "float64") if with_grad else None))
             return
         self.r.index_fill_(0, self._zero_rows, 0.0)
         if with_grad:

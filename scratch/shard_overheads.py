@@ -23,15 +23,11 @@ for world in (2, 4, 8):
         return (time.perf_counter() - t0) / n * 1e3
     t_c = timed(lambda: G.AddDomainResidualAndGrad(u, 1.0, r, A))
     t_z = timed(lambda: ex.zero_interface(True))
-    def pack_unpack():
+    def pack_unpack():     # (the library's row kernels since ABI 8; torch index ops before)
         for s in ex.sides:
-            ns = s["srows"].numel()
-            torch.index_select(r, 0, s["srows"], out=s["send"][:ns])
-            torch.index_select(A, 0, s["sidx"], out=s["send"][ns:ns + s["sidx"].numel()])
+            ex._pack(s, True)
         for s in ex.sides:
-            nr = s["rrows"].numel()
-            r.index_add_(0, s["rrows"], s["recv"][:nr])
-            A.index_add_(0, s["ridx"], s["recv"][nr:nr + s["ridx"].numel()])
+            ex._unpack_add(s, True)
     t_p = timed(pack_unpack)
     vol = sum(s["send"].numel() for s in ex.sides) * 8 / 1e6
     print(f"world {world}: slab {shard.element_box}: assembly {t_c:.2f} ms, zero_interface {t_z:.2f} ms, pack+unpack {t_p:.2f} ms, "

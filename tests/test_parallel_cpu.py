@@ -118,3 +118,17 @@ def test_contact_faces_follow_their_element_slab():
     patch2 = mimi_amd.BSplinePatch.block((3, 2, 6), 2)
     n = [len(splines.face_tables(patch2, 2, 1, element_box=parallel.SlabShard(patch2, pattern, r, 2).element_box)[0]) for r in range(2)]
     assert n == [0, 6]
+
+
+def test_boundary_boxes_that_may_run_concurrently():
+    """two boundary boxes may assemble concurrently only when no node is touched by both"""
+    import mimi_amd
+    from mimi_amd import parallel
+    patch = mimi_amd.BSplinePatch.block((3, 3, 18), 2)
+    thick = parallel.SlabShard(patch, None, 1, 3)                   # 6 layers: boundary 2 + 2, interior 2
+    boundary, interior = thick.overlap_boxes()
+    assert len(boundary) == 2 and thick.boxes_share_no_node(boundary)
+    assert not thick.boxes_share_no_node(boundary + [interior])     # the interior shares node planes with both
+    thin = parallel.SlabShard(mimi_amd.BSplinePatch.block((3, 3, 15), 2), None, 1, 3)   # 5 layers: 2 + 1 + 2
+    boundary, _ = thin.overlap_boxes()
+    assert len(boundary) == 2 and not thin.boxes_share_no_node(boundary)
