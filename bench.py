@@ -363,6 +363,9 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
 
     # N > 1, tangent assembly: the element layers next to a neighbour are integrated first, their interface rows
     # go on the wire, and the interior is integrated while they travel (parallel.SlabShard.overlap_boxes)
+    # (p layers per side although owner mode could do with p // 2 and p - p // 2 -- overlap_boxes(mode="owner"): measured in
+    # loop-back at N = 8, the thinner boundary launches cost more than the layers they move to the interior save:
+    # 1.29 against 1.27 ms, cfg3 6.36 against 6.15 ms)
     boundary_boxes, interior_box = shard.overlap_boxes() if (world > 1 and not args.residual_only) else ([], shard.element_box)
     integ = make_integrator(interior_box)
     boundary = [make_integrator(b) for b in boundary_boxes]

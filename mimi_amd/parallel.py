@@ -50,22 +50,31 @@ class SlabShard:
         dim = self.patch.dim
         return [int(b[d]) for d in range(dim)], [int(e[d]) + int(self.patch.degrees[d]) for d in range(dim)]
 
-    def overlap_boxes(self, layers=None):
+    def overlap_boxes(self, layers=None, mode="replicate"):
         """Split of this slab for overlapping the exchange with compute: (boundary boxes, interior box).
-        layers: element layers per boundary box (default and minimum: the degree p -- more layers give the boundary
-        launch more element columns to fill the chip with, at no cost in exchanged rows).
-        The rows of the node planes shared with a neighbour only receive contributions from the `p`
-        element layers next to that neighbour, so those layers are integrated first, their interface
-        rows go on the wire, and the interior is integrated while they travel.  ([], whole slab) when
-        the slab is too thin or has no neighbour."""
+        The rows that go on the wire only receive contributions from the element layers next to the neighbour, so those
+        layers are integrated first, their interface rows travel, and the interior is integrated meanwhile.
+        How many layers: of the shared node planes [e, e + p) between ranks k and k + 1, mode "replicate" sends all, which
+        the last / first p element layers touch; mode "owner" sends upward only the planes the upper rank owns,
+        [e + p // 2, e + p) -- touched by the last p - p // 2 layers -- and downward only [e, e + p // 2) -- touched by the
+        first p // 2 layers (InterfaceExchange: same split).
+        layers: element layers per boundary box at least (more layers give the boundary launch more element columns to
+        fill the chip with, at no cost in exchanged rows).
+        ([], whole slab) when the slab is too thin or has no neighbour."""
+        if mode not in ("replicate", "owner"):
+            raise ValueError(mode)
         b, e = self.element_box
         lo, hi = b[self.axis], e[self.axis]
         p = self.patch.degrees[self.axis]
         has_lower, has_upper = self.rank > 0, self.rank < self.world_size - 1
-        n_sides = int(has_lower) + int(has_upper)
+        n_lower = (p if mode == "replicate" else p // 2) if has_lower else 0
+        n_upper = (p if mode == "replicate" else p - p // 2) if has_upper else 0
+        n_sides = int(n_lower > 0) + int(n_upper > 0)
         if layers is not None and n_sides:
-            p = max(p, min(int(layers), (hi - lo - 1) // n_sides))
-        need = p * n_sides
+            extra = min(int(layers), (hi - lo - 1) // n_sides)
+            n_lower = max(n_lower, extra) if n_lower else 0
+            n_upper = max(n_upper, extra) if n_upper else 0
+        need = n_lower + n_upper
         if need == 0 or hi - lo < need + 1:
             return [], (list(b), list(e))
 
@@ -75,11 +84,11 @@ class SlabShard:
             return bb, ee
 
         boundary = []
-        if has_lower:
-            boundary.append(box(lo, lo + p))
-        if has_upper:
-            boundary.append(box(hi - p, hi))
-        return boundary, box(lo + (p if has_lower else 0), hi - (p if has_upper else 0))
+        if n_lower:
+            boundary.append(box(lo, lo + n_lower))
+        if n_upper:
+            boundary.append(box(hi - n_upper, hi))
+        return boundary, box(lo + n_lower, hi - n_upper)
 
     def boxes_share_no_node(self, boxes):
         """True when no node is touched by the elements of two of `boxes` (element boxes that differ along the sharding

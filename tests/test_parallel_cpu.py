@@ -132,3 +132,24 @@ def test_boundary_boxes_that_may_run_concurrently():
     thin = parallel.SlabShard(mimi_amd.BSplinePatch.block((3, 3, 15), 2), None, 1, 3)   # 5 layers: 2 + 1 + 2
     boundary, _ = thin.overlap_boxes()
     assert len(boundary) == 2 and not thin.boxes_share_no_node(boundary)
+
+
+def test_owner_mode_needs_fewer_boundary_layers():
+    """owner mode sends upward only the planes the upper rank owns (touched by the last p - p // 2 element layers) and
+    downward only those the lower rank owns (first p // 2 layers); replicate sends all p shared planes (p layers each)"""
+    import mimi_amd
+    from mimi_amd import parallel
+    for p, lower, upper in ((1, 0, 1), (2, 1, 1), (3, 1, 2)):
+        patch = mimi_amd.BSplinePatch.block((3, 3, 30), p)
+        sh = parallel.SlabShard(patch, None, 1, 3)              # layers 10..19
+        boundary, interior = sh.overlap_boxes(mode="owner")
+        sizes = sorted((b[2], e[2]) for b, e in boundary)
+        expect = ([(10, 10 + lower)] if lower else []) + [(20 - upper, 20)]
+        assert sizes == expect and (interior[0][2], interior[1][2]) == (10 + lower, 20 - upper)
+        # the planes that leave upward, [20 + p // 2, 20 + p), are touched by the upper boundary box only
+        first_plane_sent_up = 20 + p // 2
+        assert interior[1][2] - 1 + p < first_plane_sent_up          # last interior layer's highest node plane
+        # ... and those that leave downward, [10, 10 + p // 2), by the lower one only
+        assert lower == 0 or interior[0][2] >= 10 + p // 2
+        boundary_r, interior_r = sh.overlap_boxes(mode="replicate")
+        assert sorted((b[2], e[2]) for b, e in boundary_r) == [(10, 10 + p), (20 - p, 20)]

@@ -64,7 +64,7 @@ def _worker(rank, world, port, n_el, mode, q):
         torch.cuda.set_stream(stream)
         overlap = "+overlap" in mode
         mode = mode.split("+")[0]
-        boundary_boxes, interior_box = shard.overlap_boxes() if overlap else ([], shard.element_box)
+        boundary_boxes, interior_box = shard.overlap_boxes(mode=mode) if overlap else ([], shard.element_box)
         handles = []
         for box in boundary_boxes + [interior_box]:
             g = NonlinearSolid("domain", bench.make_material("neohookean"), pattern, patch=patch, element_box=box).Prepare()

@@ -39,7 +39,7 @@ def _worker(port, n_el, p, fake_rank, fake_world, mode, q):
         shard.pattern = pattern
         stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(stream)
-        boundary_boxes, interior_box = shard.overlap_boxes()
+        boundary_boxes, interior_box = shard.overlap_boxes(mode=mode)
         assert boundary_boxes
         handles = []
         for box in boundary_boxes + [interior_box]:
