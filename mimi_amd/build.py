@@ -25,8 +25,21 @@ def build(force=False, verbose=False, extra_flags=()):
     """Compile every HIP source of the package into mimi_amd/lib/libmimi_hip.so."""
     if not force and not _stale():
         return LIB
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(LIBDIR, exist_ok=True)
+    # one builder at a time (the ranks of a multi-GPU job all come through here at once); whoever waited finds it done
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB
+            return _build_locked(force, verbose, extra_flags)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, extra_flags):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
