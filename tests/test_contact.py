@@ -110,6 +110,82 @@ def test_contact_parity_gpu(n_el, p, axis, bodykind):
         assert rel(A_g - A0, A_o - A0) < tol
 
 
+# ---- a case with a closed-form answer: the only pin this path has that does not pass through the oracle's author ------
+KNOWN = [((4, 4, 2), 2, 2), ((5, 3), 3, 1), ((3, 4, 3), 3, 2)]
+
+
+def _n_face_points(n_el, p, axis):
+    return int(np.prod([n for d, n in enumerate(n_el) if d != axis])) * (p + 2) ** (len(n_el) - 1)
+
+
+def _uniform_penetration(P, axis, delta):
+    """rigid half-space whose face lies `delta` below the undeformed top face: every face point penetrates by delta"""
+    L = P.ctrl.max(axis=0)
+    point = [0.0] * P.dim
+    point[axis] = L[axis] - delta
+    normal = [0.0] * P.dim
+    normal[axis] = -1.0
+    area = float(np.prod([L[d] for d in range(P.dim) if d != axis]))
+    return point, normal, area
+
+
+def _check_uniform_penetration(P, axis, delta, penalty, area, r, pressure, last_area, last_force, gap_norm, tol, n_points):
+    """mortar_contact.cpp:195-261 on a uniform gap g = -delta: the area-averaged nodal gap is -delta at EVERY node (the
+    shape functions sum to one), so the pressure is penalty * (-delta) everywhere, the traction is uniform and normal,
+    its resultant is penalty * delta * area, and the residual is that resultant distributed over the face nodes with
+    weights that sum to one; nothing acts tangentially or on nodes off the face.  GapNorm (mortar_contact.cpp:423-467) is
+    the root of the UNWEIGHTED sum of g^2 over the face quadrature points: delta * sqrt(number of points)."""
+    top = P.boundary_nodes(axis, 1)
+    rr = np.asarray(r).reshape(-1, P.dim)
+    force = penalty * delta * area
+    assert np.allclose(pressure, -penalty * delta, rtol=tol, atol=0.0)
+    assert abs(last_area - area) < tol * area
+    assert abs(last_force[axis] + force) < tol * force
+    assert np.abs(np.delete(np.asarray(last_force), axis)).max() < tol * force
+    assert abs(rr[top, axis].sum() - force) < tol * force
+    assert np.abs(np.delete(rr, axis, axis=1)).max() < tol * force
+    assert np.abs(np.delete(rr, top, axis=0)).max() == 0.0
+    assert (rr[top, axis] > 0).all()
+    assert abs(gap_norm - delta * np.sqrt(n_points)) < tol * delta * np.sqrt(n_points)
+
+
+@pytest.mark.parametrize("n_el,p,axis", KNOWN)
+def test_oracle_contact_uniform_penetration_known_answer(n_el, p, axis):
+    from oracle import iga, ref_path as rp
+    P = iga.Patch.block(n_el, p)
+    delta, penalty = 0.013, 1e4
+    point, normal, area = _uniform_penetration(P, axis, delta)
+    rowptr, col = P.sparsity()
+    Cn = rp.ContactOracle(P, axis, 1, dict(kind="plane", point=point, normal=normal), penalty=penalty, rowptr=rowptr, col=col)
+    u = np.zeros(P.n_vdofs)
+    r = np.zeros(P.n_vdofs)
+    Cn.add_boundary_residual(u, r)
+    _check_uniform_penetration(P, axis, delta, penalty, area, r, Cn.pressure, Cn.last_area, Cn.last_force, Cn.gap_norm(u), 1e-11,
+                               _n_face_points(n_el, p, axis))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_el,p,axis", KNOWN)
+def test_contact_uniform_penetration_known_answer_gpu(n_el, p, axis):
+    """the same closed form through the HIP integrator: no oracle in the loop"""
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, MortarContact, RigidPlane
+    from oracle import iga
+    P = iga.Patch.block(n_el, p)                       # (node bookkeeping of the check only)
+    delta, penalty = 0.013, 1e4
+    point, normal, area = _uniform_penetration(P, axis, delta)
+    rowptr, col = P.sparsity()
+    patch = mimi_amd.BSplinePatch.block(n_el, p)
+    pattern = CSRPattern(rowptr.astype(np.int64), col.astype(np.int32), rowptr[-1])
+    G = MortarContact(RigidPlane(point, normal, penalty), "contact", pattern, patch, axis, 1).Prepare()
+    u = np.zeros(P.n_vdofs)
+    r = np.zeros(P.n_vdofs)
+    G.AddBoundaryResidual(u, r)
+    G.BoundaryPostTimeAdvance(u)
+    _check_uniform_penetration(P, axis, delta, penalty, area, r, G.AveragePressure(), G.last_area_, G.last_force_, G.GapNorm(u), 1e-11,
+                               _n_face_points(n_el, p, axis))
+
+
 # ---- rigid SPLINE bodies (NearestDistanceToSplines, coefficients/nearest_distance.hpp:215-288) ---------------------
 def nurbs_circle(center, R):
     """the standard 9-point quadratic NURBS circle, counter-clockwise (outward normal (t_y, -t_x))"""
