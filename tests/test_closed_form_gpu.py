@@ -2,7 +2,8 @@
 
 A homogeneous deformation u(X) = (F - I) X is a member of every spline space here (the blocks are mapped linearly,
 control points at the Greville abscissae), so the deformation gradient is F at every quadrature point and the first
-Piola-Kirchhoff stress is the constant P(F) of the reference's material -- written out below from the reference's source.
+Piola-Kirchhoff stress is the constant P(F) of the reference's material -- written out below from the reference's source
+(neo-Hookean and St. Venant-Kirchhoff at finite strain; J2 and J2Linear below yield, where their law is the elastic one).
 The residual is r_(a,i) = int P_iJ dN_a/dX_J dV (integrators/nonlinear_solid.cpp:48-76), and because sum_a N_a X_a = X,
 
     sum_a X_(a,K) r_(a,i)        = V P_iK(F)                                   (residual)
@@ -37,9 +38,26 @@ def pk1(kind, F):
         J = np.linalg.det(F)
         sigma = mu / J * (F @ F.T - np.eye(dim)) + lam * (J - 1.0) * np.eye(dim)
         return J * sigma @ np.linalg.inv(F).T
+    if kind in ("j2", "j2linear"):
+        # J2 / J2Linear below yield (materials.hpp:204-208, 330-333, no plastic strain yet): eps = sym(F) - I
+        # (material_utils.hpp:61-84), sigma = K tr(eps) I + 2 G dev(eps) with dev over `dim` (material_utils.hpp:22-60),
+        # K = E / (3 (1 - 2 nu)), G = mu (materials.cpp:12-13); P = J sigma F^-T (materials.cpp:60-71)
+        K = YOUNG / (3.0 * (1.0 - 2.0 * POISSON))
+        eps = 0.5 * (F + F.T) - np.eye(dim)
+        sigma = K * np.trace(eps) * np.eye(dim) + 2.0 * mu * (eps - np.trace(eps) / dim * np.eye(dim))
+        return np.linalg.det(F) * sigma @ np.linalg.inv(F).T
     # StVenantKirchhoff::EvaluatePK1 (materials.cpp:73-94): C = F^T F, E = (C - I) / 2, S = lambda tr(E) I + 2 mu E, P = F S
     E = 0.5 * (F.T @ F - np.eye(dim))
     return F @ (lam * np.trace(E) * np.eye(dim) + 2.0 * mu * E)
+
+
+def von_mises(F):
+    """q = sqrt(3/2) |s| of the elastic predictor above: the J2 cases must stay below the initial yield stress (70)"""
+    lam, mu = lame()
+    dim = F.shape[0]
+    eps = 0.5 * (F + F.T) - np.eye(dim)
+    s = 2.0 * mu * (eps - np.trace(eps) / dim * np.eye(dim))
+    return np.sqrt(1.5) * np.linalg.norm(s)
 
 
 def dpk1(kind, F, dF):
@@ -52,6 +70,15 @@ def dpk1(kind, F, dF):
         Fi = np.linalg.inv(F)
         t = np.trace(Fi @ dF)
         return mu * (dF + Fi.T @ dF.T @ Fi.T) + lam * ((2 * J - 1) * J * t * Fi.T - J * (J - 1) * Fi.T @ dF.T @ Fi.T)
+    if kind in ("j2", "j2linear"):
+        K = YOUNG / (3.0 * (1.0 - 2.0 * POISSON))
+        J = np.linalg.det(F)
+        Fi = np.linalg.inv(F)
+        eps = 0.5 * (F + F.T) - np.eye(dim)
+        deps = 0.5 * (dF + dF.T)
+        sigma = K * np.trace(eps) * np.eye(dim) + 2.0 * mu * (eps - np.trace(eps) / dim * np.eye(dim))
+        dsigma = K * np.trace(deps) * np.eye(dim) + 2.0 * mu * (deps - np.trace(deps) / dim * np.eye(dim))
+        return J * np.trace(Fi @ dF) * sigma @ Fi.T + J * dsigma @ Fi.T - J * sigma @ Fi.T @ dF.T @ Fi.T
     E = 0.5 * (F.T @ F - np.eye(dim))
     dE = 0.5 * (dF.T @ F + F.T @ dF)
     S = lam * np.trace(E) * np.eye(dim) + 2.0 * mu * E
@@ -77,11 +104,8 @@ def csr_times(rowptr, col, values, w, chunk_nnz=1 << 27):
 
 
 def material(kind):
-    import mimi_amd
-    m = mimi_amd.CompressibleOgdenNeoHookean() if kind == "neohookean" else mimi_amd.StVenantKirchhoff()
-    m.density = 1.0
-    m.set_young_poisson(YOUNG, POISSON)
-    return m
+    import bench
+    return bench.make_material(kind)        # Young 2100, Poisson 0.3; J2: Johnson-Cook A = 70; J2Linear: sigma_y = 70
 
 
 def check_block(n_el, p, kind, lengths=None, tol_r=1e-12, tol_k=1e-11):
@@ -90,8 +114,11 @@ def check_block(n_el, p, kind, lengths=None, tol_r=1e-12, tol_k=1e-11):
     from mimi_amd.integrators import CSRPattern, NonlinearSolid
     dim = len(n_el)
     rng = np.random.default_rng(20241008)
-    F = np.eye(dim) + 0.06 * rng.standard_normal((dim, dim))
+    elastoplastic = kind in ("j2", "j2linear")
+    F = np.eye(dim) + (0.004 if elastoplastic else 0.06) * rng.standard_normal((dim, dim))
     dF = rng.standard_normal((dim, dim))
+    if elastoplastic:
+        assert von_mises(F) < 0.5 * 70.0            # well inside the elastic range: the closed form is the elastic law
     # the hand-differentiated dP against central differences of P (both are the test's own closed forms)
     eps = 1e-6
     fd = (pk1(kind, F + eps * dF) - pk1(kind, F - eps * dF)) / (2 * eps)
@@ -101,6 +128,7 @@ def check_block(n_el, p, kind, lengths=None, tol_r=1e-12, tol_k=1e-11):
     dev = torch.device("cuda", 0)
     pattern = CSRPattern.of_bspline_patch(patch, on_device=True)
     G = NonlinearSolid("domain", material(kind), pattern, patch=patch).Prepare()
+    G.dt_ = 0.5
     assert G.path_ == 1
     X = torch.from_numpy(np.ascontiguousarray(patch.control_points, dtype=np.float64)).to(dev)      # [n_nodes][dim]
     V = float(np.prod(patch.control_points.max(axis=0) - patch.control_points.min(axis=0)))
@@ -127,7 +155,8 @@ def check_block(n_el, p, kind, lengths=None, tol_r=1e-12, tol_k=1e-11):
 
 
 SMALL = [((7, 5), 1, "neohookean"), ((6, 5), 2, "neohookean"), ((5, 4), 3, "stvk"), ((4, 3, 5), 1, "neohookean"),
-         ((4, 5, 3), 2, "neohookean"), ((3, 3, 4), 3, "neohookean"), ((4, 3, 3), 2, "stvk"), ((3, 2, 3), 3, "stvk")]
+         ((4, 5, 3), 2, "neohookean"), ((3, 3, 4), 3, "neohookean"), ((4, 3, 3), 2, "stvk"), ((3, 2, 3), 3, "stvk"),
+         ((6, 4), 3, "j2"), ((4, 3, 4), 2, "j2"), ((3, 3, 4), 3, "j2"), ((5, 4), 2, "j2linear"), ((3, 4, 3), 2, "j2linear")]
 
 
 @pytest.mark.parametrize("n_el,p,kind", SMALL, ids=lambda c: str(c).replace(" ", ""))
@@ -135,16 +164,17 @@ def test_homogeneous_deformation_small(n_el, p, kind):
     check_block(n_el, p, kind, lengths=[1.0 + 0.5 * d for d in range(len(n_el))])
 
 
-FULL = {"northstar": ((128, 128, 16), 2), "cfg4_domain": ((96, 96, 12), 2), "cfg3_neohookean": ((128, 128, 16), 3),
-        "cfg5": ((256, 256, 32), 2)}
+FULL = {"northstar": ((128, 128, 16), 2, "neohookean"), "cfg4_domain": ((96, 96, 12), 2, "neohookean"),
+        "cfg3": ((128, 128, 16), 3, "j2"), "cfg3_neohookean": ((128, 128, 16), 3, "neohookean"),
+        "cfg5": ((256, 256, 32), 2, "neohookean")}
 
 
 @pytest.mark.parametrize("name", list(FULL))
 def test_homogeneous_deformation_at_baseline_sizes(name):
-    """BASELINE.json's meshes at full size (cfg3's mesh and degree with the neo-Hookean law: J2 has no closed form to offer
-    here); cfg5's value array has rows beyond 2^31 entries"""
-    n_el, p = FULL[name]
+    """BASELINE.json's meshes at full size with their materials (cfg3's J2 below yield, where its law is closed-form, and
+    the same mesh with the neo-Hookean law at finite strain); cfg5's value array has rows beyond 2^31 entries"""
+    n_el, p, kind = FULL[name]
     # (the moment sum runs over up to 6.8 M nodes whose interior residual entries are cancellation noise weighted with
     # coordinates up to 256: measured 3e-13 at the north-star size, 1.4e-12 at cfg5 -- one bar of 1e-11 for both sums)
-    err_r, err_k = check_block(n_el, p, "neohookean", tol_r=1e-11, tol_k=1e-11)
+    err_r, err_k = check_block(n_el, p, kind, tol_r=1e-11, tol_k=1e-11)
     print(f"{name}: residual {err_r:.2e}, tangent {err_k:.2e}")
