@@ -3,7 +3,8 @@
 A homogeneous deformation u(X) = (F - I) X is a member of every spline space here (the blocks are mapped linearly,
 control points at the Greville abscissae), so the deformation gradient is F at every quadrature point and the first
 Piola-Kirchhoff stress is the constant P(F) of the reference's material -- written out below from the reference's source
-(neo-Hookean and St. Venant-Kirchhoff at finite strain; J2 and J2Linear below yield, where their law is the elastic one).
+(neo-Hookean and St. Venant-Kirchhoff at finite strain; J2 and J2Linear below yield, where their law is the elastic one;
+J2Linear beyond yield from the virgin state, whose return mapping is closed-form).
 The residual is r_(a,i) = int P_iJ dN_a/dX_J dV (integrators/nonlinear_solid.cpp:48-76), and because sum_a N_a X_a = X,
 
     sum_a X_(a,K) r_(a,i)        = V P_iK(F)                                   (residual)
@@ -38,6 +39,21 @@ def pk1(kind, F):
         J = np.linalg.det(F)
         sigma = mu / J * (F @ F.T - np.eye(dim)) + lam * (J - 1.0) * np.eye(dim)
         return J * sigma @ np.linalg.inv(F).T
+    if kind == "j2linear_plastic":
+        # J2Linear::PlasticStress beyond yield from the virgin state (materials.hpp:196-240; Computational Methods for
+        # Plasticity box 7.5): trial s = 2 G dev(eps), eta = s - beta = s, q = sqrt(3/2) |eta|, phi = q - sigma_y > 0,
+        # increment phi / (3 G + H_kin + H_iso), s -= sqrt(6) G increment eta / |eta|, sigma = s + K tr(eps) I
+        K = YOUNG / (3.0 * (1.0 - 2.0 * POISSON))
+        h_iso, h_kin, sigma_y = 40.0, 25.0, 70.0                  # bench.make_material("j2linear")
+        eye = np.eye(dim)
+        eps = 0.5 * (F + F.T) - eye
+        s = 2.0 * mu * (eps - np.trace(eps) / dim * eye)
+        norm = np.sqrt((s * s).sum())                             # (no abs: F may carry a complex step)
+        phi = np.sqrt(1.5) * norm - sigma_y
+        assert phi.real > 0
+        s = s - np.sqrt(6.0) * mu * (phi / (3.0 * mu + h_kin + h_iso)) * s / norm
+        sigma = s + K * np.trace(eps) * eye
+        return np.linalg.det(F) * sigma @ np.linalg.inv(F).T
     if kind in ("j2", "j2linear"):
         # J2 / J2Linear below yield (materials.hpp:204-208, 330-333, no plastic strain yet): eps = sym(F) - I
         # (material_utils.hpp:61-84), sigma = K tr(eps) I + 2 G dev(eps) with dev over `dim` (material_utils.hpp:22-60),
@@ -61,9 +77,12 @@ def von_mises(F):
 
 
 def dpk1(kind, F, dF):
-    """directional derivative of pk1 (differentiated by hand; checked against central differences in the test)"""
+    """directional derivative of pk1: differentiated by hand (checked against a complex step of pk1 in the test), or the
+    complex step itself where the hand derivative would be longer than the law"""
     lam, mu = lame()
     dim = F.shape[0]
+    if kind == "j2linear_plastic":
+        return complex_step(kind, F, dF)
     if kind == "neohookean":
         # P = mu (F - F^-T) + lambda J (J - 1) F^-T
         J = np.linalg.det(F)
@@ -86,6 +105,11 @@ def dpk1(kind, F, dF):
     return dF @ S + F @ dS
 
 
+def complex_step(kind, F, dF, h=1e-30):
+    """Im pk1(F + i h dF) / h: the directional derivative to rounding (pk1 uses no abs / conj)"""
+    return np.imag(pk1(kind, F.astype(complex) + 1j * h * dF)) / h
+
+
 def csr_times(rowptr, col, values, w, chunk_nnz=1 << 27):
     """y = A w with plain torch indexing, a chunk of rows at a time"""
     import torch
@@ -105,7 +129,7 @@ def csr_times(rowptr, col, values, w, chunk_nnz=1 << 27):
 
 def material(kind):
     import bench
-    return bench.make_material(kind)        # Young 2100, Poisson 0.3; J2: Johnson-Cook A = 70; J2Linear: sigma_y = 70
+    return bench.make_material(kind.split("_")[0])        # Young 2100, Poisson 0.3; J2: Johnson-Cook A = 70; J2Linear: sigma_y = 70
 
 
 def check_block(n_el, p, kind, lengths=None, tol_r=1e-12, tol_k=1e-11):
@@ -114,15 +138,19 @@ def check_block(n_el, p, kind, lengths=None, tol_r=1e-12, tol_k=1e-11):
     from mimi_amd.integrators import CSRPattern, NonlinearSolid
     dim = len(n_el)
     rng = np.random.default_rng(20241008)
-    elastoplastic = kind in ("j2", "j2linear")
-    F = np.eye(dim) + (0.004 if elastoplastic else 0.06) * rng.standard_normal((dim, dim))
+    elastic_only = kind in ("j2", "j2linear")
+    F = np.eye(dim) + (0.004 if elastic_only else 0.06) * rng.standard_normal((dim, dim))
     dF = rng.standard_normal((dim, dim))
-    if elastoplastic:
+    if elastic_only:
         assert von_mises(F) < 0.5 * 70.0            # well inside the elastic range: the closed form is the elastic law
-    # the hand-differentiated dP against central differences of P (both are the test's own closed forms)
+    if kind == "j2linear_plastic":
+        assert von_mises(F) > 1.5 * 70.0            # well beyond yield at every point
+    # the hand-differentiated dP against a complex step of P and against central differences (the test's own closed forms)
+    cs = complex_step(kind, F, dF)
+    assert np.abs(cs - dpk1(kind, F, dF)).max() < 1e-13 * np.abs(cs).max()
     eps = 1e-6
     fd = (pk1(kind, F + eps * dF) - pk1(kind, F - eps * dF)) / (2 * eps)
-    assert np.abs(fd - dpk1(kind, F, dF)).max() < 1e-6 * np.abs(fd).max()
+    assert np.abs(fd - cs).max() < 1e-6 * np.abs(fd).max()
 
     patch = mimi_amd.BSplinePatch.block(n_el, p, lengths) if lengths else mimi_amd.BSplinePatch.block(n_el, p)
     dev = torch.device("cuda", 0)
@@ -156,7 +184,8 @@ def check_block(n_el, p, kind, lengths=None, tol_r=1e-12, tol_k=1e-11):
 
 SMALL = [((7, 5), 1, "neohookean"), ((6, 5), 2, "neohookean"), ((5, 4), 3, "stvk"), ((4, 3, 5), 1, "neohookean"),
          ((4, 5, 3), 2, "neohookean"), ((3, 3, 4), 3, "neohookean"), ((4, 3, 3), 2, "stvk"), ((3, 2, 3), 3, "stvk"),
-         ((6, 4), 3, "j2"), ((4, 3, 4), 2, "j2"), ((3, 3, 4), 3, "j2"), ((5, 4), 2, "j2linear"), ((3, 4, 3), 2, "j2linear")]
+         ((6, 4), 3, "j2"), ((4, 3, 4), 2, "j2"), ((3, 3, 4), 3, "j2"), ((5, 4), 2, "j2linear"), ((3, 4, 3), 2, "j2linear"),
+         ((5, 4), 3, "j2linear_plastic"), ((4, 3, 4), 2, "j2linear_plastic"), ((3, 3, 3), 3, "j2linear_plastic")]
 
 
 @pytest.mark.parametrize("n_el,p,kind", SMALL, ids=lambda c: str(c).replace(" ", ""))
