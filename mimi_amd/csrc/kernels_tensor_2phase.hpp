@@ -7,15 +7,18 @@
 // integration kernel only STORES: its row pieces go, coalesced, to a dense scratch, and a second
 // kernel that owns CSR rows gathers them and does ONE coalesced read-modify-write per row.
 //
-//   phase 1  stores, for every (element, i), a piece of 2187 slots in scratch_k and the residual piece
-//            scratch_r[element][i][a].  Entries shared with the next element of the walked (third) axis are
-//            carried inside the kernel, so each (node pair, element column) is stored exactly once, by the
-//            highest element of the column that contains both nodes.  Piece layout (a = a0 + 3 a1 + 9 a2 local
-//            row node, (b2,b1,b0) local column node, j column component), what phase 2 reads contiguously:
-//              [0, 729)      rows a < 9 (a2 = 0):            a 81 + b2 27 + b1 9 + b0 3 + j
-//              [729, 1215)   rows a >= 9, b2 = 0:            729 + (a - 9) 27 + b1 9 + b0 3 + j
-//              [1215, 2187)  rows a >= 9, b2 = 1, 2 (written by the last element of a column only):
-//                                                            1215 + (a - 9) 54 + (b2 - 1) 27 + b1 9 + b0 3 + j
+//   phase 1  stores, for every element, a block of 3 x 2187 slots in scratch_k -- the pieces of the three row components I,
+//            interleaved ROW BY ROW -- and the residual piece scratch_r[element][i][a].  Entries shared with the next
+//            element of the walked (third) axis are carried inside the kernel, so each (node pair, element column) is
+//            stored exactly once, by the highest element of the column that contains both nodes.  Block layout (P2Block;
+//            a = a0 + 3 a1 + 9 a2 local row node, (b2,b1,b0) local column node, j column component):
+//              [0, 2187)      rows a < 9 (a2 = 0):            a 243 + I 81 + b2 27 + b1 9 + b0 3 + j
+//              [2187, 3645)   rows a >= 9, b2 = 0:            2187 + (a - 9) 81 + I 27 + b1 9 + b0 3 + j
+//              [3645, 6561)   rows a >= 9, b2 = 1, 2 (written by the last element of a column / segment only):
+//                                                             3645 + (a - 9) 162 + I 54 + (b2 - 1) 27 + b1 9 + b0 3 + j
+//            so that everything phase 2 needs of one element for one node A -- the three rows (a, I) -- is ONE run of
+//            243 (or 81, or 81 + 162) doubles: scattered reads of 1 944 B reach 6.0 TB/s on this chip, of 648 B 4.5, of
+//            216 B 2.1 (scratch/run_bench.hip), and the rows used to be separate runs of 648 / 216 B.
 //   phase 2  tensor_p2_kernel below.
 // Results are bitwise reproducible; nothing is atomic.
 #pragma once
@@ -28,25 +31,33 @@ namespace mimi_hip {
 
 typedef double mh_d4 __attribute__((ext_vector_type(4)));
 
+struct P2Block {
+  static constexpr int size = 3 * 27 * 81;          // 6561 doubles per element
+  static constexpr int off_b20 = 9 * 243;           // 2187
+  static constexpr int off_tail = off_b20 + 18 * 81;  // 3645
+  // where piece I keeps its carried rows: + (a - 9) 162 + (b2 - 1) 27 + b1 9 + b0 3 + j
+  MH_DEV static double* carry_of(double* E, int I) { return E + off_tail + I * 54; }
+};
+
 // phase 2: gather.  Requires: the structured CSR pattern (lexicographic numbering, or a permuted one with
 // the window ranks of permuted_window_kernel) and first[e] == e (no repeated interior knots).
 //
-// One wave per node A (its three CSR rows).  The wave walks the <= 27 elements that contain A; of
-// each piece (element, i) it needs row a = local index of A: 81 contiguous doubles [b2][b1][b0][j]
-// (or the first 27, b2 = 0, when the element is not the one that stored the (a2 >= 1) entries).
-// lane = position in that row, so the reads are contiguous runs; the position of (b, j) in A's CSR
-// row is  t = t_base(element) + t_off(lane)  with a per-lane constant t_off.  Row sums are built
-// in LDS (one wave adds piece after piece: fixed order, no conflicts inside an instruction), then
+// One wave per node A (its three CSR rows).  The wave walks the <= 27 elements that contain A; of each element block it
+// needs the rows (a, I = 0..2) of a = local index of A: one run of 243 doubles [I][b2][b1][b0][j] when a2 = 0, else one of
+// 81 ([I][b1][b0][j], b2 = 0) plus, when the element is the one that stored the (a2 >= 1, b2 >= 1) entries, one of 162.
+// lane + 64 t = position in the run, so the reads are contiguous; the position of (I, b, j) in the wave's LDS image of
+// A's three rows is  I (LMAX + 1) + t_base(element) + t_off(b, j)  with per-lane constants for the run shape at hand.
+// Row sums are built in LDS (one wave adds run after run: fixed order, no conflicts inside an instruction), then
 // A[row] += grad_factor * sum is one coalesced read-modify-write per row.
 __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_nodes) {
-  constexpr int P = 2, NB = 3, ND = 27, NROW = 81, NK = ND * NROW;
-  constexpr int LMAX = 3 * 125;
-  __shared__ double sums_all[4][3][LMAX + 1];
+  constexpr int P = 2, NB = 3, ND = 27, NROW = 81;
+  constexpr int LMAX = 3 * 125, SROW = LMAX + 1;
+  __shared__ double sums_all[4][3 * SROW];
   const int wave = threadIdx.x >> 6;
   const int64_t Al = (int64_t)blockIdx.x * 4 + wave;   // node index inside the shard's node box
   const int lane = threadIdx.x & 63;
   if (Al >= n_nodes) return;
-  double (*sums)[LMAX + 1] = sums_all[wave];
+  double* sums = sums_all[wave];
   const int n0 = p.n_ctrl[0], n1 = p.n_ctrl[1], n2 = p.n_ctrl[2];
   const int m0 = p.box_n[0] + P, m1 = p.box_n[1] + P;
   const int A0 = p.box_begin[0] + (int)(Al % m0), A1 = p.box_begin[1] + (int)((Al / m0) % m1);
@@ -67,41 +78,63 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
     return (ex - bx0) + (int64_t)p.box_n[0] * ((ey - bx1) + (int64_t)p.box_n[1] * (ez - bx2));
   };
   for (int t = lane; t < L; t += 64) {
-    sums[0][t] = 0.0;
-    sums[1][t] = 0.0;
-    sums[2][t] = 0.0;
+    sums[t] = 0.0;
+    sums[SROW + t] = 0.0;
+    sums[2 * SROW + t] = 0.0;
   }
-  // lane constants: row positions k0 = lane and k1 = lane + 64 (< 81), k = ((b2 3 + b1) 3 + b0) 3 + j
-  const int k1 = lane + 64;
-  const int toff0 = 3 * ((lane / 3) % 3 + w0 * ((lane / 9) % 3 + w1 * (lane / 27))) + lane % 3;
-  const int toff1 = 3 * ((k1 / 3) % 3 + w0 * ((k1 / 9) % 3 + w1 * (k1 / 27))) + k1 % 3;
+  // position of column (b, j), k = ((b2 3 + b1) 3 + b0) 3 + j, relative to the element's first column in A's row
+  auto toff = [&](int k) -> int { return 3 * ((k / 3) % 3 + w0 * ((k / 9) % 3 + w1 * (k / 27))) + k % 3; };
   __builtin_amdgcn_wave_barrier();
   for (int ez = ez_lo; ez <= ez_hi; ++ez) {
     const int a2 = A2 - ez;
-    const bool unit_end = ez == last_ez || (ez - bx2) % p.seg_len == p.seg_len - 1;
-    const int nb = (a2 == 0 || unit_end) ? NROW : ND;
-    const bool act0 = lane < nb, act1 = k1 < nb;
-    // P2_BATCH pieces in flight per wave (registers against occupancy)
+    const bool full = a2 == 0;                                                                  // (wave-uniform)
+    const bool tail = !full && (ez == last_ez || (ez - bx2) % p.seg_len == p.seg_len - 1);     // (wave-uniform)
+    // lane constants of the run shape: value lane + 64 t of the first run (243 = [I][81] or 81 = [I][27]) ...
+    const int per = full ? NROW : ND, len0 = 3 * per;
+    int loff0[4];
+    bool act0[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int v = lane + 64 * t;
+      act0[t] = v < len0;
+      const int vv = act0[t] ? v : 0;
+      loff0[t] = (vv / per) * SROW + toff(vv % per);
+    }
+    // ... and of the run of carried rows (162 = [I][54], b2 = 1, 2)
+    int loff1[3];
+    bool act1[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int v = lane + 64 * t;
+      act1[t] = v < 162;
+      const int vv = act1[t] ? v : 0;
+      loff1[t] = (vv / 54) * SROW + toff(ND + vv % 54);
+    }
+    // P2_BATCH elements in flight per wave (registers against occupancy)
 #ifndef P2_BATCH
 #define P2_BATCH 3
 #endif
     for (int c0 = 0; c0 < 9; c0 += P2_BATCH) {
-      double v0[P2_BATCH][3], v1[P2_BATCH][3];
+      double v0[P2_BATCH][4], v1[P2_BATCH][3];
 #pragma unroll
       for (int cc = 0; cc < P2_BATCH; ++cc) {
         const int c = c0 + cc;
         const int ey = ey_lo + c / 3, ex = ex_lo + c % 3;
         const bool in = c < 9 && ey <= ey_hi && ex <= ex_hi;
         const int a = (A0 - ex) + NB * ((A1 - ey) + NB * a2);
-        const double* piece = p.scratch_k + (elem(in ? ex : ex_lo, in ? ey : ey_lo, ez) * 3) * (int64_t)NK;
-        // row a of the piece: 81 contiguous values (a2 = 0), or 27 (b2 = 0) [+ 54 (b2 = 1, 2) from the last element]
-        const int a9 = in ? a - 9 : 0;
-        const int o0 = !in ? 0 : (a2 == 0 ? a * NROW + lane : (lane < ND ? 9 * NROW + a9 * ND + lane : 15 * NROW + a9 * 54 + lane - ND));
-        const int o1 = !in ? 0 : (a2 == 0 ? a * NROW + k1 : 15 * NROW + a9 * 54 + k1 - ND);
+        const double* E = p.scratch_k + elem(in ? ex : ex_lo, in ? ey : ey_lo, ez) * (int64_t)P2Block::size;
+        const int a9 = in && !full ? a - 9 : 0;
+        const double* run0 = E + (full ? (in ? a : 0) * 3 * NROW : P2Block::off_b20 + a9 * NROW) + lane;
 #pragma unroll
-        for (int I = 0; I < 3; ++I) {
-          v0[cc][I] = (in && act0) ? piece[I * NK + o0] : 0.0;
-          v1[cc][I] = (in && act1) ? piece[I * NK + o1] : 0.0;
+        for (int t = 0; t < 2; ++t) v0[cc][t] = (in && act0[t]) ? run0[64 * t] : 0.0;
+        if (full) {
+#pragma unroll
+          for (int t = 2; t < 4; ++t) v0[cc][t] = (in && act0[t]) ? run0[64 * t] : 0.0;
+        }
+        if (tail) {
+          const double* run1 = E + P2Block::off_tail + a9 * 162 + lane;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) v1[cc][t] = (in && act1[t]) ? run1[64 * t] : 0.0;
         }
       }
 #pragma unroll
@@ -112,9 +145,17 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
         const int tbase = 3 * ((ex - lo0) + w0 * ((ey - lo1) + w1 * (ez - lo2)));
         if (in) {
 #pragma unroll
-          for (int I = 0; I < 3; ++I) {
-            if (act0) sums[I][tbase + toff0] += v0[cc][I];
-            if (act1) sums[I][tbase + toff1] += v1[cc][I];
+          for (int t = 0; t < 2; ++t)
+            if (act0[t]) sums[tbase + loff0[t]] += v0[cc][t];
+          if (full) {
+#pragma unroll
+            for (int t = 2; t < 4; ++t)
+              if (act0[t]) sums[tbase + loff0[t]] += v0[cc][t];
+          }
+          if (tail) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+              if (act1[t]) sums[tbase + loff1[t]] += v1[cc][t];
           }
         }
         __builtin_amdgcn_wave_barrier();
@@ -122,15 +163,30 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
     }
   }
   __builtin_amdgcn_wave_barrier();
+  if (p.perm) {
 #pragma unroll
-  for (int I = 0; I < 3; ++I) {
-    double* row = p.A + p.rowptr[gA * 3 + I];
-    if (p.perm) {
+    for (int I = 0; I < 3; ++I) {
+      double* row = p.A + p.rowptr[gA * 3 + I];
       const unsigned char* pos = p.nbr_pos + A * 125;
-      for (int t = lane; t < L; t += 64) row[3 * (int)pos[t / 3] + t % 3] += p.grad_factor * sums[I][t];
-    } else {
-      for (int t = lane; t < L; t += 64) row[t] += p.grad_factor * sums[I][t];
+      for (int t = lane; t < L; t += 64) row[3 * (int)pos[t / 3] + t % 3] += p.grad_factor * sums[I * SROW + t];
     }
+  } else {
+    // all 18 loads of the three rows in flight together (L <= 375 = 6 x 64 - 9), then the adds and the stores: one
+    // round trip to memory per wave instead of one per 64 values
+    constexpr int NT = (LMAX + 63) / 64;
+    double* row[3];
+    double old[3][NT];
+#pragma unroll
+    for (int I = 0; I < 3; ++I) {
+      row[I] = p.A + p.rowptr[gA * 3 + I] + lane;
+#pragma unroll
+      for (int q = 0; q < NT; ++q) old[I][q] = lane + 64 * q < L ? row[I][64 * q] : 0.0;
+    }
+#pragma unroll
+    for (int I = 0; I < 3; ++I)
+#pragma unroll
+      for (int q = 0; q < NT; ++q)
+        if (lane + 64 * q < L) row[I][64 * q] = old[I][q] + p.grad_factor * sums[I * SROW + lane + 64 * q];
   }
   // residual rows: lane = element (dz, dy, dx) of the 3 x 3 x 3 neighbourhood, fixed-shape tree sum
   {

@@ -641,7 +641,9 @@ MH_DEV WgsLane wgs_lane_constants() {
   c.base0 = grp < 3 ? a0 * NROW + grp * ND + b0 * 3 : 9 * NROW + a0 * ND + b0 * 3;
   c.stride0 = grp < 3 ? 3 * NROW : 3 * ND;   // per a1
   c.base1 = 9 * NROW + (a0 + 9) * ND + b0 * 3;  // per a1: 3 * ND
-  c.basec = a0 * 54 + b0 * 3 + (grp == 0 ? 0 : grp == 1 ? ND : grp == 3 ? 9 * 54 : 9 * 54 + ND);  // per a1: 162
+  // carried rows in the element block (P2Block: row a - 9 at 162 (a - 9), this piece's 54 values inside at 54 I -- the
+  // caller's pointer --, then (b2 - 1) 27 + b1 9 + b0 3 + j)
+  c.basec = a0 * 162 + b0 * 3 + (grp == 0 ? 0 : grp == 1 ? ND : grp == 3 ? 9 * 162 : 9 * 162 + ND);  // per a1: 486
   // transposed: node a' = b, node b' = a.  a2' = b2 == 0 (grp 0, 3; row 6): s = (b0 + 3 b1) 81 + a2 27 + a1 9 + a0 3 + i
   //             a2' = b2 >= 1 (grp 1, 2):      s = 729 + (b0 + 3 b1 + 9 (b2 - 1)) 27 + a1 9 + a0 3 + i
   c.baseT0 = grp == 0 ? b0 * NROW + a0 * 3
@@ -651,8 +653,8 @@ MH_DEV WgsLane wgs_lane_constants() {
   c.strideT0 = (grp == 0 || grp == 3) ? 3 * NROW : 3 * ND;   // per b1; per a1: 9
   c.baseT1 = b0 * NROW + 2 * ND + a0 * 3;                      // row 6 (2,0) -> (0,2): per b1 3 * NROW; per a1 9
   // carried rows: grp 0 row 4 (1,1) -> (1,1); grp 1 row 5 (1,2) -> (2,1); grp 3 row 7 (2,1) -> (1,2); grp 2 row 8 (2,2)
-  //   s' = (a' - 9) 54 + (b2' - 1) 27 + b1' 9 + b0' 3 + i,  a' = b0 + 3 b1 + 9 b2,  b2' = a2
-  c.basecT = b0 * 54 + a0 * 3 + (grp == 0 ? 0 : grp == 1 ? 9 * 54 : grp == 3 ? ND : 9 * 54 + ND);   // per b1: 162; per a1: 9
+  //   s' = (a' - 9) 162 + (b2' - 1) 27 + b1' 9 + b0' 3 + i,  a' = b0 + 3 b1 + 9 b2,  b2' = a2
+  c.basecT = b0 * 162 + a0 * 3 + (grp == 0 ? 0 : grp == 1 ? 9 * 162 : grp == 3 ? ND : 9 * 162 + ND);   // per b1: 486; per a1: 9
   return c;
 }
 
@@ -738,7 +740,7 @@ MH_DEV void wgs_contract_block(const WgsLane& lc, const double (&ah)[9], const d
   carry_and_stage(NB - 1);
 }
 
-// carried rows of the last element of a column -> store-transposition buffer(s)
+// carried rows of the last element of a column -> the third part of the element block (st_n / st_t: P2Block::carry_of(E, i))
 template<int MODE>
 MH_DEV void wgs_stage_carry(const WgsLane& lc, const double (&C)[9], double* st_n, int jn, double* st_t, int jt) {
   constexpr int NB = 3;
@@ -746,32 +748,44 @@ MH_DEV void wgs_stage_carry(const WgsLane& lc, const double (&C)[9], double* st_
   for (int a1b1 = 0; a1b1 < 9; ++a1b1) {
     const int a1 = a1b1 / NB, b1 = a1b1 % NB;
     if (MODE == 2 && a1 < b1) continue;
-    if (lc.col_ok) st_n[lc.basec + a1 * 162 + b1 * 9 + jn] = C[a1b1];
-    if ((MODE == 1 || (MODE == 2 && a1 > b1)) && lc.col_ok) st_t[lc.basecT + b1 * 162 + a1 * 9 + jt] = C[a1b1];
+    if (lc.col_ok) st_n[lc.basec + a1 * 486 + b1 * 9 + jn] = C[a1b1];
+    if ((MODE == 1 || (MODE == 2 && a1 > b1)) && lc.col_ok) st_t[lc.basecT + b1 * 486 + a1 * 9 + jt] = C[a1b1];
   }
 }
 
-// buffer -> dense scratch piece S (affine addressing, see kernels_tensor_wgs.hpp)
-MH_DEV void wgs_flush_final(int lane, const double* ST, double* S) {
-  // the piece layout in scratch_k IS the compact layout of the buffer (kernels_tensor_2phase.hpp): 1215 contiguous values
-  constexpr int N = WgsLds::n_final, NR = (N + 63) / 64;  // 19
-  double v[NR];
+// buffer (compact: nine rows of 81, eighteen rows of 27) -> this piece's runs in the element block E (P2Block)
+MH_DEV void wgs_flush_final(int lane, const double* ST, double* E, int I) {
+  constexpr int NROW = 81, ND = 27;
+  {
+    // rows a2 = 0: E[a 243 + I 81 + k], k < 81: the first 64 values of a row per instruction, then the 17 others of
+    // three rows together (lanes 0..16, 17..33, 34..50)
+    const int g3 = lane / 17, k3 = lane - 17 * g3;
+    const bool ok3 = lane < 51;
+    const int src3 = ok3 ? g3 * NROW + 64 + k3 : 0, dst3 = g3 * 3 * NROW + 64 + k3;
+    double v0[9], v1[3];
 #pragma unroll
-  for (int c = 0; c < NR; ++c) v[c] = ST[c * 64 + ((c + 1) * 64 <= N || lane < N - c * 64 ? lane : 0)];
+    for (int a = 0; a < 9; ++a) v0[a] = ST[a * NROW + lane];
 #pragma unroll
-  for (int c = 0; c < NR; ++c)
-    if ((c + 1) * 64 <= N || lane < N - c * 64) S[(unsigned)(c * 64 + lane)] = v[c];
-}
-
-MH_DEV void wgs_flush_carry(int lane, const double* ST, double* S) {
-  // carried rows of the last element of a column: the 972 values behind the 1215 final ones
-  constexpr int N = WgsLds::n_carry, NR = (N + 63) / 64;  // 16
-  double v[NR];
+    for (int q = 0; q < 3; ++q) v1[q] = ST[q * 3 * NROW + src3];
+    double* d = E + I * NROW;
 #pragma unroll
-  for (int c = 0; c < NR; ++c) v[c] = ST[c * 64 + ((c + 1) * 64 <= N || lane < N - c * 64 ? lane : 0)];
+    for (int a = 0; a < 9; ++a) d[(unsigned)(a * 3 * NROW + lane)] = v0[a];
 #pragma unroll
-  for (int c = 0; c < NR; ++c)
-    if ((c + 1) * 64 <= N || lane < N - c * 64) S[(unsigned)(WgsLds::n_final + c * 64 + lane)] = v[c];
+    for (int q = 0; q < 3; ++q)
+      if (ok3) d[(unsigned)(q * 9 * NROW + dst3)] = v1[q];
+  }
+  {
+    // rows a2 >= 1, b2 = 0: E[2187 + (a - 9) 81 + I 27 + k], k < 27: two rows per instruction (lanes 0..26, 32..58)
+    const int half = lane >> 5, k = lane & 31;
+    const bool ok = k < ND;
+    double w[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) w[r] = ST[9 * NROW + (2 * r + half) * ND + (ok ? k : 0)];
+    double* d = E + P2Block::off_b20 + I * ND + half * NROW + k;
+#pragma unroll
+    for (int r = 0; r < 9; ++r)
+      if (ok) d[(unsigned)(2 * r * NROW)] = w[r];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -786,8 +800,8 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
   double* AH = lds + L::off_ah + I * ND * NQ3;
   double* ST = lds + L::off_st + I * L::st_size;
   const int n_seq = p.box_n[2];
-  auto piece_of = [&](int es) -> double* {
-    return p.scratch_k + ((eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * es)) * 3 + I) * (int64_t)NK;
+  auto block_of = [&](int es) -> double* {
+    return p.scratch_k + (eu + (int64_t)p.box_n[0] * (ev + (int64_t)p.box_n[1] * es)) * (int64_t)P2Block::size;
   };
   // matrix-operand lane constants: pair index on bits 3:0, contraction index on bits 5:4
   const int mrow = lane & 15, mk = lane >> 4;
@@ -866,14 +880,14 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
       wgs_contract_block<0>(lc, ah, aS0, aS2, uB1, uD1, C[2], ST, 2, ST, 2);
       // this wave's piece of the element is complete: buffer -> scratch
       __builtin_amdgcn_wave_barrier();
-      wgs_flush_final(lane, ST, piece_of(it));
+      wgs_flush_final(lane, ST, block_of(it), I);
       __builtin_amdgcn_wave_barrier();
       wgs_barrier();
     }
   }
   // the carried rows of the last element have no successor: straight from the registers into the third part of the piece
   {
-    double* Sc = piece_of(n_seq - 1) + WgsLds::n_final;
+    double* Sc = P2Block::carry_of(block_of(n_seq - 1), I);
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj) wgs_stage_carry<0>(lc, C[jj], Sc, jj, Sc, jj);
   }
@@ -920,8 +934,7 @@ __global__ __launch_bounds__(256, 2) void tensor_wgs_kernel(TensorArgs p) {
 }
 
 inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a) {
-  constexpr int NK = 27 * 81;
-  h->scratch_k.resize((size_t)h->n_el * 3 * NK);
+  h->scratch_k.resize((size_t)h->n_el * P2Block::size);
   h->scratch_r.resize((size_t)h->n_el * 3 * 27);
   a.scratch_k = h->scratch_k.ptr;
   a.scratch_r = h->scratch_r.ptr;

@@ -272,12 +272,11 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols)
   const double* AH0 = lds + L::off_ah + L::ah_block(W, W) * NQ3;
   const double* AH1 = lds + L::off_ah + L::ah_block(I1, J1) * NQ3;
   auto st_of = [&](int piece) -> double* { return lds + L::off_st + piece * WgsLds::st_size; };
-  auto piece_i = [&](int g, int i) -> double* {
+  auto block_of = [&](int g) -> double* {
     const int unit = col0 + g / sl, col = unit / nseg;
     const int64_t e = col % p.box_n[0] + (int64_t)p.box_n[0] * (col / p.box_n[0] + (int64_t)p.box_n[1] * ((unit % nseg) * sl + g % sl));
-    return p.scratch_k + (e * 3 + i) * (int64_t)NK;
+    return p.scratch_k + e * (int64_t)P2Block::size;
   };
-  auto piece_of = [&](int g) -> double* { return piece_i(g, W); };
   const int mrow = lane & 15, mk = lane >> 4;
   const bool mrow_ok = mrow < NB2;
   const int mra = mrow_ok ? mrow / NB : 0, mrb = mrow_ok ? mrow % NB : 0;
@@ -293,7 +292,7 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols)
   for (int it = 0; it < n_seq; ++it) {
     // ---- D(it), free running: flush element it - 1, tables of element it, diagonal block ----------------------
     {
-      if (it >= 1) wgs_flush_final(lane, st_of(W), piece_of(it - 1));
+      if (it >= 1) wgs_flush_final(lane, st_of(W), block_of(it - 1), W);
       const double* tab = lds + L::off_tab + (it & 1) * 6 * NB * NQ;
       {
         const double Ba = tab_ptr<P>(tab, 0, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 0, 1)[mra * NQ + mk];
@@ -341,15 +340,16 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols)
       if (it % sl == sl - 1) {
         // last element of a unit (column, or column segment): the carried rows have no successor -- straight from the registers into the third
         // part of the pieces (no LDS, no lock step) -- and the next column starts with an empty carry
-        wgs_stage_carry<WGSYM_DIAG_MODE>(lc, C0, piece_i(it, W) + WgsLds::n_final, W, piece_i(it, W) + WgsLds::n_final, W);
-        wgs_stage_carry<1>(lc, C1, piece_i(it, I1) + WgsLds::n_final, J1, piece_i(it, J1) + WgsLds::n_final, I1);
+        double* E = block_of(it);
+        wgs_stage_carry<WGSYM_DIAG_MODE>(lc, C0, P2Block::carry_of(E, W), W, P2Block::carry_of(E, W), W);
+        wgs_stage_carry<1>(lc, C1, P2Block::carry_of(E, I1), J1, P2Block::carry_of(E, J1), I1);
 #pragma unroll
         for (int k = 0; k < NB2; ++k) C0[k] = C1[k] = 0.0;
       }
     }
   }
   // ---- after the last element (no more lock steps): its pieces from the buffers ------------------------------------
-  wgs_flush_final(lane, st_of(W), piece_of(n_seq - 1));
+  wgs_flush_final(lane, st_of(W), block_of(n_seq - 1), W);
 }
 
 template<int KIND>
@@ -380,8 +380,7 @@ __global__ __launch_bounds__(256, 2) void tensor_wgsym_kernel(TensorArgs p) {
 }
 
 inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a) {
-  constexpr int NK = 27 * 81;
-  h->scratch_k.resize((size_t)h->n_el * 3 * NK);
+  h->scratch_k.resize((size_t)h->n_el * P2Block::size);
   h->scratch_r.resize((size_t)h->n_el * 3 * 27);
   a.scratch_k = h->scratch_k.ptr;
   a.scratch_r = h->scratch_r.ptr;
