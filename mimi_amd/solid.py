@@ -363,6 +363,10 @@ class NonlinearSolid(Solid):
         self._newton = dict(rel_tol=rel_tol, abs_tol=abs_tol, max_iter=int(max_iter), iterative_mode=bool(iterative_mode))
 
     def solution_view(self, fe_space, component):
+        """"x" (the displacement), "x_dot", "x_ref" (the nodes' reference positions, py_nonlinear_solid.cpp:91-114): host
+        arrays in this facade's node order, the solver's own storage for the first two (write prescribed values in place)"""
+        if component == "x_ref":
+            return np.ascontiguousarray(self.patch_.control_points, dtype=np.float64).reshape(-1).copy()
         return {"x": self.x, "x_dot": self.x_dot}[component]
 
     # -- operators::NonlinearSolid ----------------------------------------------------------------
