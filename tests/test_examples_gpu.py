@@ -38,4 +38,4 @@ def test_example_toy_problem():
     lines = [l for l in text.splitlines() if l.startswith("step")]
     assert len(lines) == 45 and all("converged True" in l for l in lines)
     assert "array([0., 0.]), array([0., 0.])" in lines[0]              # nothing touches at the start
-    assert any("array([0., 0.])" not in l for l in lines[15:])         # a wall has been reached by then
+    assert any("array([0., 0.]), array([0., 0.])" not in l for l in lines[15:])   # a wall has been reached by then
