@@ -121,22 +121,42 @@ struct ReturnMapCtx {
   double slope;   // 3G (J2, J2Log: materials.hpp:345,622) or G tr(be) (J2Simo: materials.hpp:495)
 };
 
-// materials.hpp:343-349
-MH_DEV Dual rm_residual(const mimi_hip_material& m, const ReturnMapCtx& c, Dual delta) {
-  const Dual H = hardening_evaluate(m, Dual{c.eqps_old + delta.v, delta.d});
-  const double fac = rate_contribution(m, delta.v / c.dt) * c.thermo;
-  return Dual{c.q - c.slope * delta.v - H.v * fac, -c.slope * delta.d - H.d * fac};
+// materials.hpp:343-349, evaluated once per point x with everything the caller needs afterwards: the residual and its
+// derivative (dual seed 1), the hardening value / slope and the rate factor at x.  The reference evaluates the same
+// function at the same x several times (admissibility check, both bracket ends, the Newton start, the hardening slope
+// after the solve); identical arguments give identical results, so each distinct x is evaluated once here.
+struct RmPoint {
+  double x;
+  Dual R;      // residual, d residual / d x
+  Dual H;      // hardening at eqps_old + x
+  double rc;   // rate contribution at x / dt
+};
+
+MH_DEV RmPoint rm_eval(const mimi_hip_material& m, const ReturnMapCtx& c, double x) {
+  RmPoint e;
+  e.x = x;
+  e.H = hardening_evaluate(m, Dual{c.eqps_old + x, 1.0});
+  e.rc = rate_contribution(m, x / c.dt);
+  const double fac = e.rc * c.thermo;
+  e.R = Dual{c.q - c.slope * x - e.H.v * fac, -c.slope - e.H.d * fac};
+  return e;
 }
 
-// solvers/newton.hpp:53-169; status bit 1 = root not bracketed, bit 2 = not converged
-MH_DEV double scalar_solve(const mimi_hip_material& m, const ReturnMapCtx& c, double x0, double lower,
-                           double upper, double xtol, double rtol, int max_iter, int& status) {
-  const double fl = rm_residual(m, c, Dual{lower, 0.0}).v;
-  const double fh = rm_residual(m, c, Dual{upper, 0.0}).v;
-  if (fabs(fl) < xtol) return lower;
+// solvers/newton.hpp:53-169; status bit 1 = root not bracketed, bit 2 = not converged.  at_lower: the evaluation at
+// `lower`, which the caller already has; the evaluation at the returned x is left in `last`.
+MH_DEV double scalar_solve(const mimi_hip_material& m, const ReturnMapCtx& c, const RmPoint& at_lower, double x0, double lower,
+                           double upper, double xtol, double rtol, int max_iter, int& status, RmPoint& last) {
+  const double fl = at_lower.R.v;
+  last = rm_eval(m, c, upper);
+  const double fh = last.R.v;
+  if (fabs(fl) < xtol) {
+    last = at_lower;
+    return lower;
+  }
   if (fabs(fh) < xtol) return upper;
   if (fl * fh > 0.) {
     status |= 1;
+    last = at_lower;
     return lower;
   }
   double xl = lower, xh = upper;
@@ -148,8 +168,8 @@ MH_DEV double scalar_solve(const mimi_hip_material& m, const ReturnMapCtx& c, do
   double x = x0;
   double delta_x_old = fabs(upper - lower);
   double delta_x = delta_x_old;
-  Dual R = rm_residual(m, c, Dual{x, 1.0});
-  double fval = R.v, df_dx = R.d;
+  last = x == lower ? at_lower : rm_eval(m, c, x);
+  double fval = last.R.v, df_dx = last.R.d;
   bool converged = false;
   int iterations = 0;
   while (!converged) {
@@ -167,9 +187,9 @@ MH_DEV double scalar_solve(const mimi_hip_material& m, const ReturnMapCtx& c, do
       delta_x = fval / df_dx;
       x -= delta_x;
     }
-    R = rm_residual(m, c, Dual{x, 1.0});
-    fval = R.v;
-    df_dx = R.d;
+    last = rm_eval(m, c, x);
+    fval = last.R.v;
+    df_dx = last.R.d;
     converged = (fabs(delta_x) < xtol) || (fabs(fval) < rtol);
     if (fval < 0) xl = x; else xh = x;
     ++iterations;
@@ -274,15 +294,17 @@ MH_DEV int j2_stress(const MaterialDev& md, double dt, const double* F, double* 
   ReturnMapCtx c{eqps, q, thermo_contribution(md, temperature), dt, 3.0 * m.G};
   const double tolerance = md.sigma_y_ref * 1.e-10;
   int status = 0;
-  if (rm_residual(m, c, Dual{0.0, 0.0}).v > tolerance) {
-    const double upper = (q - hardening_evaluate(m, Dual{c.eqps_old, 0.0}).v * c.thermo) / (3.0 * m.G);
-    const double delta = scalar_solve(m, c, 0.0, 0.0, upper, 1.e-10, tolerance, 100, status);
+  const RmPoint at0 = rm_eval(m, c, 0.0);
+  if (at0.R.v > tolerance) {
+    const double upper = (q - at0.H.v * c.thermo) / (3.0 * m.G);
+    RmPoint sol;
+    const double delta = scalar_solve(m, c, at0, 0.0, 0.0, upper, 1.e-10, tolerance, 100, status, sol);
     w.plastic = true;
     w.delta = delta;
     const double npf = 1.5 / q;
     if constexpr (!ACCUMULATE) {
-      const Dual H = hardening_evaluate(m, Dual{c.eqps_old + delta, 1.0});
-      const double rc = rate_contribution(m, delta / dt);
+      const Dual H = sol.H;          // (hardening and rate factor at the solution: what the last evaluation left)
+      const double rc = sol.rc;
       w.hprime = H.d * rc * c.thermo + H.v * rate_contribution_derivative(m, delta / dt) / dt * c.thermo;
 #pragma unroll
       for (int i = 0; i < DD; ++i) s[i] += -2.0 * m.G * delta * (npf * s[i]);

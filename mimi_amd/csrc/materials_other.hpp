@@ -281,12 +281,14 @@ MH_DEV T return_map_increment(const MaterialDev& md, double dt, double eqps_old,
   ReturnMapCtx c{eqps_old, ad_v(a), thermo_contribution(md, temperature), dt, ad_v(b)};
   const double tolerance = md.sigma_y_ref * 1.e-10;
   plastic = false;
-  if (rm_residual(m, c, Dual{0.0, 0.0}).v > tolerance) {
-    const double upper = (c.q - hardening_evaluate(m, Dual{c.eqps_old, 0.0}).v * c.thermo) / c.slope;
-    const double delta = scalar_solve(m, c, 0.0, 0.0, upper, 1.e-10, tolerance, 100, status);
+  const RmPoint at0 = rm_eval(m, c, 0.0);
+  if (at0.R.v > tolerance) {
+    const double upper = (c.q - at0.H.v * c.thermo) / c.slope;
+    RmPoint sol;
+    const double delta = scalar_solve(m, c, at0, 0.0, 0.0, upper, 1.e-10, tolerance, 100, status, sol);
     plastic = true;
-    const Dual H = hardening_evaluate(m, Dual{c.eqps_old + delta, 1.0});
-    const double rc = rate_contribution(m, delta / dt);
+    const Dual H = sol.H;            // (hardening and rate factor at the solution: what the last evaluation left)
+    const double rc = sol.rc;
     const double hprime = H.d * rc * c.thermo + H.v * rate_contribution_derivative(m, delta / dt) / dt * c.thermo;
     cc.plastic = true;
     cc.delta = delta;
