@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, n_el, p, mode, q):
+def _worker(rank, world, port, n_el, p, mode, q, sliced=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -42,6 +42,23 @@ def _worker(rank, world, port, n_el, p, mode, q):
         r = np.zeros(P.n_vdofs)
         A = np.zeros(D.nnz)
         D.add_domain_residual_and_grad(u, 1.0, r, A, rp.TANGENT_EXACT)
+        lrowptr = rowptr
+        if sliced:
+            # this rank's value array holds only the rows of the nodes its slab touches (SlabShard.node_box): the
+            # pattern keeps its length, the other rows are empty
+            nb, ne = shard.node_box()
+            mi = patch.node_multi_index()
+            inside = np.ones(P.n_nodes, dtype=bool)
+            for d in range(P.dim):
+                inside &= (mi[d] >= nb[d]) & (mi[d] < ne[d])
+            keep = np.repeat(inside, P.dim)
+            lengths = np.diff(rowptr)
+            lrowptr = np.concatenate([[0], np.cumsum(lengths * keep)]).astype(np.int64)
+            entries = np.repeat(keep, lengths)
+            assert np.all(A[~entries] == 0.0)          # the slab's elements write nothing outside the slice
+            A = np.ascontiguousarray(A[entries])
+            shard.pattern = CSRPattern(lrowptr, np.ascontiguousarray(col[entries]), lrowptr[-1])
+            assert 0 < lrowptr[-1] < rowptr[-1]
         tr, tA = torch.from_numpy(r), torch.from_numpy(A)
         ex = parallel.InterfaceExchange(shard, tr, tA, mode=mode)
         ex.sum_residual_and_grad()
@@ -59,7 +76,8 @@ def _worker(rank, world, port, n_el, p, mode, q):
         ok = np.allclose(r[rows], rf[rows], rtol=1e-12, atol=1e-12)
         for row in rows:
             s, t = rowptr[row], rowptr[row + 1]
-            ok = ok and np.allclose(A[s:t], Af[s:t], rtol=1e-12, atol=1e-10)
+            ls, lt = lrowptr[row], lrowptr[row + 1]
+            ok = ok and lt - ls == t - s and np.allclose(A[ls:lt], Af[s:t], rtol=1e-12, atol=1e-10)
         q.put((rank, bool(ok), len(elements), len(touched)))
     except Exception as exc:  # pragma: no cover
         q.put((rank, False, repr(exc), 0))
@@ -67,24 +85,47 @@ def _worker(rank, world, port, n_el, p, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["replicate", "owner"])
-@pytest.mark.parametrize("world,n_el,p", [(2, (3, 2, 6), 2), (3, (2, 9), 3), (2, (4, 5, 3), 1)])
-def test_interface_exchange_gloo(world, n_el, p, mode):
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _run(world, n_el, p, mode, sliced):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_el, p, mode, q)) for r in range(world)]
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_el, p, mode, q, sliced)) for r in range(world)]
     for pr in procs:
         pr.start()
-    results = [q.get(timeout=240) for _ in range(world)]
-    for pr in procs:
-        pr.join(timeout=60)
+    try:
+        results = [q.get(timeout=240) for _ in range(world)]
+        for pr in procs:
+            pr.join(timeout=60)
+    finally:
+        for pr in procs:            # whatever happened, no rank is left waiting in a receive
+            if pr.is_alive():
+                pr.terminate()
+                pr.join(timeout=10)
     assert all(ok is True for _, ok, _, _ in results), results
     assert sum(n for _, _, n, _ in results) == int(np.prod(n_el))
     if mode == "owner":
         # the owned planes partition the nodes
         assert sum(n for _, _, _, n in results) == int(np.prod([n_el[d] + p for d in range(len(n_el))]))
+
+
+@pytest.mark.parametrize("mode", ["replicate", "owner"])
+@pytest.mark.parametrize("world,n_el,p", [(2, (3, 2, 6), 2), (3, (2, 9), 3), (2, (4, 5, 3), 1)])
+def test_interface_exchange_gloo(world, n_el, p, mode):
+    _run(world, n_el, p, mode, False)
+
+
+@pytest.mark.parametrize("world,n_el,p,mode", [(2, (3, 2, 6), 2, "owner"), (3, (2, 9), 3, "replicate")])
+def test_interface_exchange_gloo_row_slices(world, n_el, p, mode):
+    """each rank holds only its row slice of the matrix (what bench.py does for N > 1)"""
+    _run(world, n_el, p, mode, True)
 
 
 def test_slab_shard_boxes():
