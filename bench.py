@@ -366,8 +366,26 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
     # (p layers per side although owner mode could do with p // 2 and p - p // 2 -- overlap_boxes(mode="owner"): measured in
     # loop-back at N = 8, the thinner boundary launches cost more than the layers they move to the interior save:
     # 1.29 against 1.27 ms, cfg3 6.36 against 6.15 ms)
-    boundary_boxes, interior_box = shard.overlap_boxes() if (world > 1 and not args.residual_only) else ([], shard.element_box)
-    integ = make_integrator(interior_box)
+    # N > 1, two ways to have the interface rows on the wire while the rest is assembled (--scheme):
+    #   "gather": ONE handle for the slab; its integration kernels run, the rows that leave the rank are gathered first, they
+    #             travel while the other rows are gathered (two-phase tensor paths: NonlinearSolid.Integrate / Gather)
+    #   "boundary": the element layers next to a neighbour as handles of their own, assembled first; the interior meanwhile
+    scheme = "none"
+    if world > 1 and not args.residual_only:
+        scheme = args.scheme
+    u = torch.from_numpy(synthetic_u(patch, scale=0.01 if workload == "cfg4" else 0.05)).to(dev)
+    integ = None
+    if scheme == "gather":
+        integ = make_integrator(shard.element_box)
+        try:                                   # (handles off the two-phase tensor paths have the one-call form only)
+            integ.Integrate(u)
+            integ.Synchronize()
+        except RuntimeError as exc:
+            sys.stderr.write(f"bench.py: rank {rank}: no two-step assembly for this handle ({exc}); --scheme boundary\n")
+            scheme, integ = "boundary", None
+    boundary_boxes, interior_box = shard.overlap_boxes() if scheme == "boundary" else ([], shard.element_box)
+    if integ is None:
+        integ = make_integrator(interior_box)
     boundary = [make_integrator(b) for b in boundary_boxes]
     # the two boundary boxes of a middle rank are a few hundred element columns each -- half of the chip's workgroup slots:
     # they share no node, so the second one runs beside the first on its own stream
@@ -376,10 +394,12 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
         side_stream = torch.cuda.Stream(device=dev)
         boundary[1].SetStream(side_stream.cuda_stream)
 
-    u = torch.from_numpy(synthetic_u(patch, scale=0.01 if workload == "cfg4" else 0.05)).to(dev)
     r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
     A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
     exchange = parallel.InterfaceExchange(shard, r, A, dev, mode="owner", loopback=loopback) if world > 1 else None
+    early = rest = None
+    if scheme == "gather":
+        early, rest = exchange.gather_windows()
     contact = None
     if workload == "cfg4":
         from mimi_amd.integrators import RigidSphere
@@ -405,7 +425,18 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
             if exchange:
                 exchange.sum_residual()
         else:
-            if boundary:
+            if scheme == "gather":
+                integ.Integrate(u)
+                for w in early:                      # the rows the neighbours wait for
+                    integ.Gather(1.0, r, A, *w)
+                if contact:          # (its rows on shared node planes must be in before they go on the wire)
+                    contact.AddBoundaryResidualAndGrad(u, 1.0, r, A)
+                ready = torch.cuda.Event()
+                ready.record(stream)
+                integ.Gather(1.0, r, A, *rest)       # ... travel while everything else is gathered
+                exchange.start(True, ready=ready)
+                exchange.finish()
+            elif boundary:
                 if side_stream:
                     side_stream.wait_stream(stream)
                 for g in boundary:
@@ -551,7 +582,9 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
                                 f"{n_elements} elements, n_q={(p + 2) ** patch.dim}, nnz={pattern.nnz}",
                     "name": workload,
                     "parallelism": f"element slabs x{world}" + (", interface rows summed on their owner rank" if world > 1 else "")
-                                   + (", exchange overlapped with the interior elements" if boundary else ""),
+                                   + (", exchange overlapped with the interior elements" if boundary else "")
+                                   + (", rows that leave the rank gathered first and sent while the others are gathered"
+                                      if scheme == "gather" else ""),
                     "kernel_path": "tensor" if integ.path_ == 1 else "general",
                     "u": f"{0.01 if workload == 'cfg4' else 0.05}*N(0,1), seed 20241008, face x=0 clamped"},
             roofline={"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
@@ -710,6 +743,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sweep", action="store_true", help="add a 1/32/64/128-thread sweep of the CPU baseline (minutes)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg3 measurement that follows the north-star one at N = 1")
+    ap.add_argument("--scheme", default="gather", choices=["gather", "boundary", "none"],
+                    help="N > 1: how the exchange is overlapped with the assembly (see measure()); none = no overlap")
     ap.add_argument("--no-check", action="store_true",
                     help="N > 1: skip the comparison of the owned rows with a whole-patch assembly that follows the timed region")
     ap.add_argument("--check", action="store_true", help="(accepted for older command lines: the check is on by default)")

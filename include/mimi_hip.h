@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MIMI_HIP_ABI_VERSION 8
+#define MIMI_HIP_ABI_VERSION 9
 
 /* ---- errors ---------------------------------------------------------------- */
 const char* mimi_hip_last_error(void);
@@ -169,6 +169,17 @@ int mimi_hip_domain_post_time_advance(mimi_hip_domain_t h, const double* u);
  *        3 its second one: beta (J2Linear, materials.hpp:158), F_old (J2Simo, materials.hpp:434) */
 int mimi_hip_domain_get_state(mimi_hip_domain_t h, int what, double* out, int64_t capacity);
 int mimi_hip_domain_reset_state(mimi_hip_domain_t h);
+/* The two-step form of mimi_hip_domain_add_residual_and_grad, for a caller that needs some rows before the others (the
+ * rows a neighbour rank is waiting for: mimi_amd/parallel.py, bench.py): integrate() runs the integration kernels of the
+ * whole handle -- element row pieces and element residual pieces into the handle's scratch, nothing into r / A_values --
+ * and gather() adds the rows of the nodes in the box [node_begin, node_end) (global node indices per direction, inside
+ * the nodes the handle's elements touch) into r / A_values.  Every node must be gathered exactly once per integrate()
+ * for the sum of the calls to equal one add_residual_and_grad (bitwise: same kernels, same order of additions per row).
+ * Two-phase tensor paths only (3-D, degree 2 or 3, structured CSR, analytic tangent), device-resident arguments only;
+ * other handles report an error and the caller stays with the one-call form. */
+int mimi_hip_domain_integrate(mimi_hip_domain_t h, const double* u);
+int mimi_hip_domain_gather(mimi_hip_domain_t h, double grad_factor, double* r, double* A_values,
+                           const int32_t node_begin[3], const int32_t node_end[3]);
 /* measurement aid (bench.py): HIP events on the launch stream around the two phases of the last two-phase tangent
  * assembly -- phase 1 = the integration kernel(s), phase 2 = the row gather.  Off by default (three event records per
  * call when on). */

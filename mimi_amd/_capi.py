@@ -77,6 +77,7 @@ EXPORTS = [
     "mimi_hip_linear_create", "mimi_hip_linear_destroy", "mimi_hip_linear_set_stream", "mimi_hip_linear_eliminate",
     "mimi_hip_linear_add_mult",
     "mimi_hip_linear_gmres", "mimi_hip_linear_cg",
+    "mimi_hip_domain_integrate", "mimi_hip_domain_gather",
     "mimi_hip_rows_zero", "mimi_hip_rows_pack", "mimi_hip_rows_unpack_add",
 ]
 
@@ -142,6 +143,8 @@ def lib():
     L.mimi_hip_bspline_sparsity.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mimi_hip_bspline_sparsity_rows.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                                  C.c_void_p, C.c_void_p]
+    L.mimi_hip_domain_integrate.argtypes = [C.c_void_p, C.c_void_p]
+    L.mimi_hip_domain_gather.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mimi_hip_rows_zero.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     L.mimi_hip_rows_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mimi_hip_rows_unpack_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

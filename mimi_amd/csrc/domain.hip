@@ -765,6 +765,57 @@ int mimi_hip_domain_set_stream(mimi_hip_domain_t h, void* stream) {
   });
 }
 
+// the two-step form of a tangent assembly: phase 1 of the whole handle, then phase 2 over parts of its nodes
+static void require_two_phase(mimi_hip_domain_s* h) {
+  const bool ok = h->dim == 3 && tensor_usable(h) && !tensor_small(h) && two_phase_supported(h) &&
+                  h->tangent_mode == MIMI_HIP_TANGENT_ANALYTIC;
+  if (!ok) fail("integrate / gather: only on the two-phase tensor paths (3-D, degree 2 or 3, structured CSR, analytic tangent)");
+}
+
+int mimi_hip_domain_integrate(mimi_hip_domain_t h, const double* u) {
+  return guarded([&] {
+    if (!h || !u) fail("null argument");
+    MH_HIP(hipSetDevice(h->device));
+    require_two_phase(h);
+    if (!is_device_pointer(u)) fail("integrate / gather: device-resident arguments only");
+    h->phase_select = 1;
+    try {
+      launch_tensor(h, 1, u, nullptr, nullptr, 0.0);
+    } catch (...) {
+      h->phase_select = 0;
+      throw;
+    }
+    h->phase_select = 0;
+    h->integrated = true;
+  });
+}
+
+int mimi_hip_domain_gather(mimi_hip_domain_t h, double grad_factor, double* r, double* A_values, const int32_t node_begin[3],
+                           const int32_t node_end[3]) {
+  return guarded([&] {
+    if (!h || !r || !A_values || !node_begin || !node_end) fail("null argument");
+    MH_HIP(hipSetDevice(h->device));
+    require_two_phase(h);
+    if (!h->integrated) fail("gather: mimi_hip_domain_integrate has not run on this handle");
+    if (!is_device_pointer(r) || !is_device_pointer(A_values)) fail("integrate / gather: device-resident arguments only");
+    for (int d = 0; d < 3; ++d) {
+      const int lo = h->el_begin[d], hi = h->el_end[d] + h->degree[d];     // nodes the handle's elements touch
+      if (node_begin[d] < lo || node_end[d] > hi || node_begin[d] >= node_end[d])
+        fail("gather: node range [%d,%d) in direction %d is not inside the handle's nodes [%d,%d)", node_begin[d], node_end[d], d, lo, hi);
+      h->gather_begin[d] = node_begin[d];
+      h->gather_end[d] = node_end[d];
+    }
+    h->phase_select = 2;
+    try {
+      launch_tensor(h, 1, nullptr, r, A_values, grad_factor);
+    } catch (...) {
+      h->phase_select = 0;
+      throw;
+    }
+    h->phase_select = 0;
+  });
+}
+
 int mimi_hip_domain_synchronize(mimi_hip_domain_t h) {
   return guarded([&] {
     if (!h) fail("null handle");

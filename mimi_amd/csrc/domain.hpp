@@ -54,6 +54,12 @@ struct mimi_hip_domain_s {
   bool phase_timing = false;
   hipEvent_t phase_ev[3] = {nullptr, nullptr, nullptr};
 
+  // mimi_hip_domain_integrate / _gather: 0 = an assembly runs both phases, 1 = phase 1 only, 2 = phase 2 only, over the
+  // node window [gather_begin, gather_end)
+  int phase_select = 0;
+  int gather_begin[3] = {0, 0, 0}, gather_end[3] = {0, 0, 0};
+  bool integrated = false;
+
   // staging for host-resident u / r / A
   mimi_hip::DeviceBuffer<double> stage_u, stage_r, stage_A;
 

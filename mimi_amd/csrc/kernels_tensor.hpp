@@ -66,6 +66,8 @@ struct TensorArgs {
   const unsigned char* nbr_pos;  // two-phase path, permuted numbering: [n_nodes][125] positions inside a CSR row
   const uint16_t* nbr_pos16; // p = 3 two-phase path, permuted numbering: [n_nodes][343] positions inside a CSR row
   double* scratch_tail;      // p = 3 two-phase path: [column][3][48*144] carried rows of the last element of a column
+  int win_begin[3], win_n[3];  // two-phase paths, phase 2: the nodes this launch gathers (global node indices per direction;
+                               // default: every node the handle's elements touch; mimi_hip_domain_gather: a part of them)
 };
 
 // wave-private LDS carve, in doubles
@@ -743,6 +745,15 @@ inline TensorArgs tensor_args(mimi_hip_domain_s* h, const double* u, double* r, 
     a.box_n[d] = h->el_end[d] - h->el_begin[d];
     a.tabB[d] = h->tab1d.ptr + h->tab_off_B[d];
     a.tabD[d] = h->tab1d.ptr + h->tab_off_D[d];
+  }
+  for (int d = 0; d < 3; ++d) {
+    if (h->phase_select == 2) {
+      a.win_begin[d] = h->gather_begin[d];
+      a.win_n[d] = h->gather_end[d] - h->gather_begin[d];
+    } else {
+      a.win_begin[d] = a.box_begin[d];
+      a.win_n[d] = a.box_n[d] + h->degree[d];
+    }
   }
   a.seg_len = a.box_n[2];   // whole columns unless the launcher cuts them (launch_tensor_wgsym)
   // walk along the shortest axis (most units), colour over the other two

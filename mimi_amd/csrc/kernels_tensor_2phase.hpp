@@ -59,9 +59,9 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
   if (Al >= n_nodes) return;
   double* sums = sums_all[wave];
   const int n0 = p.n_ctrl[0], n1 = p.n_ctrl[1], n2 = p.n_ctrl[2];
-  const int m0 = p.box_n[0] + P, m1 = p.box_n[1] + P;
-  const int A0 = p.box_begin[0] + (int)(Al % m0), A1 = p.box_begin[1] + (int)((Al / m0) % m1);
-  const int A2 = p.box_begin[2] + (int)(Al / ((int64_t)m0 * m1));
+  const int m0 = p.win_n[0], m1 = p.win_n[1];
+  const int A0 = p.win_begin[0] + (int)(Al % m0), A1 = p.win_begin[1] + (int)((Al / m0) % m1);
+  const int A2 = p.win_begin[2] + (int)(Al / ((int64_t)m0 * m1));
   const int64_t A = A0 + (int64_t)n0 * (A1 + (int64_t)n1 * A2);
   const int64_t gA = p.perm ? p.perm[A] : A;
   // elements of THIS shard containing node A: e_d in [A_d - P, A_d] clipped to the box
@@ -217,7 +217,7 @@ inline bool two_phase_supported(const mimi_hip_domain_s* h) {
 }
 
 inline void launch_tensor_p2(mimi_hip_domain_s* h, const TensorArgs& a) {
-  const int64_t n_nodes = (int64_t)(a.box_n[0] + 2) * (a.box_n[1] + 2) * (a.box_n[2] + 2);   // nodes of the shard
+  const int64_t n_nodes = (int64_t)a.win_n[0] * a.win_n[1] * a.win_n[2];   // nodes of the shard (or of the gather window)
   hipLaunchKernelGGL(tensor_p2_kernel, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, h->stream, a, n_nodes);
   MH_HIP(hipGetLastError());
 }

@@ -947,17 +947,21 @@ inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a) {
   if (kind != MIMI_HIP_MAT_NEOHOOKEAN) {
     h->scratch_pt.resize((size_t)h->n_el * (record ? WGS_REC_FIELDS : WGS_PT_FIELDS) * 64);
     a.scratch_pt = h->scratch_pt.ptr;
-    hipLaunchKernelGGL(record ? tensor_point_kernel<1> : tensor_point_kernel<0>, dim3((unsigned)((h->n_el + 3) / 4)), dim3(256), 0,
-                       h->stream, a, (int)h->n_el);
-    MH_HIP(hipGetLastError());
+    if (h->phase_select != 2) {
+      hipLaunchKernelGGL(record ? tensor_point_kernel<1> : tensor_point_kernel<0>, dim3((unsigned)((h->n_el + 3) / 4)), dim3(256), 0,
+                         h->stream, a, (int)h->n_el);
+      MH_HIP(hipGetLastError());
+    }
   }
   auto kernel = kind == MIMI_HIP_MAT_NEOHOOKEAN ? tensor_wgs_kernel<MIMI_HIP_MAT_NEOHOOKEAN>
                 : record ? tensor_wgs_kernel<WGS_KIND_RECORD> : tensor_wgs_kernel<MIMI_HIP_MAT_J2>;
   ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
-  hipLaunchKernelGGL(kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
-  MH_HIP(hipGetLastError());
+  if (h->phase_select != 2) {
+    hipLaunchKernelGGL(kernel, dim3(a.box_n[0] * a.box_n[1]), dim3(256), lds, h->stream, a);
+    MH_HIP(hipGetLastError());
+  }
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[1], h->stream));
-  launch_tensor_p2(h, a);
+  if (h->phase_select != 1) launch_tensor_p2(h, a);
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[2], h->stream));
 }
 

@@ -399,10 +399,12 @@ inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a) {
   const int n_cols_all = a.box_n[0] * a.box_n[1] * nseg;
   a.cols_per_wg = n_cols_all / WGSYM_MIN_WGS < 1 ? 1 : (n_cols_all / WGSYM_MIN_WGS > WGSYM_MAX_COLS ? WGSYM_MAX_COLS : n_cols_all / WGSYM_MIN_WGS);
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[0], h->stream));
-  hipLaunchKernelGGL(kernel, dim3((n_cols_all + a.cols_per_wg - 1) / a.cols_per_wg), dim3(256), lds, h->stream, a);
-  MH_HIP(hipGetLastError());
+  if (h->phase_select != 2) {
+    hipLaunchKernelGGL(kernel, dim3((n_cols_all + a.cols_per_wg - 1) / a.cols_per_wg), dim3(256), lds, h->stream, a);
+    MH_HIP(hipGetLastError());
+  }
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[1], h->stream));
-  launch_tensor_p2(h, a);
+  if (h->phase_select != 1) launch_tensor_p2(h, a);
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[2], h->stream));
 }
 

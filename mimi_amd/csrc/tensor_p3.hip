@@ -589,9 +589,9 @@ __global__ __launch_bounds__(256) void tp3_gather_kernel(TensorArgs p, int64_t n
   const int64_t Al = R / 3;
   const int I = (int)(R % 3);
   const int n0 = p.n_ctrl[0], n1 = p.n_ctrl[1], n2 = p.n_ctrl[2];
-  const int m0 = p.box_n[0] + P, m1 = p.box_n[1] + P;
-  const int A0 = p.box_begin[0] + (int)(Al % m0), A1 = p.box_begin[1] + (int)((Al / m0) % m1);
-  const int A2 = p.box_begin[2] + (int)(Al / ((int64_t)m0 * m1));
+  const int m0 = p.win_n[0], m1 = p.win_n[1];
+  const int A0 = p.win_begin[0] + (int)(Al % m0), A1 = p.win_begin[1] + (int)((Al / m0) % m1);
+  const int A2 = p.win_begin[2] + (int)(Al / ((int64_t)m0 * m1));
   const int64_t A = A0 + (int64_t)n0 * (A1 + (int64_t)n1 * A2);
   const int bx0 = p.box_begin[0], bx1 = p.box_begin[1], bx2 = p.box_begin[2];
   const int ex_lo = max(A0 - P, bx0), ex_hi = min(A0, bx0 + p.box_n[0] - 1);
@@ -741,19 +741,21 @@ void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {
     a.scratch_tail = h->scratch_tail.ptr;
   }
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[0], h->stream));
-  {
+  if (h->phase_select != 2) {
     auto kernel = grad ? (closed ? tp3_point_kernel<0, 1> : tp3_point_kernel<1, 1>)
                        : (closed ? tp3_point_kernel<0, 0> : tp3_point_kernel<1, 0>);
     hipLaunchKernelGGL(kernel, dim3((unsigned)h->n_el), dim3(128), 0, h->stream, a);
     MH_HIP(hipGetLastError());
   }
-  if (grad) {
+  if (grad && h->phase_select != 2) {
     hipLaunchKernelGGL(tp3_contract_kernel, dim3((unsigned)(n_cols * 9)), dim3(64), (16 * 3 * 64 + 48) * sizeof(double), h->stream, a);
     MH_HIP(hipGetLastError());
   }
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[1], h->stream));
-  const int64_t n_rows = (int64_t)(a.box_n[0] + 3) * (a.box_n[1] + 3) * (a.box_n[2] + 3) * 3;
-  if (grad)
+  const int64_t n_rows = (int64_t)a.win_n[0] * a.win_n[1] * a.win_n[2] * 3;   // (node window: the shard's nodes unless a gather asks for a part)
+  if (h->phase_select == 1) {
+    // integrate only
+  } else if (grad)
     hipLaunchKernelGGL(tp3_gather_kernel<1>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, h->stream, a, n_rows);
   else
     hipLaunchKernelGGL(tp3_gather_kernel<0>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, h->stream, a, n_rows);

@@ -170,6 +170,21 @@ class NonlinearSolid(NonlinearBase):
         self._user_stream = bool(stream)
         check(_capi.lib().mimi_hip_domain_set_stream(self._handle(), C.c_void_p(stream) if stream else None))
 
+    def Integrate(self, current_u):
+        """phase 1 of a tangent assembly on its own (mimi_hip.h: mimi_hip_domain_integrate): the element pieces stay in the
+        handle's scratch until Gather() adds them into r / A.  Two-phase tensor paths, device tensors."""
+        self._push_dt()
+        self._follow_torch(current_u)
+        check(_capi.lib().mimi_hip_domain_integrate(self._handle(), fptr(current_u)))
+
+    def Gather(self, grad_factor, residual, grad, node_begin, node_end):
+        """phase 2 over the nodes [node_begin, node_end) (global node indices per direction): r and A += the rows of those
+        nodes.  Every node the handle's elements touch is to be gathered exactly once per Integrate()."""
+        self._follow_torch(residual, grad)
+        lo = (C.c_int32 * 3)(*[int(v) for v in node_begin])
+        hi = (C.c_int32 * 3)(*[int(v) for v in node_end])
+        check(_capi.lib().mimi_hip_domain_gather(self._handle(), float(grad_factor), fptr(residual), fptr(grad), lo, hi))
+
     def _follow_torch(self, *buffers):
         # ordering with the caller's torch work (zero fills of r / A, copies of u): see _capi.torch_stream_of
         if getattr(self, "_user_stream", False):

@@ -225,6 +225,34 @@ class InterfaceExchange:
         hi = int(sh.starts[sh.rank + 1]) + p // 2 if sh.rank < sh.world_size - 1 else n_planes
         return list(range(lo, hi))
 
+    def gather_windows(self):
+        """(early, rest) for the two-step assembly (NonlinearSolid.Integrate / Gather): node boxes (begin, end) of this slab.
+        `early`: the node planes whose rows leave this rank -- gathered first, so that they can travel while `rest`,
+        everything else the slab's elements touch, is gathered."""
+        sh = self.shard
+        p = sh.patch.degrees[sh.axis]
+        nb, ne = sh.node_box()
+        b, e = int(sh.starts[sh.rank]), int(sh.starts[sh.rank + 1])
+        k_lo = p if self.mode == "replicate" else p // 2            # planes sent downward: [b, b + k_lo)
+        k_hi = p if self.mode == "replicate" else p - p // 2        # planes sent upward:   [e + p - k_hi, e + p)
+        lo, hi = nb[sh.axis], ne[sh.axis]
+
+        def box(x0, x1):
+            bb, ee = list(nb), list(ne)
+            bb[sh.axis], ee[sh.axis] = x0, x1
+            return bb, ee
+
+        early = []
+        if sh.rank > 0 and k_lo:
+            early.append(box(b, b + k_lo))
+            lo = b + k_lo
+        if sh.rank < sh.world_size - 1 and k_hi:
+            early.append(box(e + p - k_hi, e + p))
+            hi = e + p - k_hi
+        if lo >= hi:
+            raise RuntimeError("slab too thin for the two-step assembly")
+        return early, box(lo, hi)
+
     def start(self, with_grad, ready=None):
         """Pack the rows the neighbours need and put them on the wire (asynchronous with "nccl").
 

@@ -482,3 +482,45 @@ def test_small_elements_are_bitwise_reproducible(case, path, monkeypatch):
         G.AddDomainResidualAndGrad(u, 0.9, r, A)
         fd.append(A)
     assert np.array_equal(fd[0], fd[1])
+
+
+@pytest.mark.parametrize("case", [((5, 7, 4), 2, "neohook", None), ((4, 6, 5), 2, "j2", None), ((3, 5, 4), 3, "j2", None),
+                                  ((6, 8, 5), 2, "neohook", ([1, 2, 0], [5, 7, 5]))],
+                         ids=["p2-symmetric", "p2-nine-block", "p3", "p2-element-box"])
+def test_integrate_then_gather_in_parts_equals_one_call(case):
+    """the two-step form: Integrate() once, Gather() over node windows that partition the handle's nodes -- bitwise the
+    one-call assembly (same kernels, same order of additions per row); a window outside the handle's nodes is refused"""
+    import torch
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    n_el, p, matname, box = case
+    patch = mimi_amd.BSplinePatch.block(n_el, p)
+    dev = torch.device("cuda", 0)
+    pattern = CSRPattern.of_bspline_patch(patch, on_device=True)
+    G = NonlinearSolid("domain", product_material(matname), pattern, patch=patch, element_box=box).Prepare()
+    G.dt_ = 0.5
+    from oracle import iga
+    u = torch.from_numpy(synthetic_u(iga.Patch.block(n_el, p), scale=0.05 if matname == "neohook" else 0.02)).to(dev)
+    r1 = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
+    A1 = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
+    G.AddDomainResidualAndGrad(u, 0.7, r1, A1)
+    G.Synchronize()
+    eb, ee = box if box else ([0, 0, 0], list(n_el))
+    lo, hi = list(eb), [ee[d] + p for d in range(3)]                    # the nodes the handle's elements touch
+    r2, A2 = torch.zeros_like(r1), torch.zeros_like(A1)
+    with pytest.raises(RuntimeError):
+        G.Gather(0.7, r2, A2, lo, hi)                                   # nothing integrated yet
+    G.Integrate(u)
+    cuts = [lo[1], lo[1] + 1, lo[1] + 1 + (hi[1] - lo[1]) // 2, hi[1]]   # three windows along y: one plane, a half, the rest
+    for y0, y1 in zip(cuts[:-1], cuts[1:]):
+        G.Gather(0.7, r2, A2, [lo[0], y0, lo[2]], [hi[0], y1, hi[2]])
+    G.Synchronize()
+    assert float(A1.abs().max()) > 0 and torch.equal(r1, r2) and torch.equal(A1, A2)
+    with pytest.raises(RuntimeError):
+        G.Gather(0.7, r2, A2, [lo[0], lo[1] - 1, lo[2]], hi)            # a window outside the handle's nodes
+    # a handle on the general kernels has no two-step form
+    P2d = mimi_amd.BSplinePatch.block((4, 3), 2)
+    pat2 = CSRPattern.of_bspline_patch(P2d, on_device=True)
+    g2 = NonlinearSolid("domain", product_material("neohook"), pat2, patch=P2d).Prepare()
+    with pytest.raises(RuntimeError):
+        g2.Integrate(torch.zeros(P2d.n_vdofs, dtype=torch.float64, device=dev))

@@ -194,3 +194,33 @@ def test_owner_mode_needs_fewer_boundary_layers():
         assert lower == 0 or interior[0][2] >= 10 + p // 2
         boundary_r, interior_r = sh.overlap_boxes(mode="replicate")
         assert sorted((b[2], e[2]) for b, e in boundary_r) == [(10, 10 + p), (20 - p, 20)]
+
+
+def test_gather_windows_partition_the_slab_nodes():
+    """two-step assembly: the planes that leave the rank first, the rest afterwards; together every node plane of the slab once"""
+    import torch
+    import mimi_amd
+    from mimi_amd import parallel
+    from mimi_amd.integrators import CSRPattern
+    from oracle import iga
+    for p, mode, rank, world in ((2, "owner", 1, 3), (2, "replicate", 0, 2), (3, "owner", 2, 3), (1, "owner", 1, 3)):
+        n_el = (2, 2, 18)
+        P = iga.Patch.block(n_el, p)
+        rowptr, col = P.sparsity()
+        patch = mimi_amd.BSplinePatch.block(n_el, p)
+        sh = parallel.SlabShard(patch, CSRPattern(rowptr, col, rowptr[-1]), rank, world)
+        ex = parallel.InterfaceExchange.__new__(parallel.InterfaceExchange)      # (no communicator needed for the plan)
+        ex.shard, ex.mode = sh, mode
+        early, rest = ex.gather_windows()
+        nb, ne = sh.node_box()
+        planes = sorted(x for b, e in early + [rest] for x in range(b[2], e[2]))
+        assert planes == list(range(nb[2], ne[2]))
+        for b, e in early + [rest]:
+            assert b[:2] == nb[:2] and e[:2] == ne[:2]
+        b0, e0 = int(sh.starts[rank]), int(sh.starts[rank + 1])
+        sent = []
+        if rank > 0:
+            sent += list(range(b0, b0 + (p if mode == "replicate" else p // 2)))
+        if rank < world - 1:
+            sent += list(range(e0 + (0 if mode == "replicate" else p // 2), e0 + p))
+        assert sorted(x for b, e in early for x in range(b[2], e[2])) == sent

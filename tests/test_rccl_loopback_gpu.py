@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(port, n_el, p, fake_rank, fake_world, mode, q):
+def _worker(port, n_el, p, fake_rank, fake_world, mode, scheme, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -39,35 +39,53 @@ def _worker(port, n_el, p, fake_rank, fake_world, mode, q):
         shard.pattern = pattern
         stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(stream)
-        boundary_boxes, interior_box = shard.overlap_boxes(mode=mode)
-        assert boundary_boxes
-        handles = []
-        for box in boundary_boxes + [interior_box]:
-            g = NonlinearSolid("domain", bench.make_material("neohookean"), pattern, patch=patch, element_box=box).Prepare()
-            g.SetStream(stream.cuda_stream)
-            handles.append(g)
-        # a middle rank has two boundary boxes that share no node: the second runs beside the first on its own stream
-        side = None
-        if len(boundary_boxes) == 2 and shard.boxes_share_no_node(boundary_boxes):
-            side = torch.cuda.Stream(device=dev)
-            handles[1].SetStream(side.cuda_stream)
         u = torch.from_numpy(bench.synthetic_u(patch)).to(dev)
         r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
         A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
         ex = parallel.InterfaceExchange(shard, r, A, dev, mode=mode, loopback=True)
-        for _ in range(3):                       # several steps back to back: buffers are reused without a host sync
-            ex.zero_interface(True)
-            if side:
-                side.wait_stream(stream)
-            for g in handles[:-1]:
-                g.AddDomainResidualAndGrad(u, 1.0, r, A)
-            if side:
-                stream.wait_stream(side)
-            ready = torch.cuda.Event()            # the interface rows are complete here; the sends wait for this only
-            ready.record(stream)
-            handles[-1].AddDomainResidualAndGrad(u, 1.0, r, A)
-            ex.start(True, ready=ready)
-            ex.finish()
+        if scheme == "gather":
+            # one handle: integrate, gather the rows that leave first, send them while the rest is gathered
+            g = NonlinearSolid("domain", bench.make_material("neohookean"), pattern, patch=patch, element_box=shard.element_box).Prepare()
+            g.SetStream(stream.cuda_stream)
+            handles = [g]
+            early, rest = ex.gather_windows()
+            assert len(early) == len(ex.sides)
+            for _ in range(3):
+                ex.zero_interface(True)
+                g.Integrate(u)
+                for w in early:
+                    g.Gather(1.0, r, A, *w)
+                ready = torch.cuda.Event()
+                ready.record(stream)
+                g.Gather(1.0, r, A, *rest)
+                ex.start(True, ready=ready)
+                ex.finish()
+        else:
+            boundary_boxes, interior_box = shard.overlap_boxes(mode=mode)
+            assert boundary_boxes
+            handles = []
+            for box in boundary_boxes + [interior_box]:
+                g = NonlinearSolid("domain", bench.make_material("neohookean"), pattern, patch=patch, element_box=box).Prepare()
+                g.SetStream(stream.cuda_stream)
+                handles.append(g)
+            # a middle rank has two boundary boxes that share no node: the second runs beside the first on its own stream
+            side = None
+            if len(boundary_boxes) == 2 and shard.boxes_share_no_node(boundary_boxes):
+                side = torch.cuda.Stream(device=dev)
+                handles[1].SetStream(side.cuda_stream)
+            for _ in range(3):                       # several steps back to back: buffers are reused without a host sync
+                ex.zero_interface(True)
+                if side:
+                    side.wait_stream(stream)
+                for g in handles[:-1]:
+                    g.AddDomainResidualAndGrad(u, 1.0, r, A)
+                if side:
+                    stream.wait_stream(side)
+                ready = torch.cuda.Event()            # the interface rows are complete here; the sends wait for this only
+                ready.record(stream)
+                handles[-1].AddDomainResidualAndGrad(u, 1.0, r, A)
+                ex.start(True, ready=ready)
+                ex.finish()
         torch.cuda.synchronize()
         for g in handles:
             g.Synchronize()
@@ -108,9 +126,10 @@ def _worker(port, n_el, p, fake_rank, fake_world, mode, q):
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("scheme", ["boundary", "gather"])
 @pytest.mark.parametrize("n_el,p,fake_rank,fake_world,mode", [((4, 4, 18), 2, 1, 3, "replicate"), ((4, 4, 12), 2, 0, 2, "owner"),
                                                                ((3, 3, 24), 3, 1, 3, "replicate")])
-def test_interface_exchange_over_rccl_loopback(n_el, p, fake_rank, fake_world, mode):
+def test_interface_exchange_over_rccl_loopback(n_el, p, fake_rank, fake_world, mode, scheme):
     import torch.multiprocessing as mp
     import socket
     with socket.socket() as sk:
@@ -118,7 +137,7 @@ def test_interface_exchange_over_rccl_loopback(n_el, p, fake_rank, fake_world, m
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    pr = ctx.Process(target=_worker, args=(port, n_el, p, fake_rank, fake_world, mode, q))
+    pr = ctx.Process(target=_worker, args=(port, n_el, p, fake_rank, fake_world, mode, scheme, q))
     pr.start()
     try:
         res = q.get(timeout=300)
