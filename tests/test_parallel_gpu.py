@@ -63,6 +63,7 @@ def _worker(rank, world, port, n_el, mode, q):
         stream = torch.cuda.Stream(device=dev)
         torch.cuda.set_stream(stream)
         overlap = "+overlap" in mode
+        gather = "+gather" in mode
         mode = mode.split("+")[0]
         boundary_boxes, interior_box = shard.overlap_boxes(mode=mode) if overlap else ([], shard.element_box)
         handles = []
@@ -77,7 +78,16 @@ def _worker(rank, world, port, n_el, mode, q):
         ex = parallel.InterfaceExchange(shard, r, A, dev, mode=mode)
         for _ in range(2):                        # twice: zero_interface must reset the shared rows
             ex.zero_interface(True)
-            if len(handles) > 1:
+            if gather:
+                # two-step assembly: one handle, the rows that leave the rank first, the others while they travel
+                early, rest = ex.gather_windows()
+                handles[0].Integrate(u)
+                for w in early:
+                    handles[0].Gather(1.0, r, A, *w)
+                ex.start(True)
+                handles[0].Gather(1.0, r, A, *rest)
+                ex.finish()
+            elif len(handles) > 1:
                 for g in handles[:-1]:            # the element layers next to the neighbours first ...
                     g.AddDomainResidualAndGrad(u, 1.0, r, A)
                 ex.start(True)                    # ... their interface rows travel ...
@@ -127,6 +137,7 @@ def _worker(rank, world, port, n_el, mode, q):
 @pytest.mark.parametrize("world,n_el,mode", [(2, (4, 6, 3), "owner"), (3, (3, 4, 9), "owner"), (2, (5, 4, 3), "replicate"),
                                              (3, (3, 4, 15), "owner+overlap"), (2, (4, 10, 3), "owner+overlap"),
                                              (3, (3, 4, 15), "owner+overlap+slice"), (2, (4, 10, 3), "owner+slice"),
+                                             (3, (3, 4, 15), "owner+gather+slice"), (2, (4, 10, 3), "replicate+gather"),
                                              (2, (3, 4, 6), "replicate+slice")])
 def test_slabs_on_one_gpu(world, n_el, mode):
     import torch.multiprocessing as mp
