@@ -447,9 +447,7 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       DV[mn] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[mn][3], bS2[v2][1], DV[mn], 0, 0, 0);
     }
     // the operands of the next element travel while this one is contracted
-#ifndef T3X_NO_LOAD
     request(es + 1 < n_seq ? es + 1 : es);   // (the last element once more: no branch in the loop)
-#endif
     const int64_t e = e0 + e_step * es;
     double* piece = p.scratch_k + (e * 3 + I) * (int64_t)T3_PIECE;
     double* out0 = piece + pa * 192 + J * 64 + kk * 4 + pb;                       // + 4 a1 192 + b1 16
@@ -498,14 +496,7 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       };
       {
         double Em[4][NB];
-#ifdef T3X_NO_S2   // (timing experiments only: scratch/p3_variants.sh)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int a1 = 0; a1 < NB; ++a1) Em[g][a1] = DU[g + a1][b1];
-#else
         s2(std::false_type{}, Em);
-#endif
 #pragma unroll
         for (int a1 = 0; a1 < NB; ++a1) {
           const double* c = cl + (a1 * NB + b1) * 3 * 64;
@@ -513,48 +504,24 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
           Kt[a1][0] = c[0];
           Kt[a1][1] = c[64];
           Kt[a1][2] = c[128];
-#ifdef T3X_NO_S3
-#pragma unroll
-          for (int g = 0; g < 4; ++g) Kt[a1][g] += Em[g][a1];
-#else
 #pragma unroll
           for (int g = 0; g < 4; ++g) Kt[a1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Em[g][a1], bS0[g], Kt[a1], 0, 0, 0);
-#endif
         }
       }
       __builtin_amdgcn_sched_barrier(0);
       double Ex[4][NB];
-#ifdef T3X_NO_S2
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int a1 = 0; a1 < NB; ++a1) Ex[g][a1] = DV[g + a1][b1];
-#else
       s2(std::true_type{}, Ex);
-#endif
 #pragma unroll
       for (int a1 = 0; a1 < NB; ++a1) {
         double* c = cl + (a1 * NB + b1) * 3 * 64;
-#ifdef T3X_NO_S3
-        t3_d4 Kt1 = Kt[a1];
-        Kt1[0] += Ex[0][a1] + Ex[1][a1];
-        Kt1[1] += Ex[2][a1] + Ex[3][a1];
-#else
         t3_d4 Kt1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t3_low_halves(Ex[0][a1], Ex[1][a1]), bS0x[0], Kt[a1], 0, 0, 0);
         Kt1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t3_low_halves(Ex[2][a1], Ex[3][a1]), bS0x[1], Kt1, 0, 0, 0);
-#endif
         // register r of this lane: (a2 = r, b2 = (r + kk) & 3), column (a0 = pa, b0 = pb).  Final: a2 = 0 or b2 = 0.
-#ifdef T3X_NO_STORE
-        if (Kt1[0] == 123.456)
-#endif
         out0[a1 * 4 * 192 + b1 * 16] = Kt1[0];
         double fin = Kt1[1];
         fin = kk == 2 ? Kt1[2] : fin;
         fin = kk == 1 ? Kt1[3] : fin;
         fin = kk == 0 ? Kt1[0] : fin;
-#ifdef T3X_NO_STORE
-        if (fin == 123.456)
-#endif
         out1[kk == 0 ? a1 * 4 * 192 + b1 * 16 : a1 * 4 * 48 + b1 * 4] = fin;
         // the pairs (a2 >= 1, b2 >= 1) go on to the next element as its (a2 - 1, b2 - 1)
 #pragma unroll
