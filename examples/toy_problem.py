@@ -19,25 +19,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import mimi_amd as mimi  # noqa: E402
 
-# control net of the channel, first parametric direction (25 points, degree 2) fastest; rows: v = 0 and v = 1
-CHANNEL = np.array([
-    [0.5064575645756457, 0.2007200720072007], [0.5821033210332104, 0.2007200720072007], [0.6236162361623616, 0.23222322232223222],
-    [0.6559040590405905, 0.2556255625562556], [0.6559040590405905, 0.2907290729072907], [0.6559040590405905, 0.33033303330333036],
-    [0.6134686346863468, 0.35193519351935193], [0.5830258302583026, 0.36723672367236726], [0.45202952029520294, 0.38973897389738976],
-    [0.2564575645756458, 0.42304230423042305], [0.18035055350553506, 0.4513951395139514], [0.10424354243542436, 0.47974797479747977],
-    [0.05212177121771218, 0.5472547254725473], [0.0, 0.6147614761476148], [0.0, 0.7011701170117012], [0.0, 0.7956795679567957],
-    [0.05627306273062731, 0.8640864086408641], [0.11254612546125461, 0.9324932493249325], [0.21125461254612546, 0.9662466246624662],
-    [0.30996309963099633, 1.0], [0.47601476014760147, 1.0], [0.6512915129151291, 1.0], [0.7347785977859779, 0.9738973897389739],
-    [0.8182656826568265, 0.9477947794779478], [0.8740774907749077, 0.8928892889288929],
-    [0.4870848708487085, 0.0], [0.6771217712177122, 0.0], [0.7873616236162362, 0.04635463546354635],
-    [0.8976014760147601, 0.0927092709270927], [0.9488007380073801, 0.171017101710171], [1.0, 0.24932493249324933],
-    [1.0, 0.3321332133213321], [1.0, 0.414041404140414], [0.9515682656826568, 0.48244824482448245],
-    [0.9031365313653137, 0.5508550855085509], [0.8118081180811808, 0.5877587758775877], [0.7204797047970479, 0.6246624662466247],
-    [0.533210332103321, 0.6453645364536453], [0.4095940959409594, 0.6597659765976598], [0.3726937269372694, 0.6777677767776777],
-    [0.33579335793357934, 0.6957695769576958], [0.33579335793357934, 0.7308730873087309], [0.33579335793357934, 0.7623762376237624],
-    [0.36485239852398527, 0.7844284428442845], [0.39391143911439114, 0.8064806480648065], [0.4575645756457565, 0.8064806480648065],
-    [0.5202952029520295, 0.8064806480648065], [0.5645756457564576, 0.7776777677767777], [0.5968634686346863, 0.7560756075607561],
-    [0.6107011070110702, 0.7101710171017102]])
+# control net of the channel (25 x 2 points, degree 2 x 1, first parametric direction fastest; rows: v = 0 and v = 1)
+CHANNEL = np.loadtxt(os.path.join(REPO, "examples", "data", "toy_channel_net.txt"))
 KNOTS = [0.0] * 3 + [float(k) for k in range(1, 12) for _ in range(2)] + [12.0] * 3
 
 
