@@ -27,14 +27,14 @@ import subprocess
 import sys
 import time
 
-# the CPUs this process may use, read BEFORE any OpenMP runtime is loaded: with OMP_PROC_BIND the runtime pins the
-# initial thread to one place, after which the affinity mask says "1 CPU"
+# the CPUs this process may use, read before any OpenMP runtime is loaded
 try:
     _AFFINITY_AT_START = len(os.sched_getaffinity(0))
 except (AttributeError, OSError):
     _AFFINITY_AT_START = os.cpu_count() or 1
-# OMP_PROC_BIND=close for the CPU baseline; the OpenMP runtime reads it when it is loaded (import torch)
-os.environ.setdefault("OMP_PROC_BIND", "close")
+# OMP_PROC_BIND is NOT set here: an OpenMP runtime loaded under it (import torch) pins the initial thread to one CPU, and
+# every child process -- the ranks of --gpus N, their RCCL proxy threads -- inherits that one-CPU mask.  BASELINE.md 2's
+# OMP_PROC_BIND=close belongs to the CPU baseline alone, which runs in a child process of its own (cpu_baseline_child).
 
 import numpy as np
 
@@ -95,7 +95,7 @@ def recorded_pmc(workload, world, grad, material):
     kernel's 8-byte accesses by scratch/fetch_calib.hip).  bench.py cannot run the profiler on itself, so these are
     RECORDED numbers: returned with their source, and dropped (None) when the kernel sources changed since."""
     key = f"{workload}/{material}/{'grad' if grad else 'residual'}/n{world}"
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f).get(key)
@@ -105,12 +105,48 @@ def recorded_pmc(workload, world, grad, material):
             continue
         current = kernel_sources_sha()
         fresh = t.get("kernel_sources_sha") == current
+        per_kernel = {k: 2048.0 * t["fetch_size_kb_raw"].get(k, 0.0) + 1024.0 * t["write_size_kb"].get(k, 0.0)
+                      for k in t.get("fetch_size_kb_raw", {})} if "write_size_kb" in t else None
         return dict(bytes_per_step=t.get("bytes_per_step") if fresh else None,
                     pipe=t.get("pipe") if fresh else None,
+                    per_kernel_bytes=per_kernel if fresh else None,
                     traffic_source=f"profiles/{name} ({t.get('source', 'rocprofv3 --pmc')})",
                     recorded_for_kernel_sources_sha=t.get("kernel_sources_sha"), current_kernel_sources_sha=current,
                     stale=not fresh)
     return None
+
+
+# fp64 work the sum-factorised kernels usefully do per element (SURVEY 8d's F_alg prices the dense
+# B^T A B form: 2.9 / 29 MFLOP) and the chip's fp64 pipe: 1024 SIMDs x 32 flop per cycle x 2.4 GHz = 78.6 TFLOP/s
+USEFUL_FLOP = {2: 0.5e6, 3: 2.8e6}
+FP64_PEAK, N_SIMD, CLOCK_HZ = 78.6e12, 1024, 2.4e9
+
+
+def binding_rooflines(p, elements, phase_ms, pmc):
+    """"state the achieved fraction of whichever bound is binding, do not relabel".  Phase 1 (integration) is
+    bound by the fp64 pipe, phase 2 (row gather) by HBM: per phase the live duration (events in the library) and, from the
+    RECORDED counters of the same kernel sources (None when they changed since), the issued share of the fp64 pipe
+    (matrix instructions at 64 cycles, vector instructions at 4 cycles each -- all vector instructions, so an upper
+    bound on the fp64 share) and the HBM bytes over the phase's time."""
+    if phase_ms is None:
+        return None
+    t1, t2 = phase_ms[0] * 1e-3, phase_ms[1] * 1e-3
+    pipe = (pmc or {}).get("pipe") or {}
+    raw = (pmc or {}).get("per_kernel_bytes") or {}
+    integ = {k: v for k, v in pipe.items() if "gather" not in k and "p2_kernel" not in k}
+    gath = [k for k in raw if "gather" in k or "p2_kernel" in k]
+    cycles = sum(v["mfma_instructions_per_element"] * 64.0 + v["valu_instructions_per_element"] * 4.0 for v in integ.values())
+    phase1 = {"resource": "fp64 pipe (matrix and vector fp64 instructions share it on gfx950)", "ms": phase_ms[0],
+              "useful_flop_frac": USEFUL_FLOP.get(p, 0.0) * elements / t1 / FP64_PEAK if t1 > 0 else None,
+              "useful_flop_per_element": USEFUL_FLOP.get(p),
+              "issued_frac": cycles * elements / (N_SIMD * CLOCK_HZ * t1) if integ and t1 > 0 else None,
+              "issued_cycles_per_element": cycles if integ else None,
+              "peak": "78.6 TFLOP/s = 1024 SIMDs x 32 flop/cycle x 2.4 GHz"}
+    bytes2 = sum(raw[k] for k in gath) if gath else None
+    phase2 = {"resource": "hbm", "ms": phase_ms[1], "measured_bytes": bytes2,
+              "frac": bytes2 / t2 / 8e12 if bytes2 and t2 > 0 else None, "peak": "8 TB/s"}
+    return {"phase1": phase1, "phase2": phase2,
+            "counters": "recorded rocprofv3 PMC passes of these kernel sources" if pipe else "none for these kernel sources"}
 
 
 def make_material(kind):
@@ -240,6 +276,8 @@ def cpu_baseline(p, material, threads=None, n_el=None, sweep=False):
     a bounded sample of the workload, by BASELINE.md 2's protocol: threads = physical cores, OMP_PROC_BIND=close,
     3 warm-up + >= 10 timed assemblies, median."""
     from oracle import iga, ref_path as rp
+    if not n_el and os.environ.get("MIMI_BENCH_CPU_SAMPLE"):          # (tests: a sample that takes seconds)
+        n_el = [int(x) for x in os.environ["MIMI_BENCH_CPU_SAMPLE"].split("x")]
     n_el = tuple(n_el) if n_el else ((64, 64, 8) if p == 2 else (32, 32, 8))
     cores, cores_why = physical_cores()
     threads = threads or cores
@@ -294,9 +332,48 @@ def cpu_baseline(p, material, threads=None, n_el=None, sweep=False):
     return out
 
 
+def cpu_baseline_child(workload, sweep=False):
+    """cpu_baseline() in a child process of its own with OMP_PROC_BIND=close: the binding (and the one-CPU affinity mask
+    an OpenMP runtime leaves on the thread that loaded it) stays out of this process and of everything it starts.  The
+    child imports numpy and the oracle only (no torch, no HIP)."""
+    env = dict(os.environ, OMP_PROC_BIND="close")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", workload]
+    if sweep:
+        cmd.append("--cpu-sweep")
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=3000 if sweep else 900)
+    if out.returncode != 0:
+        raise RuntimeError(f"CPU baseline child exited with {out.returncode}")
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
+    return json.loads(lines[-1])
+
+
 # ------------------------------------------------------------------------------------------------
 # rank launcher
 # ------------------------------------------------------------------------------------------------
+def visible_gpu_count():
+    """GPUs this process would see, counted WITHOUT loading HIP (the launcher must not touch a GPU before it starts its
+    ranks): KFD topology nodes with SIMDs, clipped by a *_VISIBLE_DEVICES list; no KFD, no GPU."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(base)
+    except OSError:
+        return 0
+    n = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -305,30 +382,57 @@ def _free_port():
 
 def launch_ranks(args):
     """--gpus N without a launcher: N fresh processes, started before anything in this one touches a GPU."""
-    import torch
     backend = os.environ.get("MIMI_BENCH_BACKEND", "nccl")
-    visible = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    visible = visible_gpu_count()                # (sysfs: no HIP, no torch in this process)
     if backend == "nccl" and visible < args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this box shows {visible}; "
                          f"(MIMI_BENCH_BACKEND=gloo rehearses the N-rank code path on fewer GPUs, timings meaningless)\n")
         return 2
     env = dict(os.environ)
+    env.pop("OMP_PROC_BIND", None)               # (a bound OpenMP runtime would pin each rank's host threads to one CPU)
     env.update(WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    import tempfile
     procs = []
-    for rank in range(args.gpus):
-        e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for line in out0.decode().splitlines():      # (gloo greets on stdout: keep stdout to the one JSON line)
-        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+    with tempfile.TemporaryFile() as out0:       # rank 0's stdout (a file: nobody has to drain a pipe while we poll)
+        for rank in range(args.gpus):
+            e = dict(env, RANK=str(rank), LOCAL_RANK=str(rank))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                          stdout=out0 if rank == 0 else subprocess.DEVNULL))
+        codes = supervise(procs)
+        out0.seek(0)
+        for line in out0.read().decode().splitlines():      # (gloo greets on stdout: keep stdout to the one JSON line)
+            (sys.stdout if line.startswith("{") and not any(codes) else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     if any(codes):
         sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
         return 1
     return 0
+
+
+def supervise(procs, poll_s=0.2, grace_s=5.0):
+    """Wait for every rank; as soon as ONE exits non-zero the others are terminated (then killed): a rank that died at
+    start-up would otherwise leave the rest inside init_process_group / their first collective until the process
+    group's timeout.  Returns the exit codes.  (The children are fresh processes; nothing is re-executed.)"""
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            return codes
+        if any(c not in (None, 0) for c in codes):
+            bad = [i for i, c in enumerate(codes) if c not in (None, 0)]
+            sys.stderr.write(f"bench.py: rank(s) {bad} exited with {[codes[i] for i in bad]}; stopping the others\n")
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.monotonic() + grace_s
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.0, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            return [p.returncode for p in procs]
+        time.sleep(poll_s)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -581,13 +685,18 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
             config={"workload": f"{'x'.join(map(str, n_el))} p={p} {material} B-spline block, "
                                 f"{n_elements} elements, n_q={(p + 2) ** patch.dim}, nnz={pattern.nnz}",
                     "name": workload,
-                    "parallelism": f"element slabs x{world}" + (", interface rows summed on their owner rank" if world > 1 else "")
+                    "parallelism": f"element slabs x{world}" + (", interface rows summed on their owner rank; every rank holds "
+                                   "its row slice of the matrix values, a full-length residual vector and a replica of u"
+                                   if world > 1 else "")
                                    + (", exchange overlapped with the interior elements" if boundary else "")
                                    + (", rows that leave the rank gathered first and sent while the others are gathered"
                                       if scheme == "gather" else ""),
                     "kernel_path": "tensor" if integ.path_ == 1 else "general",
                     "u": f"{0.01 if workload == 'cfg4' else 0.05}*N(0,1), seed 20241008, face x=0 clamped"},
-            roofline={"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+            roofline={"bound": "hbm", "bound_note": "the HBM roofline of SURVEY 8d's algorithmic bytes, as the contract asks; the "
+                      "resource that actually binds each phase is in `binding` (phase 1: fp64 pipe, phase 2: HBM)",
+                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                      "binding": binding_rooflines(p, local_elements, phase_ms, pmc),
                       "traffic": pmc["bytes_per_step"] if pmc else None,
                       "traffic_source": None if not pmc else {k: pmc[k] for k in ("traffic_source", "recorded_for_kernel_sources_sha",
                                                                                    "current_kernel_sources_sha", "stale")},
@@ -660,10 +769,13 @@ def run_rank(args):
     comm_ranks = 1
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a short timeout: a rank that never arrives fails the others within minutes, not after the default half hour
+        import datetime
+        patience = datetime.timedelta(seconds=int(os.environ.get("MIMI_BENCH_PG_TIMEOUT", "240")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, pg_options=_rccl_options())
+            dist.init_process_group("nccl", device_id=dev, pg_options=_rccl_options(), timeout=patience)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=patience)
         # one sum over the communicator before anything is timed: every rank is there and the transport works
         ones = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(ones)
@@ -722,14 +834,29 @@ def run_rank(args):
         if other:
             out["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
-            _, p, material = WORKLOADS[args.workload]
-            out["cpu_baseline"] = cpu_baseline(p, material, sweep=args.cpu_sweep)
+            out["cpu_baseline"] = cpu_baseline_child(args.workload, sweep=args.cpu_sweep)
             out["cpu_baseline"]["gpu_over_cpu"] = main["value"] / out["cpu_baseline"]["value"]
+            # BASELINE.md holds no published figure for this metric; its section 2 names the number to compare with: the
+            # restated reference CPU path timed on this box (above), reference forward-FD Jacobian
+            out["vs_baseline"] = main["value"] / out["cpu_baseline"]["value"]
+            out["vs_baseline_note"] = ("value / cpu_baseline.value (BASELINE.md 2: no published number exists; the restated "
+                                       "reference OpenMP path on this box's host cores is the baseline)")
         else:
             out["cpu_baseline"] = None
         _emit(json_fd, out)
     if world > 1:
         dist.destroy_process_group()
+    # a wrong exchange must not exit 0 (N > 1): the check ran on every rank and the owned rows agree
+    bad = None
+    chk = main.get("check") if main else None
+    if rank == 0 and world > 1 and not args.no_check and not args.residual_only:
+        if not chk or "error" in chk:
+            bad = f"the N > 1 check did not run: {chk}"
+        elif not (chk["residual_rel_err"] < 1e-10 and chk["tangent_rel_err"] < 1e-10):
+            bad = f"owned rows differ from the whole-patch assembly: {chk}"
+    if bad:
+        sys.stderr.write("bench.py: " + bad + "\n")
+        sys.exit(3)
 
 
 def main():
@@ -741,6 +868,9 @@ def main():
                     help="time the step of the middle rank of an N-rank job on this one GPU, exchange over RCCL to itself")
     ap.add_argument("--workload", default=os.environ.get("MIMI_BENCH_WORKLOAD", "northstar"), choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="print the CPU baseline of the workload as one JSON line and exit (no GPU, no torch: what "
+                         "cpu_baseline_child runs under OMP_PROC_BIND=close)")
     ap.add_argument("--cpu-sweep", action="store_true", help="add a 1/32/64/128-thread sweep of the CPU baseline (minutes)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the cfg3 measurement that follows the north-star one at N = 1")
     ap.add_argument("--scheme", default="gather", choices=["gather", "boundary", "none"],
@@ -752,6 +882,10 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.cpu_baseline_only:
+        _, p, material = WORKLOADS[args.workload]
+        print(json.dumps(cpu_baseline(p, material, sweep=args.cpu_sweep)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     run_rank(args)

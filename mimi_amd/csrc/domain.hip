@@ -268,18 +268,7 @@ static bool ensure_general_two_phase(mimi_hip_domain_s* h, bool with_k) {
   static const bool off = getenv("MIMI_HIP_GENERAL_NO_TWO_PHASE") && getenv("MIMI_HIP_GENERAL_NO_TWO_PHASE")[0] == '1';
   if (off || h->general_two_phase_failed) return false;
   const size_t n_tdof = (size_t)h->n_dof * h->dim;
-  const size_t need = with_k ? (size_t)h->n_el * n_tdof * n_tdof : 0;
-  if (h->scratch_k.count < need) {
-    size_t free_b = 0, total_b = 0;
-    MH_HIP(hipMemGetInfo(&free_b, &total_b));
-    const size_t have = h->scratch_k.count * sizeof(double);
-    if (need * sizeof(double) > free_b + have || need * sizeof(double) > (total_b / 2)) {
-      h->general_two_phase_failed = true;
-      return false;
-    }
-    h->scratch_k.resize(need);
-  }
-  h->scratch_r.resize((size_t)h->n_el * n_tdof);
+  // what rules the path out is checked BEFORE anything is allocated (3-D degree >= 4 would be 1.1 MB per element)
   if (!h->adj_ptr.ptr) {
     // the gather kernel keeps one CSR row in LDS: rows longer than its image -> atomics
     std::vector<int64_t> rp((size_t)h->n_vdofs + 1);
@@ -290,6 +279,22 @@ static bool ensure_general_two_phase(mimi_hip_domain_s* h, bool with_k) {
       h->general_two_phase_failed = true;
       return false;
     }
+  }
+  const size_t need = with_k ? (size_t)h->n_el * n_tdof * n_tdof : 0;
+  if (h->scratch_k.count < need) {
+    size_t free_b = 0, total_b = 0;
+    MH_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t have = h->scratch_k.count * sizeof(double);
+    if (need * sizeof(double) > free_b + have || need * sizeof(double) > (total_b / 2)) {
+      h->general_two_phase_failed = true;
+      h->scratch_k.release();          // (whatever a residual-only call left: the atomics route needs none of it)
+      h->scratch_r.release();
+      return false;
+    }
+    h->scratch_k.resize(need);
+  }
+  h->scratch_r.resize((size_t)h->n_el * n_tdof);
+  if (!h->adj_ptr.ptr) {
     const size_t n = (size_t)h->n_el * h->n_dof;
     std::vector<int32_t> dofs(n);
     MH_HIP(hipMemcpy(dofs.data(), h->dofs.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -428,6 +433,7 @@ static bool launch_tensor_small(mimi_hip_domain_s* h, int mode, const double* u,
 static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double* A, double gf, bool with_grad) {
   MH_HIP(hipSetDevice(h->device));
   if (!u || !r || (with_grad && !A)) fail("null vector argument");
+  h->integrated = false;   // the element pieces of an earlier mimi_hip_domain_integrate are overwritten by this call
   Mirror<double> mu = Mirror<double>::in(u, h->n_vdofs, h->stage_u, h->stream);
   Mirror<double> mr = Mirror<double>::inout(r, h->n_vdofs, h->stage_r, h->stream);
   Mirror<double> mA;
@@ -437,9 +443,11 @@ static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double*
   // materials only: the other materials then take the general kernels)
   if (tensor_small(h) && grad != 2 && launch_tensor_small(h, grad, mu.dev, mr.dev, mA.dev, gf)) {
     // (2-D, degree 1: element kernel from the 1-D tables + the general gather)
+    h->last_family = 3;
   } else if (tensor_usable(h) && !tensor_small(h) && grad != 2 && (material_closed_form(h->mat.m.kind) || two_phase_supported(h))) {
-    launch_tensor(h, grad, mu.dev, mr.dev, mA.dev, gf);
+    h->last_family = launch_tensor(h, grad, mu.dev, mr.dev, mA.dev, gf);
   } else {
+    h->last_family = 4;
     ensure_general_tables(h);
     GeneralArgs a = general_args(h, mu.dev, mr.dev, mA.dev, gf);
     if (h->dim == 2) launch_general<2>(h, grad, a); else launch_general<3>(h, grad, a);
@@ -767,8 +775,11 @@ int mimi_hip_domain_set_stream(mimi_hip_domain_t h, void* stream) {
 
 // the two-step form of a tangent assembly: phase 1 of the whole handle, then phase 2 over parts of its nodes
 static void require_two_phase(mimi_hip_domain_s* h) {
+  const char* variant = getenv("MIMI_HIP_TENSOR_VARIANT");
+  const bool colour_forced = variant && variant[0] == 'v' && h->degree[0] == 2 &&
+                             (h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN || h->mat.m.kind == MIMI_HIP_MAT_J2);
   const bool ok = h->dim == 3 && tensor_usable(h) && !tensor_small(h) && two_phase_supported(h) &&
-                  h->tangent_mode == MIMI_HIP_TANGENT_ANALYTIC;
+                  h->tangent_mode == MIMI_HIP_TANGENT_ANALYTIC && !colour_forced;
   if (!ok) fail("integrate / gather: only on the two-phase tensor paths (3-D, degree 2 or 3, structured CSR, analytic tangent)");
 }
 
@@ -844,6 +855,7 @@ int mimi_hip_domain_post_time_advance(mimi_hip_domain_t h, const double* u) {
     if (!h) fail("null handle");
     if (!material_has_state(h->mat.m.kind)) return;  // has_states_ == false (nonlinear_solid.cpp:182-183)
     MH_HIP(hipSetDevice(h->device));
+    h->integrated = false;   // (the state the stored pieces were integrated with is about to change)
     Mirror<double> mu = Mirror<double>::in(u, h->n_vdofs, h->stage_u, h->stream);
     if (tensor_small(h)) {
       launch_tensor_small(h, 2, mu.dev, nullptr, nullptr, 0.0);
@@ -922,21 +934,6 @@ int mimi_hip_domain_reset_state(mimi_hip_domain_t h) {
   });
 }
 
-// diagnostic (MH_PROFILE builds): per-stage cycle sums of the tensor kernel; not part of the ABI header
-int mimi_hip_debug_profile(mimi_hip_domain_t h, unsigned long long* out12, int reset) {
-  return guarded([&] {
-    if (!h) fail("null handle");
-    MH_HIP(hipSetDevice(h->device));
-    if (!h->prof_dev) {
-      MH_HIP(hipMalloc(reinterpret_cast<void**>(&h->prof_dev), 12 * sizeof(unsigned long long)));
-      MH_HIP(hipMemset(h->prof_dev, 0, 12 * sizeof(unsigned long long)));
-    }
-    MH_HIP(hipDeviceSynchronize());
-    if (out12) MH_HIP(hipMemcpy(out12, h->prof_dev, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (reset) MH_HIP(hipMemset(h->prof_dev, 0, 12 * sizeof(unsigned long long)));
-  });
-}
-
 int64_t mimi_hip_domain_info(mimi_hip_domain_t h, int what) {
   if (!h) return -1;
   switch (what) {
@@ -947,6 +944,7 @@ int64_t mimi_hip_domain_info(mimi_hip_domain_t h, int what) {
   case 4: return h->n_vdofs;
   case 5: return h->path;
   case 6: return h->structured_csr ? 1 : (h->structured_perm ? 2 : 0);
+  case 7: return h->last_family;
   default: return -1;
   }
 }

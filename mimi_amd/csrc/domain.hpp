@@ -48,7 +48,6 @@ struct mimi_hip_domain_s {
   // status word raised by kernels (ScalarSolve failures, bad pattern)
   int* status_dev = nullptr;
   int* status_host = nullptr;  // pinned
-  unsigned long long* prof_dev = nullptr;  // MH_PROFILE builds only
   // mimi_hip_domain_set_phase_timing: events around phase 1 (integration kernels) and phase 2 (gather) of the last
   // two-phase assembly, on the launch stream
   bool phase_timing = false;
@@ -59,6 +58,10 @@ struct mimi_hip_domain_s {
   int phase_select = 0;
   int gather_begin[3] = {0, 0, 0}, gather_end[3] = {0, 0, 0};
   bool integrated = false;
+  // kernel family of the last assembly / state commit on this handle (mimi_hip_domain_info(h, 7)): 0 none yet,
+  // 1 two-phase tensor degree 2, 2 two-phase tensor degree 3, 3 small-element tensor kernel, 4 general kernels,
+  // 5 colour-partitioned tensor kernel
+  int last_family = 0;
 
   // staging for host-resident u / r / A
   mimi_hip::DeviceBuffer<double> stage_u, stage_r, stage_A;

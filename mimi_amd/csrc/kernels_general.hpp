@@ -213,7 +213,6 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int c = 0; c < DD; ++c) acc[mt][c] = mhg_d4{0.0, 0.0, 0.0, 0.0};
-#ifndef GEN_MF_EXP_SKIP_MFMA   // (timing experiments only)
     for (int q0 = 0; q0 < n_q; q0 += QC) {
       const int nqc = n_q - q0 < QC ? n_q - q0 : QC;
       GEN_SYNC();
@@ -247,12 +246,8 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
           }
       }
     }
-#endif
     const int32_t* pp_tab = p.pair_pos + (int64_t)e * n_dof * n_dof;
     const int b = 16 * nt + l16;
-#ifdef GEN_MF_EXP_SKIP_STORE
-    if (acc[0][0][0] == 123.456)
-#endif
     if (p.scratch_k) {
       // two-phase: the element block goes out densely, row (a, i) = 192 contiguous doubles [j][b] (16 lanes of an
       // accumulator register cover 128 contiguous bytes); general_gather_kernel

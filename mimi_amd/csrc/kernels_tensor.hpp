@@ -55,7 +55,6 @@ struct TensorArgs {
   MaterialDev mat;
   StateView state;
   int* status;
-  unsigned long long* prof;  // diagnostic build only (MH_PROFILE): per-stage cycle sums
   double* scratch_k;         // two-phase path: [n_el][3][27*81] element row pieces
   double* scratch_r;         // two-phase path: [n_el][3][27] element residual pieces
   double* scratch_pt;        // two-phase path, J2: [n_el][24][n_q] material results per quadrature point
@@ -87,20 +86,6 @@ struct TensorLds {
   static constexpr int total = off_cb + 3 * NB * n_carry;
 };
 
-#ifdef MH_PROFILE
-#define MH_STAMP(k)                                                         \
-  do {                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                      \
-    unsigned long long t_;                                                  \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-    prof_acc[k] += t_ - prof_last;                                          \
-    prof_last = t_;                                                         \
-    __builtin_amdgcn_sched_barrier(0);                                      \
-  } while (0)
-#else
-#define MH_STAMP(k)
-#endif
-
 template<int P>
 MH_DEV const double* tab_ptr(const double* tab, int dir, int isD) {
   return tab + ((dir * 2 + isD) * (P + 1)) * (P + 2);
@@ -130,11 +115,6 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
   // entries shared with the next element of the column are carried in LDS instead of being
   // written and re-read through memory (only when the walk axis is the third local direction)
   const bool use_carry = p.seq_axis == 2;
-#ifdef MH_PROFILE
-  unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long prof_last;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last)::"memory");
-#endif
 
   const int n_seq = p.seq_axis == 0 ? p.box_n[0] : (p.seq_axis == 1 ? p.box_n[1] : p.box_n[2]);
   auto element_of = [&](int es, int* el) -> int64_t {
@@ -192,7 +172,6 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
   }
 
   for (int es = 0; es < n_seq; ++es) {
-    MH_STAMP(0);
     // ---- stage 0: registers -> LDS, then issue the loads of the NEXT element -----------------
 #pragma unroll
     for (int rd = 0; rd < DROUNDS; ++rd) {
@@ -259,8 +238,6 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
       }
     }
     __builtin_amdgcn_wave_barrier();
-
-    MH_STAMP(1);
     // ---- stage A: constitutive update, lane = quadrature point ----------------------------
     double Phat[QROUNDS][3];
 #pragma unroll
@@ -352,8 +329,6 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
             }
       }
     }
-
-    MH_STAMP(2);
     // ---- stage R: residual row I by sum factorisation (scratch aliases ZB) ------------------
     {
       double* PH = ZB;                   // [3 m][NQ3]  (q = q0 + NQ q1 + NQ^2 q2)
@@ -410,8 +385,6 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
       }
       __builtin_amdgcn_wave_barrier();
     }
-
-    MH_STAMP(3);
     if constexpr (GRAD == 1) {
       // ---- issue the loads of this element's CSR entries now (3 contiguous values per node
       // pair: j = 0..2); they are consumed after the contractions.  The entries touched by
@@ -433,15 +406,12 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
           dstp[rd][a0] = (act && !carried) ? p.A + rs[a] + ppv[rd][a0] : nullptr;
         }
       }
-#ifndef MH_ABL_NOSCATTER
 #pragma unroll
       for (int rd = 0; rd < S3R; ++rd)
 #pragma unroll
         for (int a0 = 0; a0 < NB; ++a0)
 #pragma unroll
           for (int jj = 0; jj < 3; ++jj) old[rd][a0][jj] = dstp[rd][a0] ? dstp[rd][a0][jj] : 0.0;
-#endif
-      MH_STAMP(4);
 #pragma unroll 1
       for (int j = 0; j < 3; ++j) {
         const double* AHj = AH + j * 9 * NQ3;
@@ -455,11 +425,7 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
           // ---- S1+S2: lane = (q0, a2 b2); contract q2 then q1 ------------------------------
-#ifdef MH_ABL_NOS12
-          for (int t = lane; t < 0; t += 64) {
-#else
           for (int t = lane; t < NB2 * NQ; t += 64) {
-#endif
             const int q0 = t % NQ, ab2 = t / NQ, a2 = ab2 / NB, b2 = ab2 % NB;
             double tt2[4][NQ];  // BB, DB (m==2), BD (n==2), DD
 #pragma unroll
@@ -558,14 +524,9 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
               }
           }
           __builtin_amdgcn_wave_barrier();
-          MH_STAMP(5);
           // ---- S3 partial: lane = (b0, c):  K[a0] += T0a[a0] (B0[b0] Z_h0 + D0[b0] Z_h1) ----------
-#ifdef MH_ABL_NOS3
-          for (int rd = 0; rd < 0; ++rd) {
-#else
 #pragma unroll
           for (int rd = 0; rd < S3R; ++rd) {
-#endif
             const int t = rd * 64 + lane;
             const int tt = t < NB * NC ? t : 0;
             const int b0 = tt % NB, c = tt / NB;
@@ -578,7 +539,6 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
             }
           }
           __builtin_amdgcn_wave_barrier();
-          MH_STAMP(6);
         }
         if (use_carry) {
           // incoming: the previous element's (a2+1, b2+1) entries are this element's (a2, b2)
@@ -611,7 +571,6 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
           }
           __builtin_amdgcn_wave_barrier();
         }
-        MH_STAMP(7);
         // keep the block in registers without dynamic indexing (the j loop stays rolled)
 #pragma unroll
         for (int rd = 0; rd < S3R; ++rd)
@@ -620,9 +579,7 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj) Kv[jj][rd][a0] = (jj == j) ? Kt[rd][a0] : Kv[jj][rd][a0];
       }
-      MH_STAMP(8);
       // ---- CSR read-modify-write: adds and stores
-#ifndef MH_ABL_NOSCATTER
 #pragma unroll
       for (int rd = 0; rd < S3R; ++rd)
 #pragma unroll
@@ -631,23 +588,8 @@ MH_DEV void tensor_wave_body(const TensorArgs& p, double* lds, int eu, int ev, i
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj) dstp[rd][a0][jj] = old[rd][a0][jj] + p.grad_factor * Kv[jj][rd][a0];
           }
-#else
-      {
-        double sink = 0.0;
-#pragma unroll
-        for (int rd = 0; rd < S3R; ++rd)
-#pragma unroll
-          for (int a0 = 0; a0 < NB; ++a0) sink += Kv[0][rd][a0] + Kv[1][rd][a0] + Kv[2][rd][a0] + (double)(size_t)dstp[rd][a0];
-        if (sink == 1.2345e-300) p.A[0] = sink;
-      }
-#endif
     }
-    MH_STAMP(9);
   }
-#ifdef MH_PROFILE
-  if (lane == 0 && p.prof)
-    for (int k = 0; k < 12; ++k) atomicAdd(&p.prof[k], prof_acc[k]);
-#endif
 }
 
 template<int P, int GRAD>
@@ -780,7 +722,6 @@ inline TensorArgs tensor_args(mimi_hip_domain_s* h, const double* u, double* r, 
   a.mat = h->mat;
   a.state = StateView{h->eqps.ptr, h->temperature.ptr, h->plastic_strain.ptr, h->n_pts, h->state2.ptr};
   a.status = h->status_dev;
-  a.prof = h->prof_dev;
   a.perm = h->structured_perm ? h->node_ids.ptr : nullptr;
   a.nbr_pos = h->structured_perm ? h->nbr_pos.ptr : nullptr;
   a.nbr_pos16 = h->structured_perm ? h->nbr_pos16.ptr : nullptr;

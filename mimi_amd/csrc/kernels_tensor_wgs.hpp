@@ -893,16 +893,7 @@ MH_DEV void wgs_y_loop(const TensorArgs& p, double* lds, int eu, int ev) {
   }
 }
 
-#ifdef WGS_EXP_SKIP_Y
-template<int I>
-MH_DEV void wgs_y_skip(const TensorArgs& p) {
-  for (int it = 0; it < 2 * p.box_n[2] + 1; ++it) wgs_barrier();
-}
-#define wgs_y_loop wgs_y_skip
-#define WGS_Y_ARGS p
-#else
 #define WGS_Y_ARGS p, smem_wgs, eu, ev
-#endif
 
 // Two workgroups per CU (256 registers per wave) for both materials.
 template<int KIND>
@@ -918,11 +909,7 @@ __global__ __launch_bounds__(256, 2) void tensor_wgs_kernel(TensorArgs p) {
   const int eu = unit % p.box_n[0], ev = unit / p.box_n[0];
   if (role == 0) {
     int status = 0;
-#ifdef WGS_EXP_SKIP_X
-    for (int it = 0; it < 2 * p.box_n[2] + 1; ++it) wgs_barrier();
-#else
     wgs_x_loop<KIND>(p, smem_wgs, eu, ev, status);
-#endif
     if (status) atomicOr(p.status, status);
   } else if (role == 1) {
     wgs_y_loop<0>(WGS_Y_ARGS);

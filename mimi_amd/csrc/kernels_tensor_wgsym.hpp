@@ -359,23 +359,14 @@ __global__ __launch_bounds__(256, 2) void tensor_wgsym_kernel(TensorArgs p) {
   const int n_cols_all = p.box_n[0] * p.box_n[1] * (p.box_n[2] / p.seg_len);   // units
   const int col0 = blockIdx.x * p.cols_per_wg;
   const int n_cols = n_cols_all - col0 < p.cols_per_wg ? n_cols_all - col0 : p.cols_per_wg;
-  // (WGSYM_EXP_SKIP_X / _Y: timing experiments only — the skipped role just keeps the barrier count)
   if (role == 0) {
     int status = 0;
-#ifdef WGSYM_EXP_SKIP_X
-    for (int k = 0; k < 2 * n_cols * p.seg_len + 1; ++k) wgs_barrier();
-#else
     wgsym_x_loop<KIND>(p, smem_wgsym, col0, n_cols, status);
-#endif
     if (status) atomicOr(p.status, status);
   } else {
-#ifdef WGSYM_EXP_SKIP_Y
-    for (int k = 0; k < 2 * n_cols * p.seg_len + 1; ++k) wgs_barrier();
-#else
     if (role == 1) wgsym_y_loop<0>(p, smem_wgsym, col0, n_cols);
     else if (role == 2) wgsym_y_loop<1>(p, smem_wgsym, col0, n_cols);
     else wgsym_y_loop<2>(p, smem_wgsym, col0, n_cols);
-#endif
   }
 }
 

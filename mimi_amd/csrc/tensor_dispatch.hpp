@@ -18,11 +18,12 @@ inline bool tensor_usable(const mimi_hip_domain_s* h) {
   return h->path == 1 && (tensor_small_shape(h->dim, h->degree, h->nq1[0]) || h->degree[0] != 3 || tensor_p3_ready(h));
 }
 
-inline void launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, double* r, double* A, double gf) {
+// returns the kernel family that ran (mimi_hip_domain_s::last_family)
+inline int launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, double* r, double* A, double gf) {
   TensorArgs a = tensor_args(h, u, r, A, gf);
   if (h->degree[0] == 3) {
     launch_tensor_p3(h, grad, a);
-    return;
+    return 2;
   }
   // MIMI_HIP_TENSOR_VARIANT: default when supported = two-phase with role-specialised workgroups, the
   // symmetric-half kernel for hyperelastic materials; "wgs" forces the full nine-block kernel,
@@ -43,7 +44,9 @@ inline void launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, doubl
       a.pair_pos = h->pair_pos.ptr;
     }
     launch_tensor_p<2>(h, grad, a);
+    return 5;
   }
+  return 1;
 }
 
 inline void launch_tensor_post(mimi_hip_domain_s* h, const double* u) {

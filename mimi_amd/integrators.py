@@ -221,6 +221,13 @@ class NonlinearSolid(NonlinearBase):
         raise RuntimeError("Currently not implemented, use AddDomainResidualAndGrad")  # nonlinear_solid.hpp:108-113
 
     # -- material state (MaterialState, materials.hpp:278-286) --------------------------
+    KERNEL_FAMILIES = {0: "none", 1: "tensor_p2_two_phase", 2: "tensor_p3_two_phase", 3: "tensor_small", 4: "general",
+                       5: "tensor_colour"}
+
+    def LastKernelFamily(self):
+        """which kernel family the last assembly on this handle ran on (tests assert it; see mimi_hip_domain_info)"""
+        return self.KERNEL_FAMILIES[int(_capi.lib().mimi_hip_domain_info(self._handle(), 7))]
+
     def State(self, what):
         # "plastic_strain" = the material's first state matrix (J2 / J2Linear: plastic strain, J2Simo: be_old, J2Log:
         # Fp_inv); "state2" = its second one (J2Linear: beta, J2Simo: F_old)

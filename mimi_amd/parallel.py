@@ -144,6 +144,7 @@ class InterfaceExchange:
             raise ValueError(mode)
         self.torch, self.dist = torch, dist
         self.shard, self.r, self.A, self.mode = shard, r, A, mode
+        self.loopback = bool(loopback)
         device = r.device if device is None else device
         rowptr = shard.pattern.rowptr
         if not isinstance(rowptr, torch.Tensor):
@@ -280,6 +281,7 @@ class InterfaceExchange:
         torch, dist = self.torch, self.dist
         staged = self.r.is_cuda and dist.get_backend() == "gloo"
         ops = []
+        sizes = []
         for s in self.sides:
             ns, nr = s["srows"].numel(), s["rrows"].numel()
             n_send = ns + (s["sidx"].numel() if with_grad else 0)
@@ -290,20 +292,35 @@ class InterfaceExchange:
                 torch.index_select(self.r, 0, s["srows"], out=s["send"][:ns])
                 if with_grad:
                     torch.index_select(self.A, 0, s["sidx"], out=s["send"][ns:n_send])
+            sizes.append((n_send, n_recv))
             if staged:
                 # gloo moves host memory only: stage device buffers through the host (test rigs without RCCL)
                 s["send_host"] = s["send"][:n_send].cpu()
                 s["recv_host"] = torch.empty(n_recv, dtype=self.r.dtype)
-                if n_send:
-                    ops.append(dist.P2POp(dist.isend, s["send_host"], s["peer"]))
-                if n_recv:
-                    ops.append(dist.P2POp(dist.irecv, s["recv_host"], s["peer"]))
-                continue
-            if n_send:
-                ops.append(dist.P2POp(dist.isend, s["send"][:n_send], s["peer"]))
-            if n_recv:
-                ops.append(dist.P2POp(dist.irecv, s["recv"][:n_recv], s["peer"]))
+                send_buf, recv_buf = s["send_host"], s["recv_host"]
+            else:
+                send_buf, recv_buf = s["send"][:n_send], s["recv"][:n_recv]
+            ops.append((dist.P2POp(dist.isend, send_buf, s["peer"]) if n_send else None,
+                        dist.P2POp(dist.irecv, recv_buf, s["peer"]) if n_recv else None))
+        if self.loopback:
+            # messages to oneself are matched in issue order: a side's send must meet a receive of the SAME length
+            pairs = self.loopback_pairs(with_grad)
+            ops = [(ops[i][0], ops[j][1]) for i, j in pairs]
+        ops = [op for pair in ops for op in pair if op is not None]
         self._pending = (dist.batch_isend_irecv(ops) if ops else [], staged, with_grad)
+
+    def loopback_pairs(self, with_grad=True):
+        """loop-back only: [(i, j)] = the message side i sends arrives in the receive buffer of side j.  Both neighbours
+        being this rank itself, a send can only meet a receive of its own length: side i's own when they agree; in owner
+        mode at odd degree a side sends p // 2 planes and receives p - p // 2 (or the reverse), and the send of one side
+        is paired with the receive of the OTHER side, which has its plane count.  Raises when nothing pairs."""
+        sizes = [(s["srows"].numel() + (s["sidx"].numel() if with_grad else 0),
+                  s["rrows"].numel() + (s["ridx"].numel() if with_grad else 0)) for s in self.sides]
+        if all(ns == nr for ns, nr in sizes):
+            return [(i, i) for i in range(len(sizes))]
+        if len(sizes) == 2 and sizes[0][0] == sizes[1][1] and sizes[1][0] == sizes[0][1]:
+            return [(0, 1), (1, 0)]
+        raise RuntimeError(f"loop-back exchange: send / receive lengths {sizes} cannot be paired on one rank")
 
     def finish(self):
         """Wait for the neighbours' rows and add them into the rows this rank owns."""

@@ -14,43 +14,78 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 MESH = os.path.join(HERE, "golden", "meshes", "balken.mesh")
 
 
-def balken(subd, order):
+# The inputs that DEFINE the golden fixtures (the reference's tests/test_nonlinear_solid.py sets the same
+# numbers): kept as data, applied by one generic builder.
+JOHNSON_COOK = dict(A=70, B=140, n=0.2835, m=1.3558, eps0_dot=0.004, reference_temperature=20)
+THERMAL = dict(melting_temperature=1500, initial_temperature=20, specific_heat=450, heat_fraction=0.9)
+GOLDEN_CASES = {
+    # name: material class, extra material attributes, hardening, body force, dt, fixture directory
+    "neohook": dict(material="CompressibleOgdenNeoHookean", attrs={}, hardening=None, body_force=(1, -5), dt=0.05,
+                    refdir="neohook_h1_p2"),
+    "j2": dict(material="J2", attrs=THERMAL, hardening=JOHNSON_COOK, body_force=(1, -3), dt=0.5, refdir="j2_h1_p2"),
+    "j2_simo": dict(material="J2Simo", attrs=THERMAL, hardening=JOHNSON_COOK, body_force=(1, -3), dt=0.5,
+                    refdir="j2_simo_h1_p2"),
+    "j2_log": dict(material="J2Log", attrs=THERMAL, hardening=JOHNSON_COOK, body_force=(1, -3), dt=0.5,
+                   refdir="j2_log_h1_p2"),
+}
+BEAM = dict(mesh=MESH, elevate=2, subdivide=1, young=2100, poisson=0.3, density=1, viscosity=-1, ode_coefficient=0.5,
+            clamped=[(2, 0), (2, 1)], newton=("nonlinear_solid", 1e-12, 1e-8, 10, False))
+
+
+def beam(case=None, elevate=BEAM["elevate"], subdivide=BEAM["subdivide"], viscosity=BEAM["viscosity"], runtime=(),
+         tangent_mode=0, finish=True):
+    """the facade object of a golden case: mesh, refinement, material, runtime flags, boundary conditions, setup"""
     import mimi_amd as mimi
     nl = mimi.NonlinearSolid()
-    nl.read_mesh(MESH)
-    if order > 0:
-        nl.elevate_degrees(order)
-    if subd > 0:
-        nl.subdivide(subd)
-    return nl
-
-
-def balken_plasticity(subd, order, mat):
-    import mimi_amd as mimi
-    nl = balken(subd, order)
-    mat.density = 1
-    mat.viscosity = -1
-    mat.melting_temperature = 1500
-    mat.initial_temperature = 20
-    mat.specific_heat = 450
-    mat.heat_fraction = 0.9
-    mat.set_young_poisson(2100, 0.3)
-    mat.hardening = mimi.JohnsonCookTemperatureAndRateDependentHardening()
-    mat.hardening.A = 70
-    mat.hardening.B = 140
-    mat.hardening.n = 0.2835
-    mat.hardening.m = 1.3558
-    mat.hardening.eps0_dot = 0.004
-    mat.hardening.reference_temperature = 20
+    nl.read_mesh(BEAM["mesh"])
+    if elevate > 0:
+        nl.elevate_degrees(elevate)
+    if subdivide > 0:
+        nl.subdivide(subdivide)
+    if case is None:
+        return nl
+    c = GOLDEN_CASES[case]
+    mat = getattr(mimi, c["material"])()
+    for k, v in dict(density=BEAM["density"], viscosity=viscosity, **c["attrs"]).items():
+        setattr(mat, k, v)
+    mat.set_young_poisson(BEAM["young"], BEAM["poisson"])
+    if c["hardening"]:
+        mat.hardening = mimi.JohnsonCookTemperatureAndRateDependentHardening()
+        for k, v in c["hardening"].items():
+            setattr(mat.hardening, k, v)
     nl.set_material(mat)
     rc = mimi.RuntimeCommunication()
-    rc.set_real("ode_coefficient", 0.5)
+    rc.set_real("ode_coefficient", BEAM["ode_coefficient"])
+    for k, v in runtime:
+        rc.set_int(k, v)
     nl.runtime_communication = rc
     bc = mimi.BoundaryConditions()
-    bc.initial.dirichlet(2, 0).dirichlet(2, 1)
-    bc.initial.body_force(1, -3)
+    for bid, comp in BEAM["clamped"]:
+        bc.initial.dirichlet(bid, comp)
+    bc.initial.body_force(*c["body_force"])
     nl.boundary_condition = bc
+    if finish:
+        nl.tangent_mode = tangent_mode
+        nl.setup(1)
+        nl.configure_newton(*BEAM["newton"])
+        nl.time_step_size = c["dt"]
     return nl
+
+
+def follow_golden_series(nl, case, golden_dir, tol=1e-8):
+    from oracle import harness as hz
+    u = nl.solution_view("displacement", "x").ravel()
+    for i in range(10):
+        nl.step_time2()
+        ref = hz.golden_to_lexicographic(np.genfromtxt(os.path.join(golden_dir, "ref", GOLDEN_CASES[case]["refdir"], f"x_{i}.txt")))
+        assert np.allclose(u, ref)                     # the reference's criterion
+        if tol:
+            assert np.abs(u - ref).max() < tol, (i, np.abs(u - ref).max())
+
+
+# which kernels a golden series runs on (DESIGN 4.3): analytic tangent -> the sum-factorised small-element tensor kernel,
+# reference-FD tangent -> the general kernels
+FAMILY_OF_MODE = {0: "tensor_small", 1: "general"}
 
 
 def test_mesh_counts_cpu():
@@ -73,104 +108,27 @@ def test_mesh_counts_cpu():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tangent_mode", [0, 1], ids=["analytic", "referenceFD"])
-def test_nonlinear_solid_neohook(golden_dir, tangent_mode):
-    import mimi_amd as mimi
-    from oracle import harness as hz
-    nl = balken(1, 2)
-    mat = mimi.CompressibleOgdenNeoHookean()
-    mat.density = 1
-    mat.viscosity = -1
-    mat.set_young_poisson(2100, 0.3)
-    nl.set_material(mat)
-    rc = mimi.RuntimeCommunication()
-    rc.set_real("ode_coefficient", 0.5)
-    nl.runtime_communication = rc
-    bc = mimi.BoundaryConditions()
-    bc.initial.dirichlet(2, 0).dirichlet(2, 1)
-    bc.initial.body_force(1, -5)
-    nl.boundary_condition = bc
-    nl.tangent_mode = tangent_mode
-    nl.setup(1)
-    nl.configure_newton("nonlinear_solid", 1e-12, 1e-8, 10, False)
-    nl.time_step_size = 0.05
-    u = nl.solution_view("displacement", "x").ravel()
-    for i in range(10):
-        nl.step_time2()
-        ref = hz.golden_to_lexicographic(np.genfromtxt(os.path.join(golden_dir, "ref", "neohook_h1_p2", f"x_{i}.txt")))
-        assert np.allclose(u, ref)
-        assert np.abs(u - ref).max() < 1e-8, (i, np.abs(u - ref).max())
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("tangent_mode", [0, 1], ids=["analytic", "referenceFD"])
-def test_nonlinear_solid_j2(golden_dir, tangent_mode):
-    import mimi_amd as mimi
-    from oracle import harness as hz
-    nl = balken_plasticity(1, 2, mimi.J2())
-    nl.tangent_mode = tangent_mode
-    nl.setup(1)
-    nl.configure_newton("nonlinear_solid", 1e-12, 1e-8, 10, False)
-    nl.time_step_size = 0.5
-    u = nl.solution_view("displacement", "x").ravel()
-    for i in range(10):
-        nl.step_time2()
-        ref = hz.golden_to_lexicographic(np.genfromtxt(os.path.join(golden_dir, "ref", "j2_h1_p2", f"x_{i}.txt")))
-        assert np.allclose(u, ref)
-        assert np.abs(u - ref).max() < 1e-8, (i, np.abs(u - ref).max())
-    assert nl.domain_.State("accumulated_plastic_strain").max() > 0.05
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("tangent_mode", [0, 1], ids=["analytic", "referenceFD"])
-@pytest.mark.parametrize("matname,refdir", [("J2Simo", "j2_simo_h1_p2"), ("J2Log", "j2_log_h1_p2")])
-def test_nonlinear_solid_j2_simo_and_log(golden_dir, matname, refdir, tangent_mode):
-    """reference tests/test_nonlinear_solid.py:100-114: the finite-strain plasticity series through the HIP integrators"""
-    import mimi_amd as mimi
-    from oracle import harness as hz
-    nl = balken_plasticity(1, 2, getattr(mimi, matname)())
-    nl.tangent_mode = tangent_mode
-    nl.setup(1)
-    nl.configure_newton("nonlinear_solid", 1e-12, 1e-8, 10, False)
-    nl.time_step_size = 0.5
-    u = nl.solution_view("displacement", "x").ravel()
-    for i in range(10):
-        nl.step_time2()
-        ref = hz.golden_to_lexicographic(np.genfromtxt(os.path.join(golden_dir, "ref", refdir, f"x_{i}.txt")))
-        assert np.allclose(u, ref)
-        assert np.abs(u - ref).max() < 1e-8, (i, np.abs(u - ref).max())
-    assert nl.domain_.State("accumulated_plastic_strain").max() > 0.05
+@pytest.mark.parametrize("case", sorted(GOLDEN_CASES))
+def test_nonlinear_solid_golden_series(golden_dir, case, tangent_mode):
+    """reference tests/test_nonlinear_solid.py:55-114: the four golden series through the HIP integrators, on the kernel
+    family DESIGN 4.3 names for each tangent mode"""
+    nl = beam(case, tangent_mode=tangent_mode)
+    assert nl.domain_.path_ == 1
+    follow_golden_series(nl, case, golden_dir)
+    assert nl.domain_.LastKernelFamily() == FAMILY_OF_MODE[tangent_mode]
+    if GOLDEN_CASES[case]["hardening"]:
+        assert nl.domain_.State("accumulated_plastic_strain").max() > 0.05
 
 
 @pytest.mark.gpu
 def test_nonlinear_solid_neohook_iterative_solver(golden_dir):
     """the reference's "use_iterative_solver" route (py_nonlinear_solid.cpp:329-339): GMRES + Jacobi, here on the device;
     the golden series is reached through inexact Newton steps as well"""
-    import mimi_amd as mimi
-    from oracle import harness as hz
-    nl = balken(1, 2)
-    mat = mimi.CompressibleOgdenNeoHookean()
-    mat.density = 1
-    mat.viscosity = -1
-    mat.set_young_poisson(2100, 0.3)
-    nl.set_material(mat)
-    rc = mimi.RuntimeCommunication()
-    rc.set_real("ode_coefficient", 0.5)
-    rc.set_int("use_iterative_solver", 1)
-    nl.runtime_communication = rc
-    bc = mimi.BoundaryConditions()
-    bc.initial.dirichlet(2, 0).dirichlet(2, 1)
-    bc.initial.body_force(1, -5)
-    nl.boundary_condition = bc
-    nl.setup(1)
+    nl = beam("neohook", runtime=[("use_iterative_solver", 1)])
     assert nl.use_iterative_solver_
-    nl.configure_newton("nonlinear_solid", 1e-12, 1e-8, 10, False)
-    nl.time_step_size = 0.05
-    u = nl.solution_view("displacement", "x").ravel()
-    for i in range(10):
-        nl.step_time2()
-        ref = hz.golden_to_lexicographic(np.genfromtxt(os.path.join(golden_dir, "ref", "neohook_h1_p2", f"x_{i}.txt")))
-        assert np.allclose(u, ref)
+    follow_golden_series(nl, "neohook", golden_dir, tol=None)
     assert nl.linear_.final_iter_ > 1
+    assert nl.domain_.LastKernelFamily() == "tensor_small"
 
 
 @pytest.mark.gpu
@@ -272,7 +230,7 @@ def test_contact_with_rigid_spline_through_the_facade():
     pressed into the top edge of the beam by its own penalty; the steps converge and the contact carries load."""
     import types
     import mimi_amd as mimi
-    nl = balken(2, 1)
+    nl = beam(elevate=1, subdivide=2)
     mat = mimi.CompressibleOgdenNeoHookean()
     mat.density = 1
     mat.viscosity = -1
@@ -329,22 +287,7 @@ def test_viscosity_term():
     from _cases import oracle_material
     series = {}
     for nu in (-1.0, 40.0):
-        nl = balken(1, 2)
-        mat = mimi.CompressibleOgdenNeoHookean()
-        mat.density = 1
-        mat.viscosity = nu
-        mat.set_young_poisson(2100, 0.3)
-        nl.set_material(mat)
-        rc = mimi.RuntimeCommunication()
-        rc.set_real("ode_coefficient", 0.5)
-        nl.runtime_communication = rc
-        bc = mimi.BoundaryConditions()
-        bc.initial.dirichlet(2, 0).dirichlet(2, 1)
-        bc.initial.body_force(1, -5)
-        nl.boundary_condition = bc
-        nl.setup(1)
-        nl.configure_newton("nonlinear_solid", 1e-12, 1e-8, 10, False)
-        nl.time_step_size = 0.05
+        nl = beam("neohook", viscosity=nu)
         out = []
         for _ in range(4):
             nl.step_time2()

@@ -224,3 +224,37 @@ def test_gather_windows_partition_the_slab_nodes():
         if rank < world - 1:
             sent += list(range(e0 + (0 if mode == "replicate" else p // 2), e0 + p))
         assert sorted(x for b, e in early for x in range(b[2], e[2])) == sent
+
+
+@pytest.mark.parametrize("p,mode,expect", [(2, "owner", [(0, 0), (1, 1)]), (3, "replicate", [(0, 0), (1, 1)]),
+                                           (3, "owner", [(0, 1), (1, 0)])])
+def test_loopback_pairs_sends_with_receives_of_their_own_length(p, mode, expect, monkeypatch):
+    """in loop-back (a middle rank talking to itself, bench.py --rehearse-rccl) owner mode at odd degree
+    sends 1 plane and receives 2 on one side and the reverse on the other: a send must meet the OTHER side's receive."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import mimi_amd
+    from mimi_amd import parallel
+    from mimi_amd.integrators import CSRPattern
+    from oracle import iga
+    monkeypatch.setattr(dist, "get_rank", lambda *a, **k: 0)
+    n_el = (2, 2, 18)
+    P = iga.Patch.block(n_el, p)
+    rowptr, col = P.sparsity()
+    patch = mimi_amd.BSplinePatch.block(n_el, p)
+    shard = parallel.SlabShard(patch, CSRPattern(rowptr, col, rowptr[-1]), 1, 3)
+    ex = parallel.InterfaceExchange(shard, torch.zeros(P.n_vdofs, dtype=torch.float64),
+                                    torch.zeros(int(rowptr[-1]), dtype=torch.float64), mode=mode, loopback=True)
+    pairs = ex.loopback_pairs()
+    assert pairs == expect
+    for i, j in pairs:
+        assert ex.sides[i]["srows"].numel() == ex.sides[j]["rrows"].numel()
+        assert ex.sides[i]["sidx"].numel() == ex.sides[j]["ridx"].numel()
+    # an end rank in owner mode at odd degree has one side whose lengths differ: nothing to pair it with
+    if (p, mode) == (3, "owner"):
+        end = parallel.SlabShard(patch, CSRPattern(rowptr, col, rowptr[-1]), 0, 3)
+        ex0 = parallel.InterfaceExchange(end, torch.zeros(P.n_vdofs, dtype=torch.float64),
+                                         torch.zeros(int(rowptr[-1]), dtype=torch.float64), mode=mode, loopback=True)
+        with pytest.raises(RuntimeError, match="cannot be paired"):
+            ex0.loopback_pairs()

@@ -108,10 +108,11 @@ def _worker(port, n_el, p, fake_rank, fake_world, mode, scheme, q):
             return torch.repeat_interleave(start - offs, length) + torch.arange(int(length.sum()), device=dev)
 
         r_exp, A_exp = r1.clone(), A1.clone()
-        for s in ex.sides:
-            assert s["peer"] == 0 and s["srows"].numel() == s["rrows"].numel() and s["sidx"].numel() == s["ridx"].numel()
-            r_exp.index_add_(0, s["rrows"], r1[s["srows"]])
-            A_exp.index_add_(0, positions(s["rrows"]), A1[positions(s["srows"])])
+        for i, j in ex.loopback_pairs():           # side i's message lands in side j's receive buffer (same length)
+            s, t = ex.sides[i], ex.sides[j]
+            assert s["peer"] == 0 and s["srows"].numel() == t["rrows"].numel() and s["sidx"].numel() == t["ridx"].numel()
+            r_exp.index_add_(0, t["rrows"], r1[s["srows"]])
+            A_exp.index_add_(0, positions(t["rrows"]), A1[positions(s["srows"])])
         shared_rows = torch.cat([s["rrows"] for s in ex.sides])
         shared_idx = positions(shared_rows)
         er = float((r[shared_rows] - r_exp[shared_rows]).abs().max() / r1.abs().max())
@@ -128,7 +129,9 @@ def _worker(port, n_el, p, fake_rank, fake_world, mode, scheme, q):
 
 @pytest.mark.parametrize("scheme", ["boundary", "gather"])
 @pytest.mark.parametrize("n_el,p,fake_rank,fake_world,mode", [((4, 4, 18), 2, 1, 3, "replicate"), ((4, 4, 12), 2, 0, 2, "owner"),
-                                                               ((3, 3, 24), 3, 1, 3, "replicate")])
+                                                               ((3, 3, 24), 3, 1, 3, "replicate"),
+                                                               # owner mode at odd degree: a side sends 1 plane and receives 2
+                                                               ((3, 3, 24), 3, 1, 3, "owner")])
 def test_interface_exchange_over_rccl_loopback(n_el, p, fake_rank, fake_world, mode, scheme):
     import torch.multiprocessing as mp
     import socket
