@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MIMI_HIP_ABI_VERSION 9
+#define MIMI_HIP_ABI_VERSION 10
 
 /* ---- errors ---------------------------------------------------------------- */
 const char* mimi_hip_last_error(void);
@@ -185,6 +185,9 @@ int mimi_hip_domain_gather(mimi_hip_domain_t h, double grad_factor, double* r, d
  * call when on). */
 int mimi_hip_domain_set_phase_timing(mimi_hip_domain_t h, int on);
 int mimi_hip_domain_phase_ms(mimi_hip_domain_t h, double* phase1_ms, double* phase2_ms);
+/* the same with phase 1 split at the end of its material pre-pass (0 when the path has none): pre-pass, integration /
+ * contraction kernel, row gather */
+int mimi_hip_domain_phase_ms_detail(mimi_hip_domain_t h, double* prepass_ms, double* integration_ms, double* gather_ms);
 /* sizes: what = 0 n_elements, 1 n_quad, 2 n_dof, 3 nnz, 4 n_vdofs, 5 path (0 general, 1 tensor), 6 CSR kind (0 any,
  * 1 structured lexicographic, 2 structured permuted), 7 kernel family of the last assembly on the handle (0 none yet,
  * 1 two-phase tensor degree 2, 2 two-phase tensor degree 3, 3 small-element tensor, 4 general, 5 colour tensor) */

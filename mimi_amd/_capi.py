@@ -66,7 +66,7 @@ EXPORTS = [
     "mimi_hip_domain_synchronize", "mimi_hip_domain_add_residual",
     "mimi_hip_domain_add_residual_and_grad", "mimi_hip_domain_post_time_advance",
     "mimi_hip_domain_get_state", "mimi_hip_domain_reset_state", "mimi_hip_domain_info",
-    "mimi_hip_domain_set_phase_timing", "mimi_hip_domain_phase_ms",
+    "mimi_hip_domain_set_phase_timing", "mimi_hip_domain_phase_ms", "mimi_hip_domain_phase_ms_detail",
     "mimi_hip_bspline_sparsity", "mimi_hip_bspline_sparsity_rows",
     "mimi_hip_contact_create", "mimi_hip_contact_destroy", "mimi_hip_contact_set_tangent_mode",
     "mimi_hip_contact_set_stream", "mimi_hip_contact_synchronize", "mimi_hip_contact_add_residual",
@@ -138,6 +138,7 @@ def lib():
     L.mimi_hip_domain_reset_state.argtypes = [C.c_void_p]
     L.mimi_hip_domain_set_phase_timing.argtypes = [C.c_void_p, C.c_int]
     L.mimi_hip_domain_phase_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mimi_hip_domain_phase_ms_detail.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mimi_hip_domain_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.mimi_hip_domain_create_bspline.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.mimi_hip_bspline_sparsity.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -926,6 +926,26 @@ int mimi_hip_domain_phase_ms(mimi_hip_domain_t h, double* phase1_ms, double* pha
   });
 }
 
+int mimi_hip_domain_phase_ms_detail(mimi_hip_domain_t h, double* prepass_ms, double* integration_ms, double* gather_ms) {
+  return guarded([&] {
+    if (!h || !prepass_ms || !integration_ms || !gather_ms) fail("null argument");
+    if (!h->phase_timing) fail("phase timing is off (mimi_hip_domain_set_phase_timing)");
+    MH_HIP(hipSetDevice(h->device));
+    MH_HIP(hipEventSynchronize(h->phase_ev[2]));
+    float a = 0.f, b = 0.f, c = 0.f;
+    if (h->phase_has_prepass) {
+      MH_HIP(hipEventElapsedTime(&a, h->phase_ev[0], h->phase_ev[3]));
+      MH_HIP(hipEventElapsedTime(&b, h->phase_ev[3], h->phase_ev[1]));
+    } else {
+      MH_HIP(hipEventElapsedTime(&b, h->phase_ev[0], h->phase_ev[1]));
+    }
+    MH_HIP(hipEventElapsedTime(&c, h->phase_ev[1], h->phase_ev[2]));
+    *prepass_ms = a;
+    *integration_ms = b;
+    *gather_ms = c;
+  });
+}
+
 int mimi_hip_domain_reset_state(mimi_hip_domain_t h) {
   return guarded([&] {
     if (!h) fail("null handle");

@@ -51,7 +51,8 @@ struct mimi_hip_domain_s {
   // mimi_hip_domain_set_phase_timing: events around phase 1 (integration kernels) and phase 2 (gather) of the last
   // two-phase assembly, on the launch stream
   bool phase_timing = false;
-  hipEvent_t phase_ev[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t phase_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [3]: end of the material pre-pass, when there is one
+  bool phase_has_prepass = false;
 
   // mimi_hip_domain_integrate / _gather: 0 = an assembly runs both phases, 1 = phase 1 only, 2 = phase 2 only, over the
   // node window [gather_begin, gather_end)

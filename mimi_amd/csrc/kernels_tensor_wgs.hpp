@@ -940,6 +940,8 @@ inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a) {
       MH_HIP(hipGetLastError());
     }
   }
+  h->phase_has_prepass = kind != MIMI_HIP_MAT_NEOHOOKEAN;
+  if (h->phase_timing && h->phase_has_prepass) MH_HIP(hipEventRecord(h->phase_ev[3], h->stream));
   auto kernel = kind == MIMI_HIP_MAT_NEOHOOKEAN ? tensor_wgs_kernel<MIMI_HIP_MAT_NEOHOOKEAN>
                 : record ? tensor_wgs_kernel<WGS_KIND_RECORD> : tensor_wgs_kernel<MIMI_HIP_MAT_J2>;
   ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);

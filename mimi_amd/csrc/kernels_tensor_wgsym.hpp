@@ -389,6 +389,7 @@ inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a) {
   a.seg_len = a.box_n[2] / nseg;
   const int n_cols_all = a.box_n[0] * a.box_n[1] * nseg;
   a.cols_per_wg = n_cols_all / WGSYM_MIN_WGS < 1 ? 1 : (n_cols_all / WGSYM_MIN_WGS > WGSYM_MAX_COLS ? WGSYM_MAX_COLS : n_cols_all / WGSYM_MIN_WGS);
+  h->phase_has_prepass = false;
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[0], h->stream));
   if (h->phase_select != 2) {
     hipLaunchKernelGGL(kernel, dim3((n_cols_all + a.cols_per_wg - 1) / a.cols_per_wg), dim3(256), lds, h->stream, a);

@@ -248,6 +248,12 @@ class NonlinearSolid(NonlinearBase):
         check(_capi.lib().mimi_hip_domain_phase_ms(self._handle(), C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def PhaseMsDetail(self):
+        """(material pre-pass, integration / contraction kernel, row gather) milliseconds of the last two-phase tangent assembly"""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        check(_capi.lib().mimi_hip_domain_phase_ms_detail(self._handle(), C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def ResetState(self):
         check(_capi.lib().mimi_hip_domain_reset_state(self._handle()))
 

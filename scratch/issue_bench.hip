@@ -1,0 +1,117 @@
+// Issue costs on one SIMD of gfx950, in shader cycles per instruction (s_memtime around an unrolled loop), with one
+// and with two waves per SIMD: fp64 vector instructions, the fp64 matrix instruction, and what can be issued in the
+// shadow of a matrix instruction (non-fp64 vector moves, accumulator-file reads, LDS reads, fp64 FMAs).
+// Build: hipcc --offload-arch=gfx950 -O3 -o issue_bench scratch/issue_bench.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ inline unsigned long long now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+
+// MODE: what the body holds.  NM matrix instructions, each followed by NF fillers of kind MODE.
+//  0: fp64 FMA (independent chains)   1: v_mov_b32 (non-fp64)   2: v_accvgpr_read   3: ds_read_b64   4: v_mul_f64   5: v_add_f64
+//  6: fp64 FMA, all fillers AFTER all matrix instructions (not interleaved)
+template<int MODE, int NM, int NF>
+__global__ void bench(unsigned long long* out, double* sink, int iters) {
+  __shared__ double lds[1024];
+  lds[threadIdx.x & 1023] = threadIdx.x;
+  __syncthreads();
+  d4 acc[4];
+  for (int k = 0; k < 4; ++k) acc[k] = d4{0, 0, 0, 0};
+  double f[16];
+  for (int k = 0; k < 16; ++k) f[k] = 1.0 + k * 1e-3 + threadIdx.x * 1e-6;
+  unsigned m[16];
+  for (int k = 0; k < 16; ++k) m[k] = k + threadIdx.x;
+  double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 2e-3;
+  const double c0 = 0.999, c1 = 1e-9;
+  const unsigned ldsaddr = (threadIdx.x & 63) * 8;
+  unsigned long long t0 = now();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+      if constexpr (MODE == 6) {
+#pragma unroll
+        for (int k = 0; k < NM; ++k)
+          asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[k & 3]) : "v"(a), "v"(b));
+#pragma unroll
+        for (int j = 0; j < NF * NM; ++j) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(f[j & 15]) : "v"(c0), "v"(c1));
+      } else {
+#pragma unroll
+        for (int k = 0; k < (NM ? NM : 1); ++k) {
+          if constexpr (NM > 0) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[k & 3]) : "v"(a), "v"(b));
+#pragma unroll
+          for (int j = 0; j < NF; ++j) {
+            const int q = (k * NF + j) & 15;
+            if constexpr (MODE == 0) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(f[q]) : "v"(c0), "v"(c1));
+            if constexpr (MODE == 1) asm volatile("v_mov_b32 %0, %1" : "=v"(m[q]) : "v"(m[(q + 1) & 15]));
+            if constexpr (MODE == 2) asm volatile("v_accvgpr_read_b32 %0, a0" : "=v"(m[q]));
+            if constexpr (MODE == 3) asm volatile("ds_read_b64 %0, %1" : "=v"(f[q]) : "v"(ldsaddr));
+            if constexpr (MODE == 4) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(f[q]) : "v"(c0));
+            if constexpr (MODE == 5) asm volatile("v_add_f64 %0, %0, %1" : "+v"(f[q]) : "v"(c1));
+          }
+        }
+      }
+    }
+    if constexpr (MODE == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  unsigned long long t1 = now();
+  double s = 0;
+  for (int k = 0; k < 4; ++k) s += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+  for (int k = 0; k < 16; ++k) s += f[k] + m[k];
+  if (s == 12345.678) sink[0] = s;
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+template<int MODE, int NM, int NF>
+static void run(const char* what, unsigned long long* d_out, double* d_sink) {
+  const int iters = 2000;
+  for (int threads : {256, 512}) {
+    const int blocks = 256, waves = blocks * threads / 64;
+    hipLaunchKernelGGL((bench<MODE, NM, NF>), dim3(blocks), dim3(threads), 0, 0, d_out, d_sink, 10);
+    hipLaunchKernelGGL((bench<MODE, NM, NF>), dim3(blocks), dim3(threads), 0, 0, d_out, d_sink, iters);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(waves);
+    CK(hipMemcpy(h.data(), d_out, waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::sort(h.begin(), h.end());
+    const double per_body = (double)h[waves / 2] / (iters * 4.0);
+    const int nm = NM ? NM : 1;
+    printf("%-44s %d wave(s)/SIMD: %8.1f cycles per body (%d mfma + %d fillers) = %6.2f per mfma-group, %6.2f per filler beyond 64/mfma\n",
+           what, threads / 256, per_body, NM, NF * nm, per_body / nm,
+           NF ? (per_body - 64.0 * NM) / (NF * nm) : 0.0);
+  }
+}
+
+int main() {
+  unsigned long long* d_out;
+  double* d_sink;
+  CK(hipMalloc(&d_out, 1 << 20));
+  CK(hipMalloc(&d_sink, 64));
+  run<0, 0, 16>("16 independent v_fma_f64", d_out, d_sink);
+  run<4, 0, 16>("16 independent v_mul_f64", d_out, d_sink);
+  run<5, 0, 16>("16 independent v_add_f64", d_out, d_sink);
+  run<1, 0, 16>("16 v_mov_b32", d_out, d_sink);
+  run<2, 0, 16>("16 v_accvgpr_read_b32", d_out, d_sink);
+  run<3, 0, 16>("16 ds_read_b64", d_out, d_sink);
+  run<0, 4, 0>("4 mfma_f64_16x16x4 alone", d_out, d_sink);
+  run<1, 4, 4>("mfma + 4 v_mov_b32 each", d_out, d_sink);
+  run<1, 4, 8>("mfma + 8 v_mov_b32 each", d_out, d_sink);
+  run<1, 4, 12>("mfma + 12 v_mov_b32 each", d_out, d_sink);
+  run<1, 4, 16>("mfma + 16 v_mov_b32 each", d_out, d_sink);
+  run<2, 4, 8>("mfma + 8 v_accvgpr_read each", d_out, d_sink);
+  run<2, 4, 12>("mfma + 12 v_accvgpr_read each", d_out, d_sink);
+  run<3, 4, 4>("mfma + 4 ds_read_b64 each", d_out, d_sink);
+  run<0, 4, 1>("mfma + 1 v_fma_f64 each", d_out, d_sink);
+  run<0, 4, 2>("mfma + 2 v_fma_f64 each", d_out, d_sink);
+  run<0, 4, 4>("mfma + 4 v_fma_f64 each", d_out, d_sink);
+  run<0, 4, 8>("mfma + 8 v_fma_f64 each", d_out, d_sink);
+  run<6, 4, 8>("4 mfma then 32 v_fma_f64 (not interleaved)", d_out, d_sink);
+  return 0;
+}

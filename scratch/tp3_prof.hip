@@ -29,8 +29,9 @@
 #include <utility>
 
 namespace mimi_hip {
-
+__device__ unsigned long long t3_prof[16];
 namespace {
+#define T3_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); prof_acc[k] += t_ - prof_last; prof_last = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 
 typedef double t3_d4 __attribute__((ext_vector_type(4)));
 
@@ -535,8 +536,11 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
   request(0);
   double* cl = carry + lane;
   const unsigned cl_addr = (unsigned)(uintptr_t)cl;   // (the low half of a shared-aperture address is the LDS offset)
+  unsigned long long prof_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}, prof_last;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prof_last)::"memory");
 #pragma unroll 1
   for (int es = 0; es < n_seq; ++es) {
+    T3_STAMP(0);
     // S1
     double bS2[4][2];
 #pragma unroll
@@ -562,10 +566,12 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(DU[mn]) : "a"(aop[mn][1]), "v"(bS2[v2][1]));
       asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(DV[mn]) : "a"(aop[mn][3]), "v"(bS2[v2][1]));
     }
+    T3_STAMP(1);
     // the matrix results are read by the vector pipe from here on: the wait states the compiler would have placed
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // the operands of the next element travel while this one is contracted
     request(es + 1 < n_seq ? es + 1 : es);   // (the last element once more: no branch in the loop)
+    T3_STAMP(2);
     const int64_t e = e0 + e_step * es;
     double* piece = p.scratch_k + (e * 3 + I) * (int64_t)T3_PIECE;
     double* out0 = piece + pa * 192 + J * 64 + kk * 4 + pb;                       // + 4 a1 192 + b1 16
@@ -623,12 +629,13 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       {
         double Em[4][NB];
         s2(std::false_type{}, Em);
-        __builtin_amdgcn_sched_barrier(0);
+        T3_STAMP(3);
         t3_s3_main_0(K0, Em[0][0], Em[1][0], Em[2][0], Em[3][0], bS0);
         t3_s3_main_1(K1, Em[0][1], Em[1][1], Em[2][1], Em[3][1], bS0);
         t3_s3_main_2(K2, Em[0][2], Em[1][2], Em[2][2], Em[3][2], bS0);
         t3_s3_main_3(K3, Em[0][3], Em[1][3], Em[2][3], Em[3][3], bS0);
       }
+      T3_STAMP(4);
       __builtin_amdgcn_sched_barrier(0);
       {
         double Ex[4][NB];
@@ -639,13 +646,14 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
           Ey[0][a1] = t3_low_halves(Ex[0][a1], Ex[1][a1]);
           Ey[1][a1] = t3_low_halves(Ex[2][a1], Ex[3][a1]);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        T3_STAMP(5);
         t3_s3_plane_0(K0, Ey[0][0], Ey[1][0], bS0x);
         t3_s3_plane_1(K1, Ey[0][1], Ey[1][1], bS0x);
         t3_s3_plane_2(K2, Ey[0][2], Ey[1][2], bS0x);
         t3_s3_plane_3(K3, Ey[0][3], Ey[1][3], bS0x);
         t3_results_guard();
       }
+      T3_STAMP(6);
       // register r of this lane: (a2 = r, b2 = (r + kk) & 3), column (a0 = pa, b0 = pb).  Final: a2 = 0 (register 0, every
       // lane) or b2 = 0 (register 4 - kk of lane groups 1..3); the pairs (a2 >= 1, b2 >= 1) go on to the next element as its
       // (a2 - 1, b2 - 1): register r -> slot r - 1 of the carry.  So register r >= 1 is EITHER stored (the lane group with
@@ -666,8 +674,10 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
           t3_carry_out<b1, r>(cl_addr, K0[r], K1[r], K2[r], K3[r]);
         }
       });
+      T3_STAMP(7);
     });
   }
+  if (lane == 0) for (int k = 0; k < 16; ++k) atomicAdd(&t3_prof[k], prof_acc[k]);
   // (the carry of the last element is read below through plain loads: its asm stores must have landed)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // what the last element of the column would have passed on: rows a2 >= 1, b2 >= 1 -> the tail of (column, i)
@@ -874,3 +884,8 @@ void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {
 }
 
 }  // namespace mimi_hip
+extern "C" int mimi_hip_debug_t3_prof(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(mimi_hip::t3_prof), sizeof(mimi_hip::t3_prof)) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mimi_hip::t3_prof), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
