@@ -25,20 +25,3 @@ print(os.environ.get("MIMI_HIP_LIBRARY", "default"), "pre-pass %.2f ms  integrat
 # a checksum of the result: variants must agree to rounding
 print("   checksum r %.15e  A %.15e" % (float(r.abs().sum()), float(A.abs().sum())))
 
-# instrumented build (scratch/p3_prof.sh): shader cycles per stage of the contraction loop, per (element, i, j) block
-import ctypes
-from mimi_amd import _capi
-L = _capi.lib()
-if hasattr(L, "mimi_hip_debug_t3_prof"):
-    out = (ctypes.c_ulonglong * 16)()
-    L.mimi_hip_debug_t3_prof(out, 1)
-    G.AddDomainResidualAndGrad(u, 1.0, r, A)
-    G.Synchronize()
-    L.mimi_hip_debug_t3_prof(out, 0)
-    blocks = patch.n_elements * 9
-    names = ["loop top (wait for operands)", "S1", "request next operands", "S2 main (x4)", "S3 main (x4)", "S2 plane + permlane (x4)",
-             "S3 plane + guard (x4)", "stores + carry out (x4)"]
-    tot = sum(out[k] for k in range(8))
-    for k in range(8):
-        print("   %-34s %8.0f cycles per block  (%4.1f %%)" % (names[k], out[k] / blocks, 100.0 * out[k] / tot))
-    print("   total %.0f cycles per block" % (tot / blocks))
