@@ -701,25 +701,34 @@ MH_DEV void wgs_contract_block(const WgsLane& lc, const double (&ah)[9], const d
   };
 #pragma unroll
   for (int b1 = 0; b1 < NB; ++b1) {
+    // S2.  The nine (m, n) terms are merged by the table variant of their a-side BEFORE the a-side multiplication
+    // (g = 3: (0,0); g = 1: (0,1) (0,2); g = 2: (1,0) | (2,0); g = 0: (1,1) (1,2) | (2,1) (2,2)): 9 + 6 x (pairs) instead
+    // of 9 + 9 x (pairs) instructions per (b1, q1), every accumulation ONE fused multiply-add (round 3: on this chip
+    // every vector instruction costs its ~5 cycles of the SIMD whatever else is in flight, scratch/issue_bench.hip).
     double Ec[4][NB];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int a1 = 0; a1 < NB; ++a1) Ec[g][a1] = 0.0;
-#pragma unroll
-    for (int mn = 0; mn < 9; ++mn) {
-      const int m = mn / 3, n = mn % 3;
-      const int g = (m == 0 ? 1 : 0) + (n == 0 ? 2 : 0);
-      double U[NQ];
-#pragma unroll
-      for (int q1 = 0; q1 < NQ; ++q1) U[q1] = (n == 1 ? uD1[b1][q1] : uB1[b1][q1]) * D1[mn][q1];
+    for (int q1 = 0; q1 < NQ; ++q1) {
+      const double cbB = uB1[b1][q1], cbD = uD1[b1][q1];
+      const double W3 = cbB * D1[0][q1];
+      const double W1 = __builtin_fma(cbD, D1[1][q1], cbB * D1[2][q1]);
+      const double W2a = cbB * D1[3][q1], W2b = cbB * D1[6][q1];
+      const double W0a = __builtin_fma(cbD, D1[4][q1], cbB * D1[5][q1]);
+      const double W0b = __builtin_fma(cbD, D1[7][q1], cbB * D1[8][q1]);
 #pragma unroll
       for (int a1 = 0; a1 < NB; ++a1) {
         if (MODE == 2 && a1 < b1) continue;
-        double acc = Ec[g][a1];
-#pragma unroll
-        for (int q1 = 0; q1 < NQ; ++q1) acc += (m == 1 ? uD1[a1][q1] : uB1[a1][q1]) * U[q1];
-        Ec[g][a1] = acc;
+        const double caB = uB1[a1][q1], caD = uD1[a1][q1];
+        if (q1 == 0) {   // (no accumulator starts from 0.0: x + 0.0 is an instruction)
+          Ec[3][a1] = caB * W3;
+          Ec[1][a1] = caB * W1;
+          Ec[2][a1] = __builtin_fma(caD, W2a, caB * W2b);
+          Ec[0][a1] = __builtin_fma(caD, W0a, caB * W0b);
+        } else {
+          Ec[3][a1] = __builtin_fma(caB, W3, Ec[3][a1]);
+          Ec[1][a1] = __builtin_fma(caB, W1, Ec[1][a1]);
+          Ec[2][a1] = __builtin_fma(caD, W2a, __builtin_fma(caB, W2b, Ec[2][a1]));
+          Ec[0][a1] = __builtin_fma(caD, W0a, __builtin_fma(caB, W0b, Ec[0][a1]));
+        }
       }
     }
     if (b1 > 0) carry_and_stage(b1 - 1);
