@@ -31,7 +31,7 @@ def sample_nodes(n, n_random, seed):
 class SampledRows:
     """expected rows of the sampled nodes: `row(k, i, cols)` -> (values at the sorted columns `cols`, residual entry)"""
 
-    def __init__(self, P, material, nodes, u, dt=0.5):
+    def __init__(self, P, material, nodes, u, dt=0.5, u_commit=None):
         from oracle import ref_path as rp
         p = P.p[0]
         self.P, self.nodes = P, nodes
@@ -48,6 +48,11 @@ class SampledRows:
         self.slot = {int(e): k for k, e in enumerate(elements)}
         self.D = rp.DomainOracle(P, material, elements=elements, with_a_ids=False, with_sparsity=False)
         self.D.set_dt(dt)
+        self.elements = elements
+        if u_commit is not None:
+            # DomainPostTimeAdvance at u_commit on the sampled elements (nonlinear_solid.cpp:179-199): the blocks below
+            # are then integrated from the committed state
+            self.D.domain_post_time_advance(u_commit)
         self.blocks = {int(e): self.D.element_residual_and_grad(self.slot[int(e)], u, rp.TANGENT_EXACT) for e in elements}
 
     def row(self, k, i, cols):

@@ -1,7 +1,7 @@
 """The reference's other materials (StVenantKirchhoff, J2Linear, J2Simo, J2Log) through the C ABI against
 the oracle: residual <= 1e-12; tangent (dual-number consistent tangent on the device) against the oracle's point-level
-difference-quotient tangent of the same stress <= 1e-6 (at first yield the return map's own tolerance limits
-the agreement, tests/test_materials_host_cpu.py); state after DomainPostTimeAdvance
+sixth-order difference-quotient tangent of the same stress <= 1e-10 (round 3: the oracle's quotient was second
+order, good to ~1e-9, and the bar 1e-6; measured now <= 1.2e-11 point by point, tests/test_materials_host_cpu.py); state after DomainPostTimeAdvance
 <= 1e-10; and again from the advanced state.  J2Simo / J2Log are pinned by the reference's golden series in
 test_nonlinear_solid.py."""
 import numpy as np
@@ -33,7 +33,7 @@ def test_other_materials_parity(matname, block):
         D.add_domain_residual_and_grad(u, 0.7, r_o, A_o, rp.TANGENT_EXACT)
         G.AddDomainResidualAndGrad(u, 0.7, r_g, A_g)
         assert relmax(r_g, r_o) < 1e-12, (round_, relmax(r_g, r_o))
-        assert relmax(A_g, A_o) < 1e-6, (round_, relmax(A_g, A_o))
+        assert relmax(A_g, A_o) < 1e-10, (round_, relmax(A_g, A_o))
         r2 = np.zeros(P.n_vdofs)
         G.AddDomainResidual(u, r2)
         assert relmax(r2, r_o) < 1e-12
@@ -78,7 +78,7 @@ def test_other_materials_medium_block(matname):
         r_g, A_g = np.zeros(P.n_vdofs), np.zeros(D.nnz)
         g.AddDomainResidualAndGrad(u, 1.0, r_g, A_g)
         assert relmax(r_g, r_o) < 1e-12
-        assert relmax(A_g, A_o) < 1e-6
+        assert relmax(A_g, A_o) < 1e-10
         r2 = np.zeros(P.n_vdofs)
         g.AddDomainResidual(u, r2)
         assert relmax(r2, r_o) < 1e-12

@@ -1,6 +1,6 @@
 """The device constitutive routines (mimi_amd/csrc/materials.hpp, materials_other.hpp) compiled for the host
 (tests/host_materials.hip, hipcc) against the oracle, point by point: PK1 stress <= 1e-12, tangent <= 1e-11 for the
-closed forms (neo-Hookean, J2) and <= 1e-6 for the dual-number tangents of the other materials (the oracle's
+closed forms (neo-Hookean, J2) and <= 1e-10 for the dual-number tangents of the other materials (the oracle's
 difference-quotient tangent and the return map's own tolerance bound that comparison, not the device code)."""
 import ctypes as C
 import os
@@ -65,7 +65,7 @@ def test_device_materials_on_host_vs_oracle(host_lib, name, dim):
     mp = product_material(name)._c_struct()
     sigma_y_ref = 70.0
     rng = np.random.default_rng(7 + dim)
-    tol_A = 1e-11 if name in ("neohook", "j2") else 1e-6
+    tol_A = 1e-11 if name in ("neohook", "j2") else 1e-10
     n_plastic = 0
     for trial in range(120):
         scale = 10 ** rng.uniform(-2.5, -0.9)
