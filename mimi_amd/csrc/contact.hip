@@ -12,11 +12,11 @@
 //           R(a,i) += -(w |J| p_q) N_a n_i   for faces with any non-zero nodal pressure
 //   tangent with the pressure frozen               mortar_contact.cpp:263-295 (FD in the reference;
 //           analytic here, or the reference's FD rule in MIMI_HIP_TANGENT_REFERENCE_FD mode)
-// Instead of per-thread copies + a mutex (mortar_contact.cpp:235-260,338-341,400-408) the nodal
-// sums and the scatter use fp64 atomics: the contact surface is (dim-1)-dimensional, a few
-// thousand faces, so this is not a bandwidth problem.
+// Instead of per-thread copies + a mutex (mortar_contact.cpp:235-260,338-341,400-408) every contribution is stored
+// densely -- per quadrature point the nodal area / gap shares, per face the residual vector and the tangent block --
+// and summed afterwards in a fixed order through the marked nodes' (face, local node) incidences: no atomics, results
+// bitwise reproducible like the domain paths (round 3; rounds 1-2 used fp64 atomics here).
 #include <hip/hip_runtime.h>
-#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 #include <algorithm>
 #include <memory>
@@ -51,6 +51,15 @@ struct ContactArgs {
   double* pressure;
   double* scalars;           // [0] area, [1] pressure integral, [2..4] force, [5] gap norm^2
   int mode;
+  // No atomics (round 3): every contribution is stored densely and summed afterwards in a fixed order --
+  // bitwise reproducible like the domain paths.
+  double* pt_area;           // [n_faces][n_q][n_dof]  w |J| N_a        of a quadrature point
+  double* pt_gap;            // [n_faces][n_q][n_dof]  w |J| g N_a
+  double* pt_scal;           // [n_faces][n_q]         w |J|  (GapNorm: min(g, 0)^2)
+  double* face_r;            // [n_faces][dim][n_dof]  face residual vectors
+  double* face_k;            // [n_faces][(a, i)][(j, b)]  face tangent blocks
+  double* face_scal;         // [n_faces][1 + dim]     pressure integral, force
+  unsigned char* face_active;   // IsPressureZero == false
 };
 
 constexpr int kMaxFaceDof = 16;
@@ -151,21 +160,69 @@ __global__ void contact_gap_area_kernel(ContactArgs p, int gap_norm_only) {
   nearest_body<DIM>(p, xq, true_g, distance);
   if (gap_norm_only) {
     // GapNorm (mortar_contact.cpp:423-467)
-    if (true_g < 0.0) unsafeAtomicAdd(&p.scalars[5], true_g * true_g);
+    p.pt_scal[pt] = true_g < 0.0 ? true_g * true_g : 0.0;
     return;
   }
   double g = true_g < 0. ? true_g : 0.;
   double m[DIM], t[(DIM - 1) * DIM];
   const double detJ = surface_normal<DIM>(p.n_dof, x_e, p.dN + pt * p.n_dof * (DIM - 1), m, t);
   const double fac = p.weight[pt] * detJ;
-  unsafeAtomicAdd(&p.scalars[0], fac);
+  p.pt_scal[pt] = fac;
   const double ratio = fabs(true_g) / distance;
   if (acos(ratio < 1. ? ratio : 1.) > 1.e-5) g = 0.0;  // angle tolerance, mortar_contact.cpp:172-181
   const double fac_g = fac * g;
   for (int a = 0; a < p.n_dof; ++a) {
-    const int l = p.local[(int64_t)f * p.n_dof + a];
-    unsafeAtomicAdd(&p.area[l], fac * N[a]);
-    if (fac_g != 0.0) unsafeAtomicAdd(&p.gap[l], fac_g * N[a]);
+    p.pt_area[pt * p.n_dof + a] = fac * N[a];
+    p.pt_gap[pt * p.n_dof + a] = fac_g * N[a];
+  }
+}
+
+// nodal area / gap (mortar_contact.cpp:182-190, the sums the reference forms under a mutex): one WAVE per marked node;
+// entry k = (incidence, quadrature point) of the node goes to lane k % 64 in order, then a fixed-shape tree over the
+// lanes -- the same bits every run
+__global__ __launch_bounds__(256) void contact_nodal_kernel(int n_marked, int n_q, int n_dof, const int32_t* __restrict__ adj_ptr,
+                                                            const int32_t* __restrict__ adj, const double* __restrict__ pt_area,
+                                                            const double* __restrict__ pt_gap, double* __restrict__ area,
+                                                            double* __restrict__ gap) {
+  const int lane = threadIdx.x & 63;
+  const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (l >= n_marked) return;
+  const int t0 = adj_ptr[l], n = (adj_ptr[l + 1] - t0) * n_q;
+  double sa = 0.0, sg = 0.0;
+  for (int k = lane; k < n; k += 64) {
+    const int ea = adj[t0 + k / n_q];
+    const int64_t pt = (int64_t)(ea >> 6) * n_q + k % n_q;
+    sa += pt_area[pt * n_dof + (ea & 63)];
+    sg += pt_gap[pt * n_dof + (ea & 63)];
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    sa += __shfl_down(sa, off, 64);
+    sg += __shfl_down(sg, off, 64);
+  }
+  if (lane == 0) {
+    area[l] = sa;
+    gap[l] = sg;
+  }
+}
+
+// out[k] = sum_i in[i * stride + k] (k < n_out), optionally over the rows with flag[i] != 0: ONE workgroup, every thread a
+// fixed subset of the rows, then a fixed-shape tree -- the same bits every run
+__global__ __launch_bounds__(1024) void contact_sum_kernel(int64_t n, int stride, int n_out, const double* __restrict__ in,
+                                                           const unsigned char* __restrict__ flag, double* __restrict__ out) {
+  __shared__ double part[1024];
+  for (int k = 0; k < n_out; ++k) {
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024)
+      if (!flag || flag[i]) s += in[i * stride + k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+      if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) out[k] = part[0];
+    __syncthreads();
   }
 }
 
@@ -197,7 +254,8 @@ MH_DEV void face_residual(const ContactArgs& p, int f, const double* x_e, const 
   }
 }
 
-// pass 2: one thread per face (faces are few; the work per face is small)
+// pass 2: one thread per face (faces are few; the work per face is small): the face residual vector, its share of the
+// pressure integral / force, and -- reference-FD mode -- the face tangent block; all stored densely (contact_gather_kernel)
 template<int DIM>
 __global__ void contact_residual_kernel(ContactArgs p, int with_grad) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -208,83 +266,38 @@ __global__ void contact_residual_kernel(ContactArgs p, int with_grad) {
     p_e[a] = p.pressure[p.local[(int64_t)f * p.n_dof + a]];
     any = any || (p_e[a] != 0.0);
   }
+  p.face_active[f] = any ? 1 : 0;
   if (!any) return;  // IsPressureZero (integrator_utils.cpp:112-119)
   double x_e[DIM * kMaxFaceDof], R_e[DIM * kMaxFaceDof];
   gather_x<DIM>(p, f, x_e);
   double force[DIM] = {0}, pint = 0;
   face_residual<DIM>(p, f, x_e, p_e, R_e, force, &pint);
-  for (int a = 0; a < p.n_dof; ++a) {
-    const int64_t node = p.dofs[(int64_t)f * p.n_dof + a];
+  const int NT = p.n_dof * DIM;
+  for (int k = 0; k < NT; ++k) p.face_r[(int64_t)f * NT + k] = R_e[k];      // [i][a]
+  p.face_scal[(int64_t)f * (1 + DIM)] = pint;
 #pragma unroll
-    for (int i = 0; i < DIM; ++i) unsafeAtomicAdd(&p.r[node * DIM + i], R_e[i * p.n_dof + a]);
-  }
-  unsafeAtomicAdd(&p.scalars[1], pint);
-#pragma unroll
-  for (int i = 0; i < DIM; ++i) unsafeAtomicAdd(&p.scalars[2 + i], force[i]);
+  for (int i = 0; i < DIM; ++i) p.face_scal[(int64_t)f * (1 + DIM) + 1 + i] = force[i];
   if (!with_grad) return;
-  const int32_t* pp = p.pair_pos + (int64_t)f * p.n_dof * p.n_dof;
-  if (p.mode == MIMI_HIP_TANGENT_REFERENCE_FD) {
-    // mortar_contact.cpp:263-295: forward FD on the current POSITION, pressure frozen
-    double fwd[DIM * kMaxFaceDof];
-    for (int c = 0; c < p.n_dof * DIM; ++c) {
-      const double orig = x_e[c];
-      const double step = (orig != 0.0) ? fabs(orig) * 1.0e-8 : 1.0e-10;
-      const double step_inv = 1. / step;
-      x_e[c] = orig + step;
-      face_residual<DIM>(p, f, x_e, p_e, fwd, nullptr, nullptr);
-      x_e[c] = orig;
-      const int b = c % p.n_dof, j = c / p.n_dof;
-      for (int a = 0; a < p.n_dof; ++a) {
-        const int64_t rowA = (int64_t)p.dofs[(int64_t)f * p.n_dof + a] * DIM;
+  double* Kf = p.face_k + (int64_t)f * NT * NT;     // row (a, i): [j][b]
+  // mortar_contact.cpp:263-295: forward FD on the current POSITION, pressure frozen
+  double fwd[DIM * kMaxFaceDof];
+  for (int c = 0; c < NT; ++c) {
+    const double orig = x_e[c];
+    const double step = (orig != 0.0) ? fabs(orig) * 1.0e-8 : 1.0e-10;
+    const double step_inv = 1. / step;
+    x_e[c] = orig + step;
+    face_residual<DIM>(p, f, x_e, p_e, fwd, nullptr, nullptr);
+    x_e[c] = orig;
+    const int b = c % p.n_dof, j = c / p.n_dof;
+    for (int a = 0; a < p.n_dof; ++a)
 #pragma unroll
-        for (int i = 0; i < DIM; ++i) {
-          const double k_entry = (fwd[i * p.n_dof + a] - R_e[i * p.n_dof + a]) * step_inv;
-          unsafeAtomicAdd(p.A + p.rowptr[rowA + i] + pp[a * p.n_dof + b] + j, k_entry * p.grad_factor);
-        }
-      }
-    }
-    return;
-  }
-  // analytic: R(a,i) = -w p N_a m_i ;  d m / d x_bj with p frozen
-  for (int q = 0; q < p.n_q; ++q) {
-    const int64_t pt = (int64_t)f * p.n_q + q;
-    const double* N = p.N + pt * p.n_dof;
-    const double* dN = p.dN + pt * p.n_dof * (DIM - 1);
-    double pq = 0;
-    for (int a = 0; a < p.n_dof; ++a) pq += N[a] * p_e[a];
-    const double wp = p.weight[pt] * pq;
-    double m[DIM], t[(DIM - 1) * DIM];
-    surface_normal<DIM>(p.n_dof, x_e, dN, m, t);
-    for (int b = 0; b < p.n_dof; ++b)
-#pragma unroll
-      for (int j = 0; j < DIM; ++j) {
-        double dm[DIM];
-        if constexpr (DIM == 2) {
-          dm[0] = (j == 1) ? dN[b] : 0.0;
-          dm[1] = (j == 0) ? -dN[b] : 0.0;
-        } else {
-          double e[3] = {0, 0, 0};
-          e[j] = 1.0;
-          const double* t1 = t;
-          const double* t2 = t + 3;
-          const double d1 = dN[b], d2 = dN[p.n_dof + b];
-          dm[0] = d1 * (e[1] * t2[2] - e[2] * t2[1]) + d2 * (t1[1] * e[2] - t1[2] * e[1]);
-          dm[1] = d1 * (e[2] * t2[0] - e[0] * t2[2]) + d2 * (t1[2] * e[0] - t1[0] * e[2]);
-          dm[2] = d1 * (e[0] * t2[1] - e[1] * t2[0]) + d2 * (t1[0] * e[1] - t1[1] * e[0]);
-        }
-        for (int a = 0; a < p.n_dof; ++a) {
-          const int64_t rowA = (int64_t)p.dofs[(int64_t)f * p.n_dof + a] * DIM;
-#pragma unroll
-          for (int i = 0; i < DIM; ++i)
-            unsafeAtomicAdd(p.A + p.rowptr[rowA + i] + pp[a * p.n_dof + b] + j, -wp * N[a] * dm[i] * p.grad_factor);
-        }
-      }
+      for (int i = 0; i < DIM; ++i)
+        Kf[(a * DIM + i) * NT + j * p.n_dof + b] = (fwd[i * p.n_dof + a] - R_e[i * p.n_dof + a]) * step_inv;
   }
 }
 
 // analytic frozen-pressure tangent, one WAVE per face: lane = node pair (a, b), its DIM x DIM block accumulated over the
-// quadrature points in registers, then one atomic per entry (the one-thread-per-face loop above issues n_q times as
-// many, serially: 5.1 ms at cfg4's 9 216 faces against 3.4 ms for the whole domain assembly)
+// quadrature points in registers (R(a,i) = -w p N_a m_i, d m / d x_bj with p frozen), stored into the face block
 template<int DIM>
 __global__ __launch_bounds__(256) void contact_tangent_kernel(ContactArgs p) {
   const int lane = threadIdx.x & 63;
@@ -299,8 +312,8 @@ __global__ __launch_bounds__(256) void contact_tangent_kernel(ContactArgs p) {
   if (!any) return;  // IsPressureZero (integrator_utils.cpp:112-119)
   double x_e[DIM * kMaxFaceDof];
   gather_x<DIM>(p, f, x_e);
-  const int32_t* pp = p.pair_pos + (int64_t)f * p.n_dof * p.n_dof;
-  const int n_pairs = p.n_dof * p.n_dof;
+  const int n_pairs = p.n_dof * p.n_dof, NT = p.n_dof * DIM;
+  double* Kf = p.face_k + (int64_t)f * NT * NT;
   for (int pair = lane; pair < n_pairs; pair += 64) {
     const int a = pair / p.n_dof, b = pair % p.n_dof;
     double acc[DIM * DIM];
@@ -335,12 +348,62 @@ __global__ __launch_bounds__(256) void contact_tangent_kernel(ContactArgs p) {
         for (int i = 0; i < DIM; ++i) acc[i * DIM + j] += wpn * dm[i];
       }
     }
-    const int64_t rowA = (int64_t)p.dofs[(int64_t)f * p.n_dof + a] * DIM;
 #pragma unroll
     for (int i = 0; i < DIM; ++i)
 #pragma unroll
-      for (int j = 0; j < DIM; ++j)
-        unsafeAtomicAdd(p.A + p.rowptr[rowA + i] + pp[a * p.n_dof + b] + j, acc[i * DIM + j] * p.grad_factor);
+      for (int j = 0; j < DIM; ++j) Kf[(a * DIM + i) * NT + j * p.n_dof + b] = acc[i * DIM + j];
+  }
+}
+
+// The sums the reference forms under a mutex (mortar_contact.cpp:338-341,400-408), without atomics: one wave per CSR row
+// (marked node, i); the wave walks the node's (face, local node) incidences in face order, adds row (a, i) of every ACTIVE
+// face block into an LDS image of the CSR row through the pair positions (lane = column node b: distinct positions within
+// an instruction), then adds the image to the caller's values in one coalesced pass; the residual entry likewise.
+// Rows none of whose faces is active are left untouched.
+constexpr int CG_WAVES = 4;
+constexpr int CG_MAX_ROW = 1056;   // (2 p + 1)^3 neighbours x 3 at p = 3 is 1029
+template<int DIM, int WITH_K>
+__global__ __launch_bounds__(64 * CG_WAVES) void contact_gather_kernel(ContactArgs p, int n_marked, const int32_t* __restrict__ marked,
+                                                                       const int32_t* __restrict__ adj_ptr, const int32_t* __restrict__ adj) {
+  __shared__ double img_all[WITH_K ? CG_WAVES : 1][CG_MAX_ROW];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t R = (int64_t)blockIdx.x * CG_WAVES + wave;
+  if (R >= (int64_t)n_marked * DIM) return;
+  const int l = (int)(R / DIM), i = (int)(R % DIM);
+  const int a_beg = adj_ptr[l], a_end = adj_ptr[l + 1];
+  bool any = false;
+  for (int t = a_beg; t < a_end; ++t) any = any || p.face_active[adj[t] >> 6];
+  if (!any) return;
+  const int64_t row = (int64_t)marked[l] * DIM + i;
+  const int NT = p.n_dof * DIM;
+  if constexpr (WITH_K) {
+    double* img = img_all[wave];
+    const int64_t beg = p.rowptr[row];
+    const int len = (int)(p.rowptr[row + 1] - beg);
+    for (int k = lane; k < len; k += 64) img[k] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    for (int t = a_beg; t < a_end; ++t) {
+      const int64_t f = adj[t] >> 6;
+      const int a = adj[t] & 63;
+      if (!p.face_active[f]) continue;
+      const double* Kr = p.face_k + (f * NT + (a * DIM + i)) * (int64_t)NT;   // row (a, i): [j][b]
+      for (int b = lane; b < p.n_dof; b += 64) {
+        const int32_t off = p.pair_pos[(f * p.n_dof + a) * p.n_dof + b];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) img[off + j] += Kr[j * p.n_dof + b];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < len; k += 64) p.A[beg + k] += p.grad_factor * img[k];
+  }
+  if (lane == 0) {
+    double rs = 0.0;
+    for (int t = a_beg; t < a_end; ++t) {
+      const int64_t f = adj[t] >> 6;
+      if (p.face_active[f]) rs += p.face_r[f * NT + i * p.n_dof + (adj[t] & 63)];
+    }
+    p.r[row] += rs;
   }
 }
 
@@ -384,6 +447,10 @@ struct mimi_hip_contact_s {
   const int64_t* rowptr = nullptr;
   DeviceBuffer<double> stage_u, stage_r, stage_A;
   DeviceBuffer<int> status;
+  // dense stores of the atomic-free assembly and the node -> (face, local node) incidences of the marked nodes
+  DeviceBuffer<double> pt_area, pt_gap, pt_scal, face_r, face_k, face_scal;
+  DeviceBuffer<unsigned char> face_active;
+  DeviceBuffer<int32_t> madj_ptr, madj, marked_dev;
   std::vector<int32_t> marked_nodes;   // sorted global node ids of the marked dofs (local index -> node)
   SplineBodyDev spline{};
   DeviceBuffer<double> sb_knots[2], sb_ctrl, sb_sample_xi, sb_sample_x;
@@ -496,6 +563,13 @@ static ContactArgs contact_args(mimi_hip_contact_s* h, const double* u, double* 
   a.pressure = h->pressure.ptr;
   a.scalars = h->scalars.ptr;
   a.mode = h->mode;
+  a.pt_area = h->pt_area.ptr;
+  a.pt_gap = h->pt_gap.ptr;
+  a.pt_scal = h->pt_scal.ptr;
+  a.face_r = h->face_r.ptr;
+  a.face_k = h->face_k.ptr;
+  a.face_scal = h->face_scal.ptr;
+  a.face_active = h->face_active.ptr;
   return a;
 }
 
@@ -503,24 +577,32 @@ static ContactArgs contact_args(mimi_hip_contact_s* h, const double* u, double* 
 static void contact_pass1(mimi_hip_contact_s* h, const double* u_dev) {
   ContactArgs a = contact_args(h, u_dev, nullptr, nullptr, 0.0);
   // InitializeGapAreaPressure + last_* reset (mortar_contact.cpp:135-146,302-306)
-  MH_HIP(hipMemsetAsync(h->area.ptr, 0, h->n_marked * sizeof(double), h->stream));
-  MH_HIP(hipMemsetAsync(h->gap.ptr, 0, h->n_marked * sizeof(double), h->stream));
   MH_HIP(hipMemsetAsync(h->scalars.ptr, 0, 6 * sizeof(double), h->stream));
   const int threads = 128;
   const int64_t npts = (int64_t)h->n_faces * h->n_q;
   const unsigned b1 = (unsigned)((npts + threads - 1) / threads);
   if (h->dim == 2) hipLaunchKernelGGL(contact_gap_area_kernel<2>, dim3(b1), dim3(threads), 0, h->stream, a, 0);
   else hipLaunchKernelGGL(contact_gap_area_kernel<3>, dim3(b1), dim3(threads), 0, h->stream, a, 0);
+  hipLaunchKernelGGL(contact_nodal_kernel, dim3((unsigned)((h->n_marked + 3) / 4)), dim3(256), 0, h->stream,
+                     h->n_marked, h->n_q, h->n_dof, h->madj_ptr.ptr, h->madj.ptr, h->pt_area.ptr, h->pt_gap.ptr, h->area.ptr, h->gap.ptr);
+  hipLaunchKernelGGL(contact_sum_kernel, dim3(1), dim3(1024), 0, h->stream, npts, 1, 1, h->pt_scal.ptr,
+                     (const unsigned char*)nullptr, h->scalars.ptr);
   MH_HIP(hipGetLastError());
 }
 
-// pressure from the nodal area / gap (mortar_contact.cpp:195-261), then pass 2: residual (+ tangent)
+// pressure from the nodal area / gap (mortar_contact.cpp:195-261), then pass 2: face residual vectors (+ tangent blocks)
+// and their row gather
 static void contact_pass2(mimi_hip_contact_s* h, const double* u_dev, double* r_dev, double* A_dev, double gf, bool with_grad) {
   ContactArgs a = contact_args(h, u_dev, r_dev, A_dev, gf);
   const int threads = 128;
   const unsigned b2 = (unsigned)((h->n_marked + threads - 1) / threads);
   const unsigned b3 = (unsigned)((h->n_faces + 63) / 64);
   hipLaunchKernelGGL(contact_pressure_kernel, dim3(b2), dim3(threads), 0, h->stream, h->n_marked, h->area.ptr, h->gap.ptr, h->penalty, h->pressure.ptr);
+  if (with_grad && !h->face_k.ptr) {
+    const size_t nt = (size_t)h->n_dof * h->dim;
+    h->face_k.resize((size_t)h->n_faces * nt * nt);
+    a.face_k = h->face_k.ptr;
+  }
   // analytic tangent: the residual by the face-per-thread kernel, the tangent by one wave per face
   const bool wave_tangent = with_grad && h->mode != MIMI_HIP_TANGENT_REFERENCE_FD;
   const int grad_flag = (with_grad && !wave_tangent) ? 1 : 0;
@@ -530,6 +612,17 @@ static void contact_pass2(mimi_hip_contact_s* h, const double* u_dev, double* r_
     const unsigned b4 = (unsigned)((h->n_faces + 3) / 4);
     if (h->dim == 2) hipLaunchKernelGGL(contact_tangent_kernel<2>, dim3(b4), dim3(256), 0, h->stream, a);
     else hipLaunchKernelGGL(contact_tangent_kernel<3>, dim3(b4), dim3(256), 0, h->stream, a);
+  }
+  // pressure integral and force of the active faces (last_pressure_ / last_force_), in a fixed order
+  hipLaunchKernelGGL(contact_sum_kernel, dim3(1), dim3(1024), 0, h->stream, (int64_t)h->n_faces, 1 + h->dim, 1 + h->dim,
+                     h->face_scal.ptr, h->face_active.ptr, h->scalars.ptr + 1);
+  const unsigned b5 = (unsigned)(((int64_t)h->n_marked * h->dim + CG_WAVES - 1) / CG_WAVES);
+  if (h->dim == 2) {
+    if (with_grad) hipLaunchKernelGGL((contact_gather_kernel<2, 1>), dim3(b5), dim3(64 * CG_WAVES), 0, h->stream, a, h->n_marked, h->marked_dev.ptr, h->madj_ptr.ptr, h->madj.ptr);
+    else hipLaunchKernelGGL((contact_gather_kernel<2, 0>), dim3(b5), dim3(64 * CG_WAVES), 0, h->stream, a, h->n_marked, h->marked_dev.ptr, h->madj_ptr.ptr, h->madj.ptr);
+  } else {
+    if (with_grad) hipLaunchKernelGGL((contact_gather_kernel<3, 1>), dim3(b5), dim3(64 * CG_WAVES), 0, h->stream, a, h->n_marked, h->marked_dev.ptr, h->madj_ptr.ptr, h->madj.ptr);
+    else hipLaunchKernelGGL((contact_gather_kernel<3, 0>), dim3(b5), dim3(64 * CG_WAVES), 0, h->stream, a, h->n_marked, h->marked_dev.ptr, h->madj_ptr.ptr, h->madj.ptr);
   }
   MH_HIP(hipGetLastError());
 }
@@ -609,6 +702,26 @@ int mimi_hip_contact_create(const mimi_hip_contact_tables* t, int device, mimi_h
     h->pressure.resize(h->n_marked);
     h->scalars.resize(6);
     MH_HIP(hipMemsetAsync(h->pressure.ptr, 0, h->n_marked * sizeof(double), h->stream));
+    {
+      // marked node -> its (face, local node) incidences, faces in ascending order: the summation order of every gather
+      if (t->n_faces >= (1 << 25)) fail("too many boundary faces for the incidence encoding");
+      std::vector<int32_t> ptr(marked.size() + 1, 0), adj(nfd);
+      for (size_t k = 0; k < nfd; ++k) ++ptr[local[k] + 1];
+      for (size_t l = 0; l < marked.size(); ++l) ptr[l + 1] += ptr[l];
+      std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+      for (size_t k = 0; k < nfd; ++k) adj[fill[local[k]]++] = (int32_t)(((k / t->n_dof) << 6) | (k % t->n_dof));
+      h->madj_ptr.assign(ptr.data(), ptr.size(), h->stream);
+      h->madj.assign(adj.data(), adj.size(), h->stream);
+      h->marked_dev.assign(marked.data(), marked.size(), h->stream);
+      const size_t npts_ = (size_t)t->n_faces * t->n_quad;
+      h->pt_area.resize(npts_ * t->n_dof);
+      h->pt_gap.resize(npts_ * t->n_dof);
+      h->pt_scal.resize(npts_);
+      h->face_r.resize((size_t)t->n_faces * t->n_dof * t->dim);
+      h->face_scal.resize((size_t)t->n_faces * (1 + t->dim));
+      h->face_active.resize((size_t)t->n_faces);
+      MH_HIP(hipMemsetAsync(h->face_active.ptr, 0, (size_t)t->n_faces, h->stream));
+    }
     h->status.resize(1);
     MH_HIP(hipMemsetAsync(h->status.ptr, 0, sizeof(int), h->stream));
     if (!t->csr_rowptr || !t->csr_col) fail("csr_rowptr / csr_col must be given");
@@ -691,7 +804,6 @@ int mimi_hip_contact_gap_norm(mimi_hip_contact_t h, const double* u, double* out
     MH_HIP(hipSetDevice(h->device));
     Mirror<double> mu = Mirror<double>::in(u, h->n_vdofs, h->stage_u, h->stream);
     ContactArgs a = contact_args(h, mu.dev, nullptr, nullptr, 0.0);
-    MH_HIP(hipMemsetAsync(h->scalars.ptr + 5, 0, sizeof(double), h->stream));
     const int threads = 128;
     const int64_t npts = (int64_t)h->n_faces * h->n_q;
     const unsigned b1 = (unsigned)((npts + threads - 1) / threads);
@@ -699,6 +811,8 @@ int mimi_hip_contact_gap_norm(mimi_hip_contact_t h, const double* u, double* out
       hipLaunchKernelGGL(contact_gap_area_kernel<2>, dim3(b1), dim3(threads), 0, h->stream, a, 1);
     else
       hipLaunchKernelGGL(contact_gap_area_kernel<3>, dim3(b1), dim3(threads), 0, h->stream, a, 1);
+    hipLaunchKernelGGL(contact_sum_kernel, dim3(1), dim3(1024), 0, h->stream, npts, 1, 1, h->pt_scal.ptr,
+                       (const unsigned char*)nullptr, h->scalars.ptr + 5);
     MH_HIP(hipGetLastError());
     double g2 = 0;
     MH_HIP(hipMemcpyAsync(&g2, h->scalars.ptr + 5, sizeof(double), hipMemcpyDeviceToHost, h->stream));

@@ -389,37 +389,50 @@ class ShardedContact:
                 raise
         face_nodes = patch.boundary_nodes(axis, side)                 # sorted global node ids of the whole face
         self.n_face = len(face_nodes)
-        if self.contact is not None:
-            self.slot = torch.from_numpy(np.searchsorted(face_nodes, self.contact.MarkedNodes()).astype(np.int64))
         backend = dist.get_backend() if dist.is_initialized() else None
         self.comm_device = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
         self.device = torch.device("cuda", device)
+        # Only the ranks whose slab touches the contact face take part in the nodal sum (the others have no face, no
+        # pressure, nothing to add): a communicator of their own, made once (collective over ALL ranks: every rank
+        # reports whether it has faces); one rank alone needs no exchange at all.
+        self.group, self.group_size = None, 1
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            has = [None] * dist.get_world_size()
+            dist.all_gather_object(has, self.contact is not None)
+            ranks = [r for r, f in enumerate(has) if f]
+            self.group_size = len(ranks)
+            if 1 < len(ranks) < dist.get_world_size():
+                self.group = dist.new_group(ranks)              # (collective: every rank calls it with the same list)
+        if self.contact is not None:
+            n = len(self.contact.MarkedNodes())
+            self.slot = torch.from_numpy(np.searchsorted(face_nodes, self.contact.MarkedNodes()).astype(np.int64)).to(self.comm_device)
+            # persistent buffers: the step allocates nothing and -- with RCCL -- never waits on the host
+            self.buf = torch.zeros(2, self.n_face, dtype=torch.float64, device=self.comm_device)
+            self.nodal = torch.empty(2, n, dtype=torch.float64, device=self.device)
 
     def SetStream(self, stream):
         if self.contact is not None:
             self.contact.SetStream(stream)
 
     def _sum_nodal(self, u):
-        torch = self.torch
-        buf = torch.zeros(2, self.n_face, dtype=torch.float64, device=self.comm_device)
-        if self.contact is not None:
-            c = self.contact
-            c.GapArea(u)
-            n = len(self.slot)
-            area = torch.empty(n, dtype=torch.float64, device=self.device)
-            gap = torch.empty(n, dtype=torch.float64, device=self.device)
-            c.GetNodal(area, gap)
-            c.Synchronize()
-            slot = self.slot.to(self.comm_device)
-            buf[0, slot] = area.to(self.comm_device)
-            buf[1, slot] = gap.to(self.comm_device)
-        if self.dist.is_initialized() and self.dist.get_world_size() > 1:
-            self.dist.all_reduce(buf)
-        if self.contact is not None:
-            area = buf[0, slot].to(self.device).contiguous()
-            gap = buf[1, slot].to(self.device).contiguous()
-            self.contact.SetNodal(area, gap)
-            self._keep = (area, gap)
+        """pass 1 on this rank's faces, then the nodal area / gap summed over the ranks that share the face.  Device
+        tensors and RCCL: everything is enqueued -- the kernels on the handle's stream, the copies on torch's current
+        stream, which the caller keeps identical to it (bench.py: torch.cuda.set_stream + SetStream), the all-reduce
+        ordered behind them by torch.distributed -- and the host does not wait.  gloo (tests): staged through the host."""
+        if self.contact is None:
+            return
+        c = self.contact
+        c.GapArea(u)
+        c.GetNodal(self.nodal[0], self.nodal[1])
+        if self.group_size > 1:
+            staged = self.comm_device.type == "cpu"
+            if staged:
+                c.Synchronize()
+            self.buf.zero_()
+            self.buf[:, self.slot] = self.nodal.to(self.comm_device)
+            self.dist.all_reduce(self.buf, group=self.group)
+            self.nodal.copy_(self.buf[:, self.slot])
+            c.SetNodal(self.nodal[0], self.nodal[1])
 
     def AddBoundaryResidual(self, u, r):
         self._sum_nodal(u)

@@ -108,6 +108,18 @@ def test_contact_parity_gpu(n_el, p, axis, bodykind):
         G.AddBoundaryResidualAndGrad(u, 0.6, r_g, A_g)
         assert rel(r_g - r0, r_o - r0) < 1e-12
         assert rel(A_g - A0, A_o - A0) < tol
+        # no atomics anywhere on the contact path (round 3): the same bits every run, history scalars included
+        r_2, A_2 = r0.copy(), A0.copy()
+        G.AddBoundaryResidualAndGrad(u, 0.6, r_2, A_2)
+        assert np.array_equal(r_2, r_g) and np.array_equal(A_2, A_g)
+    first = (G.AveragePressure().copy(), G.GapNorm(u))
+    G.BoundaryPostTimeAdvance(u)
+    hist = (G.last_area_, tuple(G.last_force_), G.last_pressure_)
+    for _ in range(3):
+        G.AddBoundaryResidual(u, r0.copy())
+        G.BoundaryPostTimeAdvance(u)
+        assert np.array_equal(G.AveragePressure(), first[0]) and G.GapNorm(u) == first[1]
+        assert (G.last_area_, tuple(G.last_force_), G.last_pressure_) == hist
 
 
 # ---- a case with a closed-form answer: the only pin this path has that does not pass through the oracle's author ------
