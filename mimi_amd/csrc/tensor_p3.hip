@@ -329,12 +329,18 @@ MH_DEV void t3_for(std::integer_sequence<int, Is...>, F&& f) {
 // (8 v_accvgpr_write per tile going in, an AGPR -> VGPR -> AGPR round trip per value going out, 7.7 cycles per half
 // each -- scratch/issue_bench.hip); the hardware does not need to.  To the compiler a tile is four doubles bound to
 // those registers (a 256-bit value bound to a physical tuple crashes its copy lowering).  Carry in LDS:
-// [pair a1 4 + b1][slot 0..3][lane], slot 3 stays zero; `addr` = LDS byte address of this lane's slot 0 of pair 0.
+// [pair a1 4 + b1][slot 0..3][lane], slot 3 stays zero.  EVERY lane writes its registers 1..3 to the slots 0..2 -- also
+// the lane group whose register is final (b2 = 0) and must not be carried on: the READ of slot s = r - 1 by that lane
+// group goes to slot 3 instead (addr[s] = this lane's slot-0 address of pair 0, plus (3 - s) slots for lane group 3 - s),
+// so that neither side needs an execution mask (with masks: 3 branches and 12 single writes per pair column, 1.0 of
+// the 19.4 ms a variant of this kernel without its memory traffic took).
 template<int B1>
-MH_DEV void t3_carry_in_0(unsigned addr, double (&K)[4]) {   // requests the carry of (0, B1) as the tile's start value (no wait)
-  asm volatile("ds_read2st64_b64 a[0:3], %4 offset0:%5 offset1:%6\n\tds_read2st64_b64 a[4:7], %4 offset0:%7 offset1:%8"
+MH_DEV void t3_carry_in_0(const unsigned (&addr)[4], double (&K)[4]) {   // requests the carry of (0, B1) as the tile's start value (no wait)
+  asm volatile("ds_read_b64 a[0:1], %4 offset:%8\n\tds_read_b64 a[2:3], %5 offset:%9\n\t"
+               "ds_read_b64 a[4:5], %6 offset:%10\n\tds_read_b64 a[6:7], %7 offset:%11"
                : "={a[0:1]}"(K[0]), "={a[2:3]}"(K[1]), "={a[4:5]}"(K[2]), "={a[6:7]}"(K[3])
-               : "v"(addr), "n"(0 + B1 * 4), "n"(0 + B1 * 4 + 1), "n"(0 + B1 * 4 + 2), "n"(0 + B1 * 4 + 3));
+               : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "n"((0 + B1 * 4) * 512), "n"((0 + B1 * 4 + 1) * 512),
+                 "n"((0 + B1 * 4 + 2) * 512), "n"((0 + B1 * 4 + 3) * 512));
 }
 MH_DEV void t3_s3_main_0(double (&K)[4], double e0, double e1, double e2, double e3, const double (&b)[4]) {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1\n\t"
@@ -349,10 +355,12 @@ MH_DEV void t3_s3_plane_0(double (&K)[4], double e0, double e1, const double (&b
                : "v"(e0), "v"(e1), "v"(b[0]), "v"(b[1]));
 }
 template<int B1>
-MH_DEV void t3_carry_in_1(unsigned addr, double (&K)[4]) {   // requests the carry of (1, B1) as the tile's start value (no wait)
-  asm volatile("ds_read2st64_b64 a[8:11], %4 offset0:%5 offset1:%6\n\tds_read2st64_b64 a[12:15], %4 offset0:%7 offset1:%8"
+MH_DEV void t3_carry_in_1(const unsigned (&addr)[4], double (&K)[4]) {   // requests the carry of (1, B1) as the tile's start value (no wait)
+  asm volatile("ds_read_b64 a[8:9], %4 offset:%8\n\tds_read_b64 a[10:11], %5 offset:%9\n\t"
+               "ds_read_b64 a[12:13], %6 offset:%10\n\tds_read_b64 a[14:15], %7 offset:%11"
                : "={a[8:9]}"(K[0]), "={a[10:11]}"(K[1]), "={a[12:13]}"(K[2]), "={a[14:15]}"(K[3])
-               : "v"(addr), "n"(16 + B1 * 4), "n"(16 + B1 * 4 + 1), "n"(16 + B1 * 4 + 2), "n"(16 + B1 * 4 + 3));
+               : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "n"((16 + B1 * 4) * 512), "n"((16 + B1 * 4 + 1) * 512),
+                 "n"((16 + B1 * 4 + 2) * 512), "n"((16 + B1 * 4 + 3) * 512));
 }
 MH_DEV void t3_s3_main_1(double (&K)[4], double e0, double e1, double e2, double e3, const double (&b)[4]) {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1\n\t"
@@ -367,10 +375,12 @@ MH_DEV void t3_s3_plane_1(double (&K)[4], double e0, double e1, const double (&b
                : "v"(e0), "v"(e1), "v"(b[0]), "v"(b[1]));
 }
 template<int B1>
-MH_DEV void t3_carry_in_2(unsigned addr, double (&K)[4]) {   // requests the carry of (2, B1) as the tile's start value (no wait)
-  asm volatile("ds_read2st64_b64 a[16:19], %4 offset0:%5 offset1:%6\n\tds_read2st64_b64 a[20:23], %4 offset0:%7 offset1:%8"
+MH_DEV void t3_carry_in_2(const unsigned (&addr)[4], double (&K)[4]) {   // requests the carry of (2, B1) as the tile's start value (no wait)
+  asm volatile("ds_read_b64 a[16:17], %4 offset:%8\n\tds_read_b64 a[18:19], %5 offset:%9\n\t"
+               "ds_read_b64 a[20:21], %6 offset:%10\n\tds_read_b64 a[22:23], %7 offset:%11"
                : "={a[16:17]}"(K[0]), "={a[18:19]}"(K[1]), "={a[20:21]}"(K[2]), "={a[22:23]}"(K[3])
-               : "v"(addr), "n"(32 + B1 * 4), "n"(32 + B1 * 4 + 1), "n"(32 + B1 * 4 + 2), "n"(32 + B1 * 4 + 3));
+               : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "n"((32 + B1 * 4) * 512), "n"((32 + B1 * 4 + 1) * 512),
+                 "n"((32 + B1 * 4 + 2) * 512), "n"((32 + B1 * 4 + 3) * 512));
 }
 MH_DEV void t3_s3_main_2(double (&K)[4], double e0, double e1, double e2, double e3, const double (&b)[4]) {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1\n\t"
@@ -385,10 +395,12 @@ MH_DEV void t3_s3_plane_2(double (&K)[4], double e0, double e1, const double (&b
                : "v"(e0), "v"(e1), "v"(b[0]), "v"(b[1]));
 }
 template<int B1>
-MH_DEV void t3_carry_in_3(unsigned addr, double (&K)[4]) {   // requests the carry of (3, B1) as the tile's start value (no wait)
-  asm volatile("ds_read2st64_b64 a[24:27], %4 offset0:%5 offset1:%6\n\tds_read2st64_b64 a[28:31], %4 offset0:%7 offset1:%8"
+MH_DEV void t3_carry_in_3(const unsigned (&addr)[4], double (&K)[4]) {   // requests the carry of (3, B1) as the tile's start value (no wait)
+  asm volatile("ds_read_b64 a[24:25], %4 offset:%8\n\tds_read_b64 a[26:27], %5 offset:%9\n\t"
+               "ds_read_b64 a[28:29], %6 offset:%10\n\tds_read_b64 a[30:31], %7 offset:%11"
                : "={a[24:25]}"(K[0]), "={a[26:27]}"(K[1]), "={a[28:29]}"(K[2]), "={a[30:31]}"(K[3])
-               : "v"(addr), "n"(48 + B1 * 4), "n"(48 + B1 * 4 + 1), "n"(48 + B1 * 4 + 2), "n"(48 + B1 * 4 + 3));
+               : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "n"((48 + B1 * 4) * 512), "n"((48 + B1 * 4 + 1) * 512),
+                 "n"((48 + B1 * 4 + 2) * 512), "n"((48 + B1 * 4 + 3) * 512));
 }
 MH_DEV void t3_s3_main_3(double (&K)[4], double e0, double e1, double e2, double e3, const double (&b)[4]) {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 1\n\t"
@@ -402,8 +414,7 @@ MH_DEV void t3_s3_plane_3(double (&K)[4], double e0, double e1, const double (&b
                : "+{a[24:25]}"(K[0]), "+{a[26:27]}"(K[1]), "+{a[28:29]}"(K[2]), "+{a[30:31]}"(K[3])
                : "v"(e0), "v"(e1), "v"(b[0]), "v"(b[1]));
 }
-// register R (1..3) of the four tiles -> slot R - 1 of their carry (called under the execution mask of the lane groups
-// whose register R is not final)
+// register R (1..3) of the four tiles -> slot R - 1 of their carry (every lane)
 template<int B1, int R>
 MH_DEV void t3_carry_out(unsigned addr, double k0, double k1, double k2, double k3) {
   static_assert(R >= 1 && R <= 3, "register 0 is always final");
@@ -535,6 +546,9 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
   request(0);
   double* cl = carry + lane;
   const unsigned cl_addr = (unsigned)(uintptr_t)cl;   // (the low half of a shared-aperture address is the LDS offset)
+  // where this lane reads slot s of a pair's carry: the lane group that stored register s + 1 as final reads the zero slot
+  const unsigned cl_in[4] = {cl_addr + (kk == 3 ? 3u * 512u : 0u), cl_addr + (kk == 2 ? 2u * 512u : 0u),
+                             cl_addr + (kk == 1 ? 1u * 512u : 0u), cl_addr};
 #pragma unroll 1
   for (int es = 0; es < n_seq; ++es) {
     // S1
@@ -616,10 +630,10 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       };
       // the carry of the four pairs (a1, b1): requested before the vector work, waited for after it
       double K0[4], K1[4], K2[4], K3[4];
-      t3_carry_in_0<b1>(cl_addr, K0);
-      t3_carry_in_1<b1>(cl_addr, K1);
-      t3_carry_in_2<b1>(cl_addr, K2);
-      t3_carry_in_3<b1>(cl_addr, K3);
+      t3_carry_in_0<b1>(cl_in, K0);
+      t3_carry_in_1<b1>(cl_in, K1);
+      t3_carry_in_2<b1>(cl_in, K2);
+      t3_carry_in_3<b1>(cl_in, K3);
       {
         double Em[4][NB];
         s2(std::false_type{}, Em);
@@ -648,22 +662,21 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       }
       // register r of this lane: (a2 = r, b2 = (r + kk) & 3), column (a0 = pa, b0 = pb).  Final: a2 = 0 (register 0, every
       // lane) or b2 = 0 (register 4 - kk of lane groups 1..3); the pairs (a2 >= 1, b2 >= 1) go on to the next element as its
-      // (a2 - 1, b2 - 1): register r -> slot r - 1 of the carry.  So register r >= 1 is EITHER stored (the lane group with
-      // b2 = 0) OR carried (the others) -- under execution masks, no selects; the carry slots of the storing lane group
-      // stay at the zero they were given before the loop.
+      // (a2 - 1, b2 - 1): register r -> slot r - 1 of the carry.  Register r >= 1 is stored by the lane group with b2 = 0
+      // (under its execution mask: no selects) and written to the carry by every lane; the next element's read skips
+      // what the storing lane group wrote (t3_carry_in).
       out0[0 * 4 * 192 + b1 * 16] = K0[0];
       out0[1 * 4 * 192 + b1 * 16] = K1[0];
       out0[2 * 4 * 192 + b1 * 16] = K2[0];
       out0[3 * 4 * 192 + b1 * 16] = K3[0];
       t3_for(std::make_integer_sequence<int, 3>{}, [&](auto rr_c) {
         constexpr int r = decltype(rr_c)::value + 1;
+        t3_carry_out<b1, r>(cl_addr, K0[r], K1[r], K2[r], K3[r]);   // (every lane: see t3_carry_in)
         if (kk == 4 - r) {
           out1[0 * 4 * 48 + b1 * 4] = K0[r];
           out1[1 * 4 * 48 + b1 * 4] = K1[r];
           out1[2 * 4 * 48 + b1 * 4] = K2[r];
           out1[3 * 4 * 48 + b1 * 4] = K3[r];
-        } else {
-          t3_carry_out<b1, r>(cl_addr, K0[r], K1[r], K2[r], K3[r]);
         }
       });
     });
