@@ -512,12 +512,17 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
   const int vq0 = c16 < 4 ? c16 : 4;
   const int vq1 = c16 < 4 ? 4 : (c16 == 5 ? 3 : (c16 == 9 ? 4 : c16 / 4 - 1));
   const int ptV = vrow ? vq0 + NQ * vq1 : 0;
-  const int offU0 = ptU + NQ * NQ * kk, offU1 = ptU + NQ * NQ * (NQ - 1);
-  const int offV0 = ptV + NQ * NQ * kk, offV1 = ptV + NQ * NQ * (NQ - 1);
+  const int offU0 = ptU + NQ * NQ * kk, offV0 = ptV + NQ * NQ * kk;
+  // second k-step (q2 = 4, one live k): ONE operand register serves both tiles -- lane group 0 holds tile U's points,
+  // lane group 1 tile V's, and the B operands of the two instructions are zero outside lane group 0 / 1 (27 record
+  // loads per element instead of 36: a load costs the CU's address unit its 16 cycles whatever it fetches)
+  const int offX1 = (kk == 1 ? ptV : ptU) + NQ * NQ * (NQ - 1);
 
   const int64_t e0 = eu + (int64_t)p.box_n[0] * ev;
   const t3_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
-  double aop[9][4], t2[2][4];   // operands of the element about to be contracted: Ahat values, raw direction-2 tables
+  // operands of the element about to be contracted: Ahat values [mn][tile U first k-step, second k-step of BOTH tiles, tile V
+  // first k-step], raw direction-2 tables
+  double aop[9][3], t2[2][4];
   auto request = [&](int es) {
     const int64_t e = e0 + e_step * es;
     const double* rec = p.scratch_pt + e * (int64_t)(T3_REC * PS) + (int64_t)I * 27 * PS;
@@ -528,9 +533,8 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       // every lane loads a real (finite) value: the lanes that carry no point meet a zero B operand (second k-step)
       // or feed rows of the result that nothing reads
       aop[mn][0] = f[offU0];
-      aop[mn][1] = f[offU1];
+      aop[mn][1] = f[offX1];
       aop[mn][2] = f[offV0];
-      aop[mn][3] = f[offV1];
     }
     const double* B2 = p.tabB[2] + (int64_t)(p.box_begin[2] + es) * NB * NQ;
     const double* D2 = p.tabD[2] + (int64_t)(p.box_begin[2] + es) * NB * NQ;
@@ -552,12 +556,14 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
 #pragma unroll 1
   for (int es = 0; es < n_seq; ++es) {
     // S1
-    double bS2[4][2];
+    double bS2[4], bS2U[4], bS2V[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-        bS2[v][s] = (s == 0 || kk == 0) ? ((v & 1) ? t2[s][1] : t2[s][0]) * ((v & 2) ? t2[s][3] : t2[s][2]) : 0.0;
+    for (int v = 0; v < 4; ++v) {
+      bS2[v] = ((v & 1) ? t2[0][1] : t2[0][0]) * ((v & 2) ? t2[0][3] : t2[0][2]);
+      const double x = ((v & 1) ? t2[1][1] : t2[1][0]) * ((v & 2) ? t2[1][3] : t2[1][2]);
+      bS2U[v] = kk == 0 ? x : 0.0;
+      bS2V[v] = kk == 1 ? x : 0.0;
+    }
     // (written as asm to pin the register files: the results, which the vector pipe reads four times each, in the
     // architectural registers; the prefetched record values, which only these instructions read, in the accumulation
     // file -- a value on the wrong side costs a v_accvgpr move of 7.7 cycles per half, scratch/issue_bench.hip)
@@ -566,15 +572,15 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
     for (int mn = 0; mn < 9; ++mn) {
       const int m = mn / 3, n = mn % 3;
       const int v2 = (m == 2 ? 1 : 0) + (n == 2 ? 2 : 0);
-      asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(DU[mn]) : "a"(aop[mn][0]), "v"(bS2[v2][0]));
-      asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(DV[mn]) : "a"(aop[mn][2]), "v"(bS2[v2][0]));
+      asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(DU[mn]) : "a"(aop[mn][0]), "v"(bS2[v2]));
+      asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(DV[mn]) : "a"(aop[mn][2]), "v"(bS2[v2]));
     }
 #pragma unroll
     for (int mn = 0; mn < 9; ++mn) {
       const int m = mn / 3, n = mn % 3;
       const int v2 = (m == 2 ? 1 : 0) + (n == 2 ? 2 : 0);
-      asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(DU[mn]) : "a"(aop[mn][1]), "v"(bS2[v2][1]));
-      asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(DV[mn]) : "a"(aop[mn][3]), "v"(bS2[v2][1]));
+      asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(DU[mn]) : "a"(aop[mn][1]), "v"(bS2U[v2]));
+      asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(DV[mn]) : "a"(aop[mn][1]), "v"(bS2V[v2]));
     }
     // the matrix results are read by the vector pipe from here on: the wait states the compiler would have placed
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
