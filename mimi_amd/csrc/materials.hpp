@@ -80,7 +80,9 @@ MH_DEV double thermo_contribution(const MaterialDev& md, double T) {
 MH_DEV double rate_contribution(const mimi_hip_material& m, double rate) {
   if (m.hardening >= MIMI_HIP_HARD_JC_RATE) {
     double v = 1.0;
-    if (rate > m.eps0_dot) v += m.C * log(rate / m.eps0_dot);
+    // (C == 0 -- the reference's tests never set C, SURVEY 8c: 1 + 0 log(..) is 1 to the bit; the logarithm, ~150
+    // instructions in every iteration of the return-map Newton, is skipped)
+    if (m.C != 0.0 && rate > m.eps0_dot) v += m.C * log(rate / m.eps0_dot);
     return v;
   }
   return 1.0;
@@ -92,8 +94,11 @@ MH_DEV double rate_contribution_derivative(const mimi_hip_material& m, double ra
 }
 
 // utils/ad.inl:263-279: pow(x, n) = x * x^(n-1), derivative n * x^(n-1) * x'
+// (x^(n-1) as exp((n-1) log x) for x > 0: the library pow carries the logarithm in extended precision to stay under one
+// ulp for every argument -- about 400 instructions, inside every iteration of the return-map Newton; exp o log is good
+// to |(n-1) ln x| ulp, < 2e-15 relative for the plastic strains that occur, far inside the 1e-9 / 1e-11 bars)
 MH_DEV Dual dual_pow(Dual b, double power) {
-  const double tmp = pow(b.v, power - 1.0);
+  const double tmp = b.v > 0.0 ? exp((power - 1.0) * log(b.v)) : pow(b.v, power - 1.0);
   return Dual{b.v * tmp, b.d * (power * tmp)};
 }
 
