@@ -1,4 +1,4 @@
-"""profiles/r02_traffic.json from rocprofv3 PMC passes (run on the GPU box by scratch/profile_round.sh).
+"""profiles/r03_traffic.json from rocprofv3 PMC passes (run on the GPU box by scratch/profile_round.sh).
 usage: python scratch/make_traffic_json.py OUT.json KEY:DIR_PIPE:DIR_FETCH:DIR_WRITE:ELEMENTS:B_ALG [...]
 Per kernel and dispatch: FETCH_SIZE (KB, doubled: gfx950 tallies 128-B requests at 64 B -- MI355X guide, HBM section; the
 factor holds for this code's 8-byte per-lane accesses, profiles/r01_pmc_calibration.txt), WRITE_SIZE (KB, exact),
