@@ -294,13 +294,27 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols)
     {
       if (it >= 1) wgs_flush_final(lane, st_of(W), block_of(it - 1), W);
       const double* tab = lds + L::off_tab + (it & 1) * 6 * NB * NQ;
-      {
+      // the tables of directions 0 and 1 belong to the element COLUMN: read (24 LDS reads, 48 v_readfirstlane, the pair
+      // products of direction 0) at the first element of a unit only -- every vector instruction of a contraction wave
+      // is on the kernel's critical path; direction 2 changes with every element
+      if (it % sl == 0) {
         const double Ba = tab_ptr<P>(tab, 0, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 0, 1)[mra * NQ + mk];
         const double Bb = tab_ptr<P>(tab, 0, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 0, 1)[mrb * NQ + mk];
         aS0[0] = mrow_ok ? Ba * Bb : 0.0;
         aS0[1] = mrow_ok ? Da * Bb : 0.0;
         aS0[2] = mrow_ok ? Ba * Db : 0.0;
         aS0[3] = mrow_ok ? Da * Db : 0.0;
+#pragma unroll
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+          for (int q1 = 0; q1 < NQ; ++q1) {
+            const unsigned long long vb = __double_as_longlong(tab_ptr<P>(tab, 1, 0)[a * NQ + q1]);
+            const unsigned long long vd = __double_as_longlong(tab_ptr<P>(tab, 1, 1)[a * NQ + q1]);
+            const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)vb), bhi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
+            const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)vd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(vd >> 32));
+            uB1[a][q1] = __longlong_as_double(((unsigned long long)bhi << 32) | blo);
+            uD1[a][q1] = __longlong_as_double(((unsigned long long)dhi << 32) | dlo);
+          }
       }
       {
         const double Ba = tab_ptr<P>(tab, 2, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 2, 1)[mra * NQ + mk];
@@ -310,17 +324,6 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols)
         aS2[2] = mrow_ok ? Ba * Db : 0.0;
         aS2[3] = mrow_ok ? Da * Db : 0.0;
       }
-#pragma unroll
-      for (int a = 0; a < NB; ++a)
-#pragma unroll
-        for (int q1 = 0; q1 < NQ; ++q1) {
-          const unsigned long long vb = __double_as_longlong(tab_ptr<P>(tab, 1, 0)[a * NQ + q1]);
-          const unsigned long long vd = __double_as_longlong(tab_ptr<P>(tab, 1, 1)[a * NQ + q1]);
-          const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)vb), bhi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
-          const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)vd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(vd >> 32));
-          uB1[a][q1] = __longlong_as_double(((unsigned long long)bhi << 32) | blo);
-          uD1[a][q1] = __longlong_as_double(((unsigned long long)dhi << 32) | dlo);
-        }
       double ah[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k) ah[k] = AH0[k * NQ3 + lane];
