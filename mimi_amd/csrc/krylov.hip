@@ -61,36 +61,100 @@ __device__ __forceinline__ double kr_total(const double* partial, double* sh) {
   return t;
 }
 
-// y = Dinv (A x) (or A x when dinv == nullptr; y = Dinv (b - A x) when b != nullptr): one wave per row
-__global__ __launch_bounds__(256) void kr_spmv_kernel(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                      const double* __restrict__ val, const double* __restrict__ x,
-                                                      const double* __restrict__ b, const double* __restrict__ dinv,
-                                                      double* __restrict__ y) {
+// The products of one wave: ROWS consecutive rows that share ONE column list (ROWS = 3: the three dofs of a node in the
+// byVDIM numbering of py_nonlinear_solid.cpp:63, whose CSR rows have identical columns; ROWS = 1: any CSR matrix).  The
+// column indices and the gathered x are read once for the ROWS rows; two entries per lane are in flight per trip.  Every
+// lane adds its entries in increasing position and the lanes are combined by the same shuffle tree for both values of
+// ROWS, so a row's sum does not depend on which form ran.
+template<int ROWS>
+__device__ __forceinline__ void kr_row_products(int64_t row0, int lane, const int64_t* __restrict__ rowptr,
+                                                const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                const double* __restrict__ x, double (&s)[ROWS]) {
+  const double* v[ROWS];
+  const int64_t beg = rowptr[row0];
+  const int len = (int)(rowptr[row0 + 1] - beg);
+#pragma unroll
+  for (int j = 0; j < ROWS; ++j) {
+    v[j] = val + (j == 0 ? beg : rowptr[row0 + j]);
+    s[j] = 0.0;
+  }
+  const int32_t* c = col + beg;
+  int k = lane;
+  for (; k + 64 < len; k += 128) {
+    const int32_t c0 = c[k], c1 = c[k + 64];
+    double a0[ROWS], a1[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+      a0[j] = v[j][k];
+      a1[j] = v[j][k + 64];
+    }
+    const double x0 = x[c0], x1 = x[c1];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) s[j] = __builtin_fma(a1[j], x1, __builtin_fma(a0[j], x0, s[j]));
+  }
+  if (k < len) {
+    const double x0 = x[c[k]];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) s[j] = __builtin_fma(v[j][k], x0, s[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < ROWS; ++j) s[j] = kr_wave_sum(s[j]);
+}
+
+// y = Dinv (A x) (or A x when dinv == nullptr; y = Dinv (b - A x) when b != nullptr): one wave per unit of ROWS rows
+template<int ROWS>
+__global__ __launch_bounds__(256) void kr_spmv_kernel(int64_t n_units, const int64_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                      const double* __restrict__ x, const double* __restrict__ b,
+                                                      const double* __restrict__ dinv, double* __restrict__ y) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n) return;
-  const int64_t beg = rowptr[row], end = rowptr[row + 1];
-  double s = 0.0;
-  for (int64_t k = beg + lane; k < end; k += 64) s += val[k] * x[col[k]];
-  s = kr_wave_sum(s);
-  if (lane == 0) {
-    if (b) s = b[row] - s;
-    y[row] = dinv ? dinv[row] * s : s;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= n_units) return;
+  const int64_t row0 = unit * ROWS;
+  double s[ROWS];
+  kr_row_products<ROWS>(row0, lane, rowptr, col, val, x, s);
+  if (lane < ROWS) {
+    double t = s[0];
+#pragma unroll
+    for (int j = 1; j < ROWS; ++j) t = lane == j ? s[j] : t;
+    if (b) t = b[row0 + lane] - t;
+    y[row0 + lane] = dinv ? dinv[row0 + lane] * t : t;
   }
 }
 
-// y += alpha A x (mfem::SparseMatrix::AddMult): one wave per row
-__global__ __launch_bounds__(256) void kr_add_mult_kernel(int64_t n, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                          const double* __restrict__ val, const double* __restrict__ x, double alpha,
-                                                          double* __restrict__ y) {
+// y += alpha A x (mfem::SparseMatrix::AddMult)
+template<int ROWS>
+__global__ __launch_bounds__(256) void kr_add_mult_kernel(int64_t n_units, const int64_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ col, const double* __restrict__ val,
+                                                          const double* __restrict__ x, double alpha, double* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= n_units) return;
+  const int64_t row0 = unit * ROWS;
+  double s[ROWS];
+  kr_row_products<ROWS>(row0, lane, rowptr, col, val, x, s);
+  if (lane < ROWS) {
+    double t = s[0];
+#pragma unroll
+    for (int j = 1; j < ROWS; ++j) t = lane == j ? s[j] : t;
+    y[row0 + lane] += alpha * t;
+  }
+}
+
+// do rows g b, ..., g b + g - 1 hold the same column list for every b?  One wave per row that is not the first of its
+// group; a difference sets `bit` of *status
+__global__ __launch_bounds__(256) void kr_groups_kernel(int64_t n, int g, const int64_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col, int bit, int* __restrict__ status) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n) return;
-  const int64_t beg = rowptr[row], end = rowptr[row + 1];
-  double s = 0.0;
-  for (int64_t k = beg + lane; k < end; k += 64) s += val[k] * x[col[k]];
-  s = kr_wave_sum(s);
-  if (lane == 0) y[row] += alpha * s;
+  if (row >= n || row % g == 0) return;
+  const int64_t first = row - row % g;
+  const int64_t beg = rowptr[row], beg0 = rowptr[first];
+  const int64_t len = rowptr[row + 1] - beg;
+  bool differ = len != rowptr[first + 1] - beg0;
+  if (!differ)
+    for (int64_t k = lane; k < len; k += 64) differ |= col[beg + k] != col[beg0 + k];
+  if (differ) atomicOr(status, bit);
 }
 
 // dinv[row] = 1 / A(row, row)   (mfem::DSmoother, type 0, scale 1)
@@ -235,9 +299,27 @@ struct mimi_hip_linear_s {
   const int32_t* col = nullptr;
   DeviceBuffer<unsigned char> is_ess;
   int64_t n_ess = 0;
+  int group = 1;          // rows g b .. g b + g - 1 share their column list (kr_groups_kernel; g = 3, 2 or 1): read once per group
   DeviceBuffer<double> dinv, V, w, r, partials, totals, ycoef, stage_val, stage_b, stage_x;
   int* status_dev = nullptr;
+  double* column_host[2] = {nullptr, nullptr};   // pinned: the Hessenberg column of the step before last and of the last one
+  hipEvent_t column_ready[2] = {nullptr, nullptr};
+  int column_cap = 0;
+  void reserve_columns(int count) {
+    if (count <= column_cap) return;
+    for (int k = 0; k < 2; ++k) {
+      if (column_host[k]) MH_HIP(hipHostFree(column_host[k]));
+      column_host[k] = nullptr;
+      MH_HIP(hipHostMalloc(reinterpret_cast<void**>(&column_host[k]), sizeof(double) * count, hipHostMallocDefault));
+      if (!column_ready[k]) MH_HIP(hipEventCreateWithFlags(&column_ready[k], hipEventDisableTiming));
+    }
+    column_cap = count;
+  }
   ~mimi_hip_linear_s() {
+    for (int k = 0; k < 2; ++k) {
+      if (column_host[k]) (void)hipHostFree(column_host[k]);
+      if (column_ready[k]) (void)hipEventDestroy(column_ready[k]);
+    }
     if (status_dev) (void)hipFree(status_dev);
     if (own_stream) (void)hipStreamDestroy(own_stream);
   }
@@ -260,8 +342,15 @@ int guarded_k(F&& f) {
 }
 
 void spmv(mimi_hip_linear_s* h, const double* val, const double* x, const double* b, const double* dinv, double* y) {
-  hipLaunchKernelGGL(kr_spmv_kernel, dim3((unsigned)((h->n + 3) / 4)), dim3(256), 0, h->stream, h->n, h->rowptr, h->col, val, x, b,
-                     dinv, y);
+  if (h->group == 3)
+    hipLaunchKernelGGL(kr_spmv_kernel<3>, dim3((unsigned)((h->n / 3 + 3) / 4)), dim3(256), 0, h->stream, h->n / 3, h->rowptr, h->col,
+                       val, x, b, dinv, y);
+  else if (h->group == 2)
+    hipLaunchKernelGGL(kr_spmv_kernel<2>, dim3((unsigned)((h->n / 2 + 3) / 4)), dim3(256), 0, h->stream, h->n / 2, h->rowptr, h->col,
+                       val, x, b, dinv, y);
+  else
+    hipLaunchKernelGGL(kr_spmv_kernel<1>, dim3((unsigned)((h->n + 3) / 4)), dim3(256), 0, h->stream, h->n, h->rowptr, h->col, val, x,
+                       b, dinv, y);
   MH_HIP(hipGetLastError());
 }
 
@@ -308,6 +397,15 @@ int mimi_hip_linear_create(int64_t n, const int64_t* csr_rowptr, const int32_t* 
     MH_HIP(hipMemcpyAsync(&status, h->status_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     MH_HIP(hipStreamSynchronize(h->stream));
     if (status) fail("CSR pattern has a row without a diagonal entry");
+    // the dofs of a node (byVDIM numbering) have identical rows in the pattern the integrators assemble into
+    for (int g = 3; g >= 2; --g)
+      if (n % g == 0)
+        hipLaunchKernelGGL(kr_groups_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, h->stream, n, g, h->rowptr, h->col, 1 << g,
+                           h->status_dev);
+    MH_HIP(hipGetLastError());
+    MH_HIP(hipMemcpyAsync(&status, h->status_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    MH_HIP(hipStreamSynchronize(h->stream));
+    h->group = (n % 3 == 0 && !(status & 8)) ? 3 : (n % 2 == 0 && !(status & 4)) ? 2 : 1;
     h->is_ess.resize((size_t)n);
     MH_HIP(hipMemsetAsync(h->is_ess.ptr, 0, (size_t)n, h->stream));
     h->n_ess = n_ess;
@@ -371,8 +469,15 @@ int mimi_hip_linear_add_mult(mimi_hip_linear_t h, const double* A_values, const 
     Mirror<double> mA = Mirror<double>::in(A_values, (size_t)h->nnz, h->stage_val, h->stream);
     Mirror<double> mx = Mirror<double>::in(x, (size_t)h->n, h->stage_x, h->stream);
     Mirror<double> my = Mirror<double>::inout(y, (size_t)h->n, h->stage_b, h->stream);
-    hipLaunchKernelGGL(kr_add_mult_kernel, dim3((unsigned)((h->n + 3) / 4)), dim3(256), 0, h->stream, h->n, h->rowptr, h->col, mA.dev,
-                       mx.dev, alpha, my.dev);
+    if (h->group == 3)
+      hipLaunchKernelGGL(kr_add_mult_kernel<3>, dim3((unsigned)((h->n / 3 + 3) / 4)), dim3(256), 0, h->stream, h->n / 3, h->rowptr,
+                         h->col, mA.dev, mx.dev, alpha, my.dev);
+    else if (h->group == 2)
+      hipLaunchKernelGGL(kr_add_mult_kernel<2>, dim3((unsigned)((h->n / 2 + 3) / 4)), dim3(256), 0, h->stream, h->n / 2, h->rowptr,
+                         h->col, mA.dev, mx.dev, alpha, my.dev);
+    else
+      hipLaunchKernelGGL(kr_add_mult_kernel<1>, dim3((unsigned)((h->n + 3) / 4)), dim3(256), 0, h->stream, h->n, h->rowptr, h->col,
+                         mA.dev, mx.dev, alpha, my.dev);
     MH_HIP(hipGetLastError());
     my.finish(h->stream);
     if (mA.host || mx.host || my.host) MH_HIP(hipStreamSynchronize(h->stream));
@@ -396,6 +501,7 @@ int mimi_hip_linear_gmres(mimi_hip_linear_t h, const double* A_values, const dou
     h->partials.resize((size_t)(kdim + 2) * KR_BLOCKS);
     h->totals.resize((size_t)(kdim + 2));
     h->ycoef.resize((size_t)kdim);
+    h->reserve_columns(kdim + 2);
     const double* dinv = nullptr;
     if (use_jacobi) {
       h->dinv.resize((size_t)n);
@@ -408,7 +514,7 @@ int mimi_hip_linear_gmres(mimi_hip_linear_t h, const double* A_values, const dou
     double* w = h->w.ptr;
     double* r = h->r.ptr;
     double* part = h->partials.ptr;
-    std::vector<double> H((size_t)(kdim + 1) * kdim, 0.0), sv(kdim + 1, 0.0), cs(kdim + 1, 0.0), sn(kdim + 1, 0.0), col(kdim + 2),
+    std::vector<double> H((size_t)(kdim + 1) * kdim, 0.0), sv(kdim + 1, 0.0), cs(kdim + 1, 0.0), sn(kdim + 1, 0.0),
         y(kdim);
     auto Hat = [&](int i, int j) -> double& { return H[(size_t)i + (size_t)j * (kdim + 1)]; };
     auto norm_of = [&](const double* vec) -> double {   // vec also goes to `part[0..)` as its squared norm
@@ -452,30 +558,40 @@ int mimi_hip_linear_gmres(mimi_hip_linear_t h, const double* A_values, const dou
       finish(0, beta, true);
       return;
     }
+    // One Arnoldi step on the stream: w = M A v_i, the i + 2 modified Gram-Schmidt stages (stage k subtracts
+    // h_{k-1} v_{k-1} and forms h_k = w . v_k; the last one forms ||w||^2), v_{i+1}, and the Hessenberg column into
+    // pinned host memory.  Nothing here waits for the host, so step i + 1 is launched BEFORE the host reads column i:
+    // the round trip of the column is hidden behind the next step, and when column i ends the solve the step that was
+    // launched ahead is simply not used (the update reads v_0 .. v_i only).
+    auto launch_step = [&](int i) {
+      spmv(h, mA.dev, V + (int64_t)i * n, nullptr, dinv, w);
+      for (int k = 0; k <= i + 1; ++k) {
+        const double* v_prev = k > 0 ? V + (int64_t)(k - 1) * n : nullptr;
+        const double* p_prev = k > 0 ? part + (int64_t)(k - 1) * KR_BLOCKS : nullptr;
+        const double* v_next = k <= i ? V + (int64_t)k * n : w;
+        hipLaunchKernelGGL(kr_mgs_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, w, v_prev, p_prev, v_next,
+                           part + (int64_t)k * KR_BLOCKS);
+      }
+      hipLaunchKernelGGL(kr_normalize_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, w, part + (int64_t)(i + 1) * KR_BLOCKS,
+                         V + (int64_t)(i + 1) * n);
+      hipLaunchKernelGGL(kr_totals_kernel, dim3(i + 2), dim3(KR_THREADS), 0, s, part, h->totals.ptr);
+      MH_HIP(hipGetLastError());
+      MH_HIP(hipMemcpyAsync(h->column_host[i & 1], h->totals.ptr, sizeof(double) * (i + 2), hipMemcpyDeviceToHost, s));
+      MH_HIP(hipEventRecord(h->column_ready[i & 1], s));
+    };
     int j = 1;
     while (j <= max_iter) {
       // v_0 = r / beta (partials of ||r||^2 are in part[0..))
       hipLaunchKernelGGL(kr_normalize_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, r, part, V);
       std::fill(sv.begin(), sv.end(), 0.0);
       sv[0] = beta;
+      const int steps = std::min(kdim, max_iter - j + 1);   // of this cycle, unless one of them converges
+      launch_step(0);
       int i = 0;
-      for (; i < kdim && j <= max_iter; ++i, ++j) {
-        // w = M A v_i
-        spmv(h, mA.dev, V + (int64_t)i * n, nullptr, dinv, w);
-        // modified Gram-Schmidt: stage k subtracts h_{k-1} v_{k-1} and forms h_k = w . v_k; the last stage forms ||w||^2
-        for (int k = 0; k <= i + 1; ++k) {
-          const double* v_prev = k > 0 ? V + (int64_t)(k - 1) * n : nullptr;
-          const double* p_prev = k > 0 ? part + (int64_t)(k - 1) * KR_BLOCKS : nullptr;
-          const double* v_next = k <= i ? V + (int64_t)k * n : w;
-          hipLaunchKernelGGL(kr_mgs_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, w, v_prev, p_prev, v_next,
-                             part + (int64_t)k * KR_BLOCKS);
-        }
-        hipLaunchKernelGGL(kr_normalize_kernel, dim3(KR_BLOCKS), dim3(KR_THREADS), 0, s, n, w, part + (int64_t)(i + 1) * KR_BLOCKS,
-                           V + (int64_t)(i + 1) * n);
-        hipLaunchKernelGGL(kr_totals_kernel, dim3(i + 2), dim3(KR_THREADS), 0, s, part, h->totals.ptr);
-        MH_HIP(hipGetLastError());
-        MH_HIP(hipMemcpyAsync(col.data(), h->totals.ptr, sizeof(double) * (i + 2), hipMemcpyDeviceToHost, s));
-        MH_HIP(hipStreamSynchronize(s));
+      for (; i < steps; ++i, ++j) {
+        if (i + 1 < steps) launch_step(i + 1);
+        MH_HIP(hipEventSynchronize(h->column_ready[i & 1]));
+        const double* col = h->column_host[i & 1];
         for (int k = 0; k <= i; ++k) Hat(k, i) = col[k];
         Hat(i + 1, i) = std::sqrt(col[i + 1]);
         // Givens rotations (GMRESSolver: ApplyPlaneRotation / GeneratePlaneRotation)
