@@ -74,7 +74,7 @@ EXPORTS = [
     "mimi_hip_contact_last_history", "mimi_hip_contact_get_pressure",
     "mimi_hip_contact_update_body", "mimi_hip_contact_gap_area", "mimi_hip_contact_marked_nodes", "mimi_hip_contact_nodal",
     "mimi_hip_contact_add_residual_from_nodal",
-    "mimi_hip_linear_create", "mimi_hip_linear_destroy", "mimi_hip_linear_set_stream", "mimi_hip_linear_eliminate",
+    "mimi_hip_linear_create", "mimi_hip_linear_destroy", "mimi_hip_linear_set_stream", "mimi_hip_linear_info", "mimi_hip_linear_eliminate",
     "mimi_hip_linear_add_mult",
     "mimi_hip_linear_gmres", "mimi_hip_linear_cg",
     "mimi_hip_domain_integrate", "mimi_hip_domain_gather",
@@ -170,6 +170,8 @@ def lib():
     L.mimi_hip_linear_create.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
     L.mimi_hip_linear_destroy.argtypes = [C.c_void_p]
     L.mimi_hip_linear_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.mimi_hip_linear_info.argtypes = [C.c_void_p, C.c_int]
+    L.mimi_hip_linear_info.restype = C.c_int64
     L.mimi_hip_linear_eliminate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mimi_hip_linear_add_mult.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
     L.mimi_hip_linear_gmres.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,

@@ -63,7 +63,7 @@ __device__ __forceinline__ double kr_total(const double* partial, double* sh) {
 
 // The products of one wave: ROWS consecutive rows that share ONE column list (ROWS = 3: the three dofs of a node in the
 // byVDIM numbering of py_nonlinear_solid.cpp:63, whose CSR rows have identical columns; ROWS = 1: any CSR matrix).  The
-// column indices and the gathered x are read once for the ROWS rows; two entries per lane are in flight per trip.  Every
+// column indices and the gathered x are read once for the ROWS rows; four entries per lane are in flight per trip.  Every
 // lane adds its entries in increasing position and the lanes are combined by the same shuffle tree for both values of
 // ROWS, so a row's sum does not depend on which form ran.
 template<int ROWS>
@@ -79,23 +79,24 @@ __device__ __forceinline__ void kr_row_products(int64_t row0, int lane, const in
     s[j] = 0.0;
   }
   const int32_t* c = col + beg;
-  int k = lane;
-  for (; k + 64 < len; k += 128) {
-    const int32_t c0 = c[k], c1 = c[k + 64];
-    double a0[ROWS], a1[ROWS];
+  // four entries per lane and trip, every load of the trip issued before the first product
+  for (int k0 = lane; k0 < len; k0 += 256) {
+    int32_t cc[4];
+    double a[4][ROWS], xx[4];
 #pragma unroll
-    for (int j = 0; j < ROWS; ++j) {
-      a0[j] = v[j][k];
-      a1[j] = v[j][k + 64];
-    }
-    const double x0 = x[c0], x1 = x[c1];
+    for (int u = 0; u < 4; ++u) cc[u] = k0 + 64 * u < len ? c[k0 + 64 * u] : 0;
 #pragma unroll
-    for (int j = 0; j < ROWS; ++j) s[j] = __builtin_fma(a1[j], x1, __builtin_fma(a0[j], x0, s[j]));
-  }
-  if (k < len) {
-    const double x0 = x[c[k]];
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int j = 0; j < ROWS; ++j) s[j] = __builtin_fma(v[j][k], x0, s[j]);
+      for (int j = 0; j < ROWS; ++j) a[u][j] = k0 + 64 * u < len ? v[j][k0 + 64 * u] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xx[u] = k0 + 64 * u < len ? x[cc[u]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (k0 + 64 * u < len) {
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) s[j] = __builtin_fma(a[u][j], xx[u], s[j]);
+      }
   }
 #pragma unroll
   for (int j = 0; j < ROWS; ++j) s[j] = kr_wave_sum(s[j]);
@@ -113,12 +114,12 @@ __global__ __launch_bounds__(256) void kr_spmv_kernel(int64_t n_units, const int
   const int64_t row0 = unit * ROWS;
   double s[ROWS];
   kr_row_products<ROWS>(row0, lane, rowptr, col, val, x, s);
-  if (lane < ROWS) {
-    double t = s[0];
+  if (lane == 0) {   // kr_wave_sum leaves the sums in lane 0
 #pragma unroll
-    for (int j = 1; j < ROWS; ++j) t = lane == j ? s[j] : t;
-    if (b) t = b[row0 + lane] - t;
-    y[row0 + lane] = dinv ? dinv[row0 + lane] * t : t;
+    for (int j = 0; j < ROWS; ++j) {
+      const double t = b ? b[row0 + j] - s[j] : s[j];
+      y[row0 + j] = dinv ? dinv[row0 + j] * t : t;
+    }
   }
 }
 
@@ -133,11 +134,9 @@ __global__ __launch_bounds__(256) void kr_add_mult_kernel(int64_t n_units, const
   const int64_t row0 = unit * ROWS;
   double s[ROWS];
   kr_row_products<ROWS>(row0, lane, rowptr, col, val, x, s);
-  if (lane < ROWS) {
-    double t = s[0];
+  if (lane == 0) {
 #pragma unroll
-    for (int j = 1; j < ROWS; ++j) t = lane == j ? s[j] : t;
-    y[row0 + lane] += alpha * t;
+    for (int j = 0; j < ROWS; ++j) y[row0 + j] += alpha * s[j];
   }
 }
 
@@ -188,18 +187,36 @@ __global__ __launch_bounds__(KR_THREADS) void kr_mgs_kernel(int64_t n, double* _
                                                             const double* __restrict__ partial_prev, const double* v_next,
                                                             double* __restrict__ partial_out) {
   __shared__ double sh[KR_THREADS / 64];
-  double h = 0.0;
-  if (v_prev) h = kr_total(partial_prev, sh);
-  double acc = 0.0;
+  constexpr int B = 8;   // entries of a thread whose loads are in flight together (n <= 1 M: all of them)
+  const int64_t stride = (int64_t)KR_BLOCKS * KR_THREADS;
   const bool self = (v_next == w);
-  for (int64_t i = (int64_t)blockIdx.x * KR_THREADS + threadIdx.x; i < n; i += (int64_t)KR_BLOCKS * KR_THREADS) {
-    double wi = w[i];
-    if (v_prev) {
-      wi -= h * v_prev[i];
-      w[i] = wi;
+  double h = 0.0, acc = 0.0;
+  const int64_t first = (int64_t)blockIdx.x * KR_THREADS + threadIdx.x;
+  int64_t base = first;
+  do {   // (every thread makes the first trip, entries or not: the total below holds block barriers)
+    double wv[B], pv[B], nv[B];
+#pragma unroll
+    for (int e = 0; e < B; ++e) {
+      const int64_t i = base + e * stride;
+      wv[e] = i < n ? w[i] : 0.0;
+      pv[e] = (v_prev && i < n) ? v_prev[i] : 0.0;
+      nv[e] = (!self && i < n) ? v_next[i] : 0.0;
     }
-    acc += wi * (self ? wi : v_next[i]);
-  }
+    if (v_prev && base == first) h = kr_total(partial_prev, sh);   // after the loads are issued
+#pragma unroll
+    for (int e = 0; e < B; ++e) {
+      const int64_t i = base + e * stride;
+      if (i < n) {
+        double wi = wv[e];
+        if (v_prev) {
+          wi -= h * pv[e];
+          w[i] = wi;
+        }
+        acc += wi * (self ? wi : nv[e]);
+      }
+    }
+    base += B * stride;
+  } while (base < n);
   const double t = kr_block_sum(acc, sh);
   if (threadIdx.x == 0) partial_out[blockIdx.x] = t;
 }
@@ -435,6 +452,16 @@ int mimi_hip_linear_set_stream(mimi_hip_linear_t h, void* stream) {
     if (!h) fail("null handle");
     h->stream = stream == MIMI_HIP_STREAM_NULL ? nullptr : (stream ? reinterpret_cast<hipStream_t>(stream) : h->own_stream);
   });
+}
+
+int64_t mimi_hip_linear_info(mimi_hip_linear_t h, int what) {
+  if (!h) return -1;
+  switch (what) {
+    case 0: return h->n;
+    case 1: return h->nnz;
+    case 2: return h->group;
+    default: return -1;
+  }
 }
 
 int mimi_hip_linear_eliminate(mimi_hip_linear_t h, double* r, double* A_values) {

@@ -45,6 +45,10 @@ class LinearSolver:
             check(_capi.lib().mimi_hip_linear_set_stream(self._h, C.c_void_p(s) if s else None))
             self._followed = s
 
+    def RowGroup(self):
+        """consecutive rows sharing one column list that the products read once (3, 2 or 1)"""
+        return int(_capi.lib().mimi_hip_linear_info(self._h, 2))
+
     def Eliminate(self, r=None, A_values=None):
         """r[ess] = 0; A.EliminateRowCol(ess, DIAG_ONE)"""
         self._follow_torch(r, A_values)

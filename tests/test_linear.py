@@ -144,3 +144,60 @@ def test_hip_cg_against_restatement():
     assert np.linalg.norm(A @ x - bv) <= 1e-6 * np.linalg.norm(bv)
     x2 = S.MultCG(Mv, bv, np.empty_like(bv))
     assert np.array_equal(x, x2)              # deterministic reductions
+
+
+def _vector_pattern(nx, ny, nz, vdim):
+    """CSR pattern of a vdim-vector field on an nx x ny (x nz) node grid, every node coupled to its 3 x 3 (x 3)
+    neighbourhood, byVDIM numbering (node * vdim + c): the vdim rows of a node share their column list"""
+    import itertools
+    dims = [nx, ny] + ([nz] if nz else [])
+    nodes = np.arange(int(np.prod(dims))).reshape(dims)
+    rows = []
+    for idx in itertools.product(*[range(d) for d in dims]):
+        sl = tuple(slice(max(i - 1, 0), min(i + 2, d)) for i, d in zip(idx, dims))
+        nb = np.sort(nodes[sl].ravel())
+        cols = (nb[:, None] * vdim + np.arange(vdim)[None, :]).ravel()
+        rows.extend([cols] * vdim)
+    rowptr = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int64)
+    return rowptr, np.concatenate(rows).astype(np.int32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,group", [("3d", 3), ("2d", 2), ("2d_of_3n_rows", 2), ("ragged", 1)])
+def test_hip_products_on_every_row_grouping(kind, group):
+    """the products read a node's column list once for its dofs when the rows of a node share it (csrc/krylov.hip
+    kr_row_products): the three forms against scipy, and which form the pattern got"""
+    from mimi_amd.integrators import CSRPattern
+    from mimi_amd.linear import LinearSolver
+    rng = np.random.default_rng(17)
+    if kind == "3d":
+        rowptr, col = _vector_pattern(9, 7, 6, 3)          # rows of 24 .. 81 entries: the tail and the two-per-trip loop
+    elif kind == "2d":
+        rowptr, col = _vector_pattern(23, 19, 0, 2)
+    elif kind == "2d_of_3n_rows":
+        rowptr, col = _vector_pattern(24, 15, 0, 2)        # 720 rows: divisible by 3, but grouped in pairs
+    else:
+        n = 601
+        A0 = sp.random(n, n, density=0.3, random_state=5, format="csr") + sp.eye(n, format="csr")
+        A0.sort_indices()
+        rowptr, col = A0.indptr.astype(np.int64), A0.indices.astype(np.int32)
+    n = len(rowptr) - 1
+    val = rng.standard_normal(len(col))
+    A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+    S = LinearSolver(CSRPattern(rowptr, col, len(col)))
+    assert S.RowGroup() == group
+    x = rng.standard_normal(n)
+    y0 = rng.standard_normal(n)
+    y = S.AddMult(val, x, y0.copy(), alpha=-0.75)
+    exp = y0 - 0.75 * (A @ x)
+    assert np.abs(y - exp).max() <= 1e-13 * np.abs(exp).max()
+    # the solver's own product: diagonally dominant values, GMRES without restart converges and the answer solves A x = b
+    val2 = val * 0.02
+    diag = np.flatnonzero(col == np.repeat(np.arange(n), np.diff(rowptr)))
+    assert len(diag) == n
+    val2[diag] = 4.0 + rng.random(n)
+    A2 = sp.csr_matrix((val2, col, rowptr), shape=(n, n))
+    b = rng.standard_normal(n)
+    xs = S.Mult(val2, b, np.empty(n))
+    assert S.converged_ and S.final_iter_ < 50
+    assert np.linalg.norm(A2 @ xs - b) <= 1e-7 * np.linalg.norm(b)
