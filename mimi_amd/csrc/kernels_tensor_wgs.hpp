@@ -622,6 +622,9 @@ MH_DEV void wgs_x_loop(const TensorArgs& p, double* lds, int eu, int ev, int& st
 struct WgsLane {
   int lane, grp;
   bool col_ok;
+  // 1.0 where the carried value (as held / rotated by 32 lanes) belongs into the first / second result register of this
+  // lane group, else 0.0: the carry is added by ONE fused multiply-add instead of a select and an add
+  double take_c0, take_c1;
   // compact store-transposition slots (kernels_tensor_wgs.hpp): as computed ...
   int base0, stride0, base1, basec;
   // ... and with the roles of a and b exchanged
@@ -635,6 +638,8 @@ MH_DEV WgsLane wgs_lane_constants() {
   const int col = c.lane & 15;
   c.grp = c.lane >> 4;
   c.col_ok = col < 9;
+  c.take_c0 = c.grp != 2 ? 1.0 : 0.0;
+  c.take_c1 = c.grp == 0 ? 1.0 : 0.0;
   const int a0 = c.col_ok ? col / NB : 0, b0 = c.col_ok ? col % NB : 0;
   const int grp = c.grp;
   // rows of register 0: (a2,b2) = (0,0) (0,1) (0,2) (1,0) for grp 0..3; register 1, grp 2: (2,0)
@@ -677,7 +682,9 @@ MH_DEV void wgs_contract_block(const WgsLane& lc, const double (&ah)[9], const d
   for (int mn = 0; mn < 9; ++mn) {
     const int m = mn / 3, n = mn % 3;
     const int v2 = (m == 2 ? 1 : 0) + (n == 2 ? 2 : 0);
-    D1[mn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[mn], aS2[v2], zero4, 0, 0, 0);
+    // (diagonal block: Ahat_(i m)(i n) is symmetric in (m, n) and (0, 1), (1, 0) share the table variant: one product)
+    if (MODE == 2 && mn == 3) D1[3] = D1[1];
+    else D1[mn] = __builtin_amdgcn_mfma_f64_16x16x4f64(ah[mn], aS2[v2], zero4, 0, 0, 0);
   }
   mh_d4 Kt[NB];
   auto carry_and_stage = [&](int b1) {
@@ -688,8 +695,9 @@ MH_DEV void wgs_contract_block(const WgsLane& lc, const double (&ah)[9], const d
       const double cin = C[a1b1];
       double c_rot, o2_rot;
       swap32_f64(cin, Kt[a1][2], c_rot, o2_rot);
-      const double out0 = Kt[a1][0] + (grp != 2 ? cin : 0.0);
-      const double out1 = Kt[a1][1] + (grp == 0 ? c_rot : 0.0);
+      // (the nine-block kernel, MODE 0, has no registers for the two lane masks: it keeps the select + add form)
+      const double out0 = MODE == 0 ? Kt[a1][0] + (grp != 2 ? cin : 0.0) : __builtin_fma(cin, lc.take_c0, Kt[a1][0]);
+      const double out1 = MODE == 0 ? Kt[a1][1] + (grp == 0 ? c_rot : 0.0) : __builtin_fma(c_rot, lc.take_c1, Kt[a1][1]);
       if (lc.col_ok) st_n[lc.base0 + a1 * lc.stride0 + b1 * 9 + jn] = out0;
       if (lc.col_ok && grp == 2) st_n[lc.base1 + a1 * (3 * ND) + b1 * 9 + jn] = out1;
       if (MODE == 1 || (MODE == 2 && a1 > b1)) {

@@ -41,3 +41,32 @@ def test_rehearsal_of_one_rank_over_rccl():
     assert d["ranks_rehearsed"] == 4 and d["n_gpus"] == 1 and "rehearsal" in d
     assert d["elements_on_this_rank"] == 64 * 64 * 8 // 4
     assert d["ms_per_step"] > 0.0
+
+
+@pytest.mark.parametrize("launcher", ["own", "torchrun"])
+def test_two_ranks_sharing_the_gpu_over_gloo(launcher):
+    """the N > 1 code path of bench.py end to end (slabs, two-step assembly, interface exchange, barrier + max-over-ranks
+    timing, the owned-rows check against a whole-patch assembly) with both ways of starting the ranks: bench.py's own
+    launcher and the driver's `python -m torch.distributed.run`.  Two ranks share the one GPU and exchange over gloo
+    (MIMI_BENCH_BACKEND=gloo): the timings mean nothing, the line's contract and the check do."""
+    import socket
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MIMI_BENCH_BACKEND"] = "gloo"
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg2", "--steps", "2", "--warmup", "1"]
+    if launcher == "own":
+        cmd = [sys.executable] + tail
+    else:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + tail
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["name"] == "cfg2"
+    assert abs(d["value"] - 64 * 64 * 8 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    check = d["check"]
+    assert check["residual_rel_err"] < 1e-12 and check["tangent_rel_err"] < 1e-12
