@@ -434,6 +434,19 @@ MH_DEV void t3_carry_out(unsigned addr, double k0, double k1, double k2, double 
                  ::"{a[6:7]}"(k0), "{a[14:15]}"(k1), "{a[22:23]}"(k2), "{a[30:31]}"(k3), "v"(addr), "n"((B1 * 4 + R - 1) * 512), "n"((16 + B1 * 4 + R - 1) * 512),
                  "n"((32 + B1 * 4 + R - 1) * 512), "n"((48 + B1 * 4 + R - 1) * 512) : "memory");
 }
+// The final entries with b2 = 0 -- register 4 - kk of lane groups kk = 1..3 -- of the pair column B1 of the element BEFORE:
+// they lie in the carry (every lane writes its registers 1..3 there) until this element's t3_carry_out<B1> overwrites
+// them.  One read per tile at the lane group's own slot (addr = this lane's address of slot 3 - kk) and then ONE store
+// per tile instead of three under three execution masks: a store costs the CU's address unit the same whatever its
+// mask, and the 48 masked stores per element were 1.3 of this kernel's 21.2 ms (scratch/p3_variants.sh, round 3).
+template<int B1>
+MH_DEV void t3_finals_in(unsigned addr, double (&f)[4]) {
+  asm volatile("ds_read_b64 %0, %4 offset:%5\n\tds_read_b64 %1, %4 offset:%6\n\tds_read_b64 %2, %4 offset:%7\n\t"
+               "ds_read_b64 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3])
+               : "v"(addr), "n"((B1 * 4) * 512), "n"((16 + B1 * 4) * 512), "n"((32 + B1 * 4) * 512), "n"((48 + B1 * 4) * 512)
+               : "memory");
+}
 // the wait states between a matrix write and a store / LDS read of its result (nothing is padded inside asm)
 MH_DEV void t3_results_guard() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
@@ -553,6 +566,8 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
   // where this lane reads slot s of a pair's carry: the lane group that stored register s + 1 as final reads the zero slot
   const unsigned cl_in[4] = {cl_addr + (kk == 3 ? 3u * 512u : 0u), cl_addr + (kk == 2 ? 2u * 512u : 0u),
                              cl_addr + (kk == 1 ? 1u * 512u : 0u), cl_addr};
+  const unsigned fin_addr = cl_addr + (kk == 0 ? 3u : (unsigned)(3 - kk)) * 512u;   // (lane group 0 has no such entry: the zero slot)
+  double* out1_prev = nullptr;
 #pragma unroll 1
   for (int es = 0; es < n_seq; ++es) {
     // S1
@@ -648,6 +663,15 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
         t3_s3_main_1(K1, Em[0][1], Em[1][1], Em[2][1], Em[3][1], bS0);
         t3_s3_main_2(K2, Em[0][2], Em[1][2], Em[2][2], Em[3][2], bS0);
         t3_s3_main_3(K3, Em[0][3], Em[1][3], Em[2][3], Em[3][3], bS0);
+        // behind the sixteen matrix instructions just issued: the b2 = 0 entries of the element before, LDS -> scratch
+        double fin[4];
+        t3_finals_in<b1>(fin_addr, fin);
+        if (es > 0 && kk > 0) {
+          out1_prev[0 * 4 * 48 + b1 * 4] = fin[0];
+          out1_prev[1 * 4 * 48 + b1 * 4] = fin[1];
+          out1_prev[2 * 4 * 48 + b1 * 4] = fin[2];
+          out1_prev[3 * 4 * 48 + b1 * 4] = fin[3];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       {
@@ -677,18 +701,22 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       out0[3 * 4 * 192 + b1 * 16] = K3[0];
       t3_for(std::make_integer_sequence<int, 3>{}, [&](auto rr_c) {
         constexpr int r = decltype(rr_c)::value + 1;
-        t3_carry_out<b1, r>(cl_addr, K0[r], K1[r], K2[r], K3[r]);   // (every lane: see t3_carry_in)
-        if (kk == 4 - r) {
-          out1[0 * 4 * 48 + b1 * 4] = K0[r];
-          out1[1 * 4 * 48 + b1 * 4] = K1[r];
-          out1[2 * 4 * 48 + b1 * 4] = K2[r];
-          out1[3 * 4 * 48 + b1 * 4] = K3[r];
-        }
+        t3_carry_out<b1, r>(cl_addr, K0[r], K1[r], K2[r], K3[r]);   // (every lane: see t3_carry_in, t3_finals_in)
       });
     });
+    out1_prev = out1;
   }
   // (the carry of the last element is read below through plain loads: its asm stores must have landed)
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // the b2 = 0 entries of the last element (t3_finals_in found those of every other one)
+  {
+    const double* fl = cl + (kk == 0 ? 3 : 3 - kk) * 64;
+#pragma unroll
+    for (int ab = 0; ab < 16; ++ab) {
+      const double v = fl[ab * 4 * 64];
+      if (kk > 0) out1_prev[(ab / NB) * 4 * 48 + (ab % NB) * 4] = v;
+    }
+  }
   // what the last element of the column would have passed on: rows a2 >= 1, b2 >= 1 -> the tail of (column, i)
   double* tail = p.scratch_tail + ((e0 * 3 + I) * (int64_t)T3_TAIL) + pa * 144 + J * 48 + pb;
 #pragma unroll
