@@ -447,6 +447,21 @@ MH_DEV void t3_finals_in(unsigned addr, double (&f)[4]) {
                : "v"(addr), "n"((B1 * 4) * 512), "n"((16 + B1 * 4) * 512), "n"((32 + B1 * 4) * 512), "n"((48 + B1 * 4) * 512)
                : "memory");
 }
+// S2 coefficients by DPP: a register pair holds sixteen coefficients per row of 16 lanes (lane n of the row = coefficient
+// n); `row_newbcast:N` hands every lane of a row the value of the row's lane N as the operand of the multiply-add itself --
+// at the cost of the plain instruction (4.9 cycles, scratch/issue_bench.hip; what it does: scratch/dpp_bcast.hip).  The
+// rows of 16 lanes are the lane groups kk, so the plane q0 = 4, whose coefficients differ per lane group, needs nothing
+// special.  Before: 32 LDS reads of 16 bytes per lane and pair column to fetch the same eight doubles again and again.
+template<int N>
+MH_DEV void t3_fmac_bc(double& acc, double table, double w) {   // acc += table[lane N of the row] * w
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(table), "v"(w), "n"(N));
+}
+template<int N>
+MH_DEV double t3_bc(double table) {   // table[lane N of the row] in every lane of the row
+  double c;
+  asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(c) : "v"(table), "n"(N));
+  return c;
+}
 // the wait states between a matrix write and a store / LDS read of its result (nothing is padded inside asm)
 MH_DEV void t3_results_guard() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
@@ -515,9 +530,18 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
 #pragma unroll
   for (int k = 0; k < 16 * 4; ++k) carry[k * 64 + lane] = 0.0;
   __syncthreads();
-  const double* xrow[3];
-#pragma unroll
-  for (int r = 1; r < 4; ++r) xrow[r - 1] = tl + 8 * (kk == 0 ? r - 1 : ((kk == 1 && r < 3) ? r + 2 : NQ));
+  // ... and from there into four coefficient registers (t3_fmac_bc): lane n of a row holds coefficient n & 7 = v 4 + a of
+  // slot n >> 3.  TA: slots q1 = 0, 1 of the points q0 < 4; TB: q1 = 2, 3; TC: q1 = 4 | slot 0 of the plane q0 = 4; TD: slots
+  // 1, 2 of the plane -- whose slot r holds q1 = r in lane group 0, q1 = r + 3 in lane group 1 (r < 2), zeros elsewhere
+  double TA, TB, TC, TD;
+  {
+    const int ti = lane & 15, th = ti >> 3, tk = ti & 7;
+    auto plane_row = [&](int r) -> int { return kk == 0 ? r : ((kk == 1 && r < 2) ? r + 3 : NQ); };
+    TA = tl[8 * th + tk];
+    TB = tl[8 * (2 + th) + tk];
+    TC = tl[8 * (th == 0 ? 4 : plane_row(0)) + tk];
+    TD = tl[8 * plane_row(1 + th) + tk];
+  }
 
   // S1 A operands: the points of this lane
   const int ptU = (c16 & 3) + NQ * (c16 >> 2);
@@ -615,39 +639,44 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       // of tile V, per-lane coefficients; two partial sums in lane groups 0 and 1)
       auto s2 = [&](auto extra_tag, double (&E)[4][NB]) {
         constexpr bool ex = decltype(extra_tag)::value;
-#pragma unroll
-        for (int s = 0; s < (ex ? 3 : NQ); ++s) {
+        t3_for(std::make_integer_sequence<int, (ex ? 3 : NQ)>{}, [&](auto s_c) {
+          constexpr int s = decltype(s_c)::value;
           double X[9];
 #pragma unroll
           for (int mn = 0; mn < 9; ++mn) X[mn] = ex ? DV[mn][s + 1] : (s < 4 ? DU[mn][s < 4 ? s : 0] : DV[mn][0]);
-          const double* row = ex ? xrow[s < 3 ? s : 0] : tl + 8 * s;
-          double cf[2][NB];
-#pragma unroll
-          for (int k = 0; k < 2 * NB; ++k) cf[k / NB][k % NB] = row[k];
-          const double cbB = cf[0][b1], cbD = cf[1][b1];
+          // this slot's eight coefficients [B a = 0..3, D a = 0..3]: table register and first lane
+          constexpr int slot = ex ? NQ + s : s;
+          const double T = slot < 2 ? TA : (slot < 4 ? TB : (slot < 6 ? TC : TD));
+          constexpr int cB = (slot & 1) * 8, cD = cB + 4;
           // every accumulation is ONE fused multiply-add (written out: a sum of two products added to E would cost a
           // multiply, a multiply-add and an add -- on this chip every vector instruction of the wave, fp64 or not, waits
           // for the matrix pipe and the matrix instructions for it, scratch/issue_bench.hip, so the count is the time)
+          const double cbB = t3_bc<cB + b1>(T);   // (a plain multiplication takes no DPP operand)
           const double W3 = cbB * X[0];
-          const double W1 = __builtin_fma(cbD, X[1], cbB * X[2]);
+          double W1 = cbB * X[2];
+          t3_fmac_bc<cD + b1>(W1, T, X[1]);
           const double W2a = cbB * X[3], W2b = cbB * X[6];
-          const double W0a = __builtin_fma(cbD, X[4], cbB * X[5]), W0b = __builtin_fma(cbD, X[7], cbB * X[8]);
-#pragma unroll
-          for (int a1 = 0; a1 < NB; ++a1) {
-            const double caB = cf[0][a1], caD = cf[1][a1];
-            if (s == 0) {   // (no accumulator starts from 0.0: x + 0.0 is an instruction)
+          double W0a = cbB * X[5], W0b = cbB * X[8];
+          t3_fmac_bc<cD + b1>(W0a, T, X[4]);
+          t3_fmac_bc<cD + b1>(W0b, T, X[7]);
+          t3_for(std::make_integer_sequence<int, NB>{}, [&](auto a1_c) {
+            constexpr int a1 = decltype(a1_c)::value;
+            if constexpr (s == 0) {   // (no accumulator starts from 0.0: x + 0.0 is an instruction)
+              const double caB = t3_bc<cB + a1>(T);
               E[3][a1] = caB * W3;
               E[1][a1] = caB * W1;
-              E[2][a1] = __builtin_fma(caD, W2a, caB * W2b);
-              E[0][a1] = __builtin_fma(caD, W0a, caB * W0b);
+              E[2][a1] = caB * W2b;
+              E[0][a1] = caB * W0b;
             } else {
-              E[3][a1] = __builtin_fma(caB, W3, E[3][a1]);
-              E[1][a1] = __builtin_fma(caB, W1, E[1][a1]);
-              E[2][a1] = __builtin_fma(caD, W2a, __builtin_fma(caB, W2b, E[2][a1]));
-              E[0][a1] = __builtin_fma(caD, W0a, __builtin_fma(caB, W0b, E[0][a1]));
+              t3_fmac_bc<cB + a1>(E[3][a1], T, W3);
+              t3_fmac_bc<cB + a1>(E[1][a1], T, W1);
+              t3_fmac_bc<cB + a1>(E[2][a1], T, W2b);
+              t3_fmac_bc<cB + a1>(E[0][a1], T, W0b);
             }
-          }
-        }
+            t3_fmac_bc<cD + a1>(E[2][a1], T, W2a);
+            t3_fmac_bc<cD + a1>(E[0][a1], T, W0a);
+          });
+        });
       };
       // the carry of the four pairs (a1, b1): requested before the vector work, waited for after it
       double K0[4], K1[4], K2[4], K3[4];

@@ -22,6 +22,7 @@ __device__ inline unsigned long long now() {
 //  7: global_store_dwordx2 (4 x 128-byte segments per wave instruction, from the accumulation file)
 //  8: global_load_dwordx2 into the accumulation file     9: all matrix instructions on ONE accumulator (dependent chain)
 // 10: ds_write_b64 from the accumulation file    11: global_store_dwordx2 with 16 of 64 lanes active (4 x 32-byte segments)
+// 14: v_fmac_f64 with a DPP operand (row_newbcast: lane N of the row of 16 to all lanes of the row)   15: v_mov_b64 with the same
 // 12: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks, one double of the result per lane) as the filler, NM = 0
 template<int MODE, int NM, int NF>
 __global__ void bench(unsigned long long* out, double* sink, int iters, double* buf) {
@@ -69,6 +70,8 @@ __global__ void bench(unsigned long long* out, double* sink, int iters, double* 
             if constexpr (MODE == 8) asm volatile("global_load_dwordx2 a[4:5], %0, off" ::"v"(gp) : "memory", "a4", "a5");
             if constexpr (MODE == 11) asm volatile("s_mov_b64 exec, %1\n\tglobal_store_dwordx2 %0, a[2:3], off\n\ts_mov_b64 exec, -1" ::"v"(gp2), "s"(0x000f000f000f000full) : "memory", "a2", "a3");
             if constexpr (MODE == 10) asm volatile("ds_write_b64 %0, a[2:3]" ::"v"(ldsaddr) : "memory", "a2", "a3");
+            if constexpr (MODE == 14) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(f[q]) : "v"(a), "v"(b));
+            if constexpr (MODE == 15) asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "=v"(f[q]) : "v"(a));
             if constexpr (MODE == 12) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(f[q]) : "v"(a), "v"(b));
             if constexpr (MODE == 13) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(f[0]) : "v"(a), "v"(b));
           }
@@ -147,6 +150,9 @@ int main() {
   run<11, 0, 16>("16 masked global_store (16 lanes)", d_out, d_sink);
   run<11, 4, 1>("mfma + 1 masked global_store each", d_out, d_sink);
   run<11, 4, 2>("mfma + 2 masked global_store each", d_out, d_sink);
+  run<14, 0, 16>("16 independent v_fmac_f64_dpp row_newbcast", d_out, d_sink);
+  run<15, 0, 16>("16 v_mov_b64_dpp row_newbcast", d_out, d_sink);
+  run<14, 4, 4>("mfma + 4 v_fmac_f64_dpp each", d_out, d_sink);
   run<12, 0, 16>("16 independent v_mfma_f64_4x4x4_4b", d_out, d_sink);
   run<13, 0, 16>("16 v_mfma_f64_4x4x4_4b on ONE accumulator", d_out, d_sink);
   run<10, 4, 2>("mfma + 2 ds_write_b64 each", d_out, d_sink);
