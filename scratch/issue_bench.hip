@@ -23,6 +23,7 @@ __device__ inline unsigned long long now() {
 //  8: global_load_dwordx2 into the accumulation file     9: all matrix instructions on ONE accumulator (dependent chain)
 // 10: ds_write_b64 from the accumulation file    11: global_store_dwordx2 with 16 of 64 lanes active (4 x 32-byte segments)
 // 14: v_fmac_f64 with a DPP operand (row_newbcast: lane N of the row of 16 to all lanes of the row)   15: v_mov_b64 with the same
+// 16: global_store_dwordx4 (64 lanes x 16 B contiguous = eight 128-byte lines)   17: global_store_dwordx2, one line per lane
 // 12: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks, one double of the result per lane) as the filler, NM = 0
 template<int MODE, int NM, int NF>
 __global__ void bench(unsigned long long* out, double* sink, int iters, double* buf) {
@@ -43,6 +44,9 @@ __global__ void bench(unsigned long long* out, double* sink, int iters, double* 
   double* gp = buf + ((size_t)(blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64)) * 8192 + (l & 15) + (l >> 4) * 192;
   // the masked stores of tp3_contract_kernel: lanes (pa, pb) of one lane group: 4 doubles contiguous, 4 such 384 B apart
   double* gp2 = buf + ((size_t)(blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64)) * 8192 + (l & 3) + ((l >> 4) & 3) * 48;
+  // 16 bytes per lane, contiguous over the wave (1 KB); and 8 bytes per lane, every lane its own 128-byte line
+  double* gp4 = buf + ((size_t)(blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64)) * 8192 + l * 2;
+  double* gp1 = buf + ((size_t)(blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64)) * 8192 + l * 16;
   unsigned long long t0 = now();
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -72,6 +76,8 @@ __global__ void bench(unsigned long long* out, double* sink, int iters, double* 
             if constexpr (MODE == 10) asm volatile("ds_write_b64 %0, a[2:3]" ::"v"(ldsaddr) : "memory", "a2", "a3");
             if constexpr (MODE == 14) asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(f[q]) : "v"(a), "v"(b));
             if constexpr (MODE == 15) asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "=v"(f[q]) : "v"(a));
+            if constexpr (MODE == 16) asm volatile("global_store_dwordx4 %0, a[4:7], off" ::"v"(gp4) : "memory", "a4", "a5", "a6", "a7");
+            if constexpr (MODE == 17) asm volatile("global_store_dwordx2 %0, a[2:3], off" ::"v"(gp1) : "memory", "a2", "a3");
             if constexpr (MODE == 12) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(f[q]) : "v"(a), "v"(b));
             if constexpr (MODE == 13) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(f[0]) : "v"(a), "v"(b));
           }
@@ -79,7 +85,7 @@ __global__ void bench(unsigned long long* out, double* sink, int iters, double* 
       }
     }
     if constexpr (MODE == 3 || MODE == 10) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if constexpr (MODE == 7 || MODE == 8 || MODE == 11) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (MODE == 7 || MODE == 8 || MODE == 11 || MODE == 16 || MODE == 17) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   unsigned long long t1 = now();
   double s = 0;
@@ -147,6 +153,9 @@ int main() {
   run<7, 4, 2>("mfma + 2 global_store each", d_out, d_sink);
   run<8, 4, 1>("mfma + 1 global_load each", d_out, d_sink);
   run<8, 4, 2>("mfma + 2 global_load each", d_out, d_sink);
+  run<16, 0, 16>("16 global_store_dwordx4 (1 KB contiguous)", d_out, d_sink);
+  run<16, 4, 1>("mfma + 1 global_store_dwordx4 each", d_out, d_sink);
+  run<17, 0, 16>("16 global_store_dwordx2, one line per lane", d_out, d_sink);
   run<11, 0, 16>("16 masked global_store (16 lanes)", d_out, d_sink);
   run<11, 4, 1>("mfma + 1 masked global_store each", d_out, d_sink);
   run<11, 4, 2>("mfma + 2 masked global_store each", d_out, d_sink);
