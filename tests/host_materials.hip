@@ -45,3 +45,8 @@ extern "C" int host_accumulate(const mimi_hip_material* m, double sigma_y_ref, i
     return dim == 2 ? accumulate_state<2>(md, dt, sv, 0, F) : accumulate_state<3>(md, dt, sv, 0, F);
   return dim == 2 ? accumulate_other<2>(md, dt, sv, 0, F) : accumulate_other<3>(md, dt, sv, 0, F);
 }
+
+// x^q for x > 0 as the return-map Newton evaluates it (materials.hpp pow_positive)
+extern "C" void host_pow_positive(int n, const double* x, const double* q, double* out) {
+  for (int k = 0; k < n; ++k) out[k] = pow_positive(x[k], q[k]);
+}

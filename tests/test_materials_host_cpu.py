@@ -91,3 +91,22 @@ def test_device_materials_on_host_vs_oracle(host_lib, name, dim):
         n_plastic += e.value > eqps
     if name not in ("neohook", "stvk"):
         assert n_plastic > 20      # the plastic branch was exercised
+
+
+def test_pow_positive_against_long_double_pow(host_lib):
+    """csrc/materials.hpp pow_positive: exp(q ln x) written out for the return-map Newton (hardening laws with eqps^n,
+    material_hardening.hpp:79-346).  Against numpy's long-double power over the strains and exponents that occur: the error
+    stays under 3 ulp x (|q ln x| + 1) -- the conditioning of exp(q ln x) -- i.e. under 3e-14 relative everywhere here."""
+    rng = np.random.default_rng(11)
+    n = 200000
+    x = 10.0 ** rng.uniform(-13.0, 1.0, n)
+    q = rng.uniform(-0.9, 4.0, n)
+    # the exponents of the fixtures' hardening laws, at strains from the first Newton iterate to large ones
+    x[:6], q[:6] = [1e-13, 1e-9, 1e-6, 1e-3, 0.05, 0.5], 0.2835 - 1.0
+    out = np.empty(n)
+    host_lib.host_pow_positive(n, x.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    ref = np.power(x.astype(np.longdouble), q.astype(np.longdouble))
+    rel = np.abs((out.astype(np.longdouble) - ref) / ref).astype(np.float64)
+    ulp = 1.1102230246251565e-16
+    assert np.all(rel <= 3.0 * ulp * (np.abs(q * np.log(x)) + 1.0))
+    assert rel.max() < 3e-14 and rel[:6].max() < 2e-15
