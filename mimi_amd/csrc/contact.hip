@@ -231,6 +231,12 @@ __global__ void contact_pressure_kernel(int n, const double* area, const double*
   if (i < n) pressure[i] = gap[i] / area[i] * penalty;  // mortar_contact.cpp:253-257
 }
 
+MH_DEV double contact_lane_read(double v, int l) {   // the value lane l holds, in every lane (l wave-uniform)
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, l), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), l);
+  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
 // element residual at given x_e (used by the FD mode too)
 template<int DIM>
 MH_DEV void face_residual(const ContactArgs& p, int f, const double* x_e, const double* p_e, double* R_e,
@@ -254,8 +260,8 @@ MH_DEV void face_residual(const ContactArgs& p, int f, const double* x_e, const 
   }
 }
 
-// pass 2: one thread per face (faces are few; the work per face is small): the face residual vector, its share of the
-// pressure integral / force, and -- reference-FD mode -- the face tangent block; all stored densely (contact_gather_kernel)
+// reference-FD mode of pass 2: one thread per face, the face tangent block by forward differences of the face residual
+// (stored densely: contact_gather_kernel)
 template<int DIM>
 __global__ void contact_residual_kernel(ContactArgs p, int with_grad) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -266,17 +272,13 @@ __global__ void contact_residual_kernel(ContactArgs p, int with_grad) {
     p_e[a] = p.pressure[p.local[(int64_t)f * p.n_dof + a]];
     any = any || (p_e[a] != 0.0);
   }
-  p.face_active[f] = any ? 1 : 0;
   if (!any) return;  // IsPressureZero (integrator_utils.cpp:112-119)
   double x_e[DIM * kMaxFaceDof], R_e[DIM * kMaxFaceDof];
   gather_x<DIM>(p, f, x_e);
-  double force[DIM] = {0}, pint = 0;
-  face_residual<DIM>(p, f, x_e, p_e, R_e, force, &pint);
+  face_residual<DIM>(p, f, x_e, p_e, R_e, nullptr, nullptr);
   const int NT = p.n_dof * DIM;
-  for (int k = 0; k < NT; ++k) p.face_r[(int64_t)f * NT + k] = R_e[k];      // [i][a]
-  p.face_scal[(int64_t)f * (1 + DIM)] = pint;
-#pragma unroll
-  for (int i = 0; i < DIM; ++i) p.face_scal[(int64_t)f * (1 + DIM) + 1 + i] = force[i];
+  // (the face residual, pressure integral and force are stored by contact_residual_wave_kernel in every mode, so that
+  // the history scalars do not depend on the tangent mode to the last bit; this kernel adds the difference tangent)
   if (!with_grad) return;
   double* Kf = p.face_k + (int64_t)f * NT * NT;     // row (a, i): [j][b]
   // mortar_contact.cpp:263-295: forward FD on the current POSITION, pressure frozen
@@ -296,38 +298,157 @@ __global__ void contact_residual_kernel(ContactArgs p, int with_grad) {
   }
 }
 
-// analytic frozen-pressure tangent, one WAVE per face: lane = node pair (a, b), its DIM x DIM block accumulated over the
-// quadrature points in registers (R(a,i) = -w p N_a m_i, d m / d x_bj with p frozen), stored into the face block
+// pass 2 without the reference-FD tangent, one WAVE per face: lane = quadrature point for pressure, normal and weights,
+// then lane = (i, a) for the residual entries -- summed over the points in the order of the one-thread form above, so
+// the two give the same bits (that form left 9 216 faces to 144 waves: 0.19 ms of latency at configuration 4)
+template<int DIM>
+__global__ __launch_bounds__(256) void contact_residual_wave_kernel(ContactArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (f >= p.n_faces) return;
+  const int n_dof = p.n_dof, n_q = p.n_q, NT = n_dof * DIM;
+  double pc = 0.0, xc[DIM];
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) xc[i] = 0.0;
+  if (lane < n_dof) {
+    pc = p.pressure[p.local[(int64_t)f * n_dof + lane]];
+    const int64_t node = p.dofs[(int64_t)f * n_dof + lane];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) xc[i] = p.u[node * DIM + i] + p.x_ref[node * DIM + i];
+  }
+  const bool any = __ballot(pc != 0.0) != 0;
+  if (lane == 0) p.face_active[f] = any ? 1 : 0;
+  if (!any) return;  // IsPressureZero (integrator_utils.cpp:112-119)
+  // lane q: fac = w detJ p(q), n = m / detJ
+  double fac = 0.0, nq[DIM];
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) nq[i] = 0.0;
+  {
+    const int q = lane < n_q ? lane : 0;
+    const int64_t pt = (int64_t)f * n_q + q;
+    const double* N = p.N + pt * n_dof;
+    const double* dN = p.dN + pt * n_dof * (DIM - 1);
+    double pq = 0.0, t[(DIM - 1) * DIM];
+#pragma unroll
+    for (int k = 0; k < (DIM - 1) * DIM; ++k) t[k] = 0.0;
+    for (int c = 0; c < n_dof; ++c) {
+      pq = __builtin_fma(N[c], contact_lane_read(pc, c), pq);
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) {
+        const double x = contact_lane_read(xc[i], c);
+#pragma unroll
+        for (int k = 0; k < DIM - 1; ++k) t[k * DIM + i] = __builtin_fma(x, dN[k * n_dof + c], t[k * DIM + i]);
+      }
+    }
+    double m[DIM], detJ;
+    if constexpr (DIM == 2) {
+      m[0] = t[1];
+      m[1] = -t[0];
+      detJ = sqrt(m[0] * m[0] + m[1] * m[1]);
+    } else {
+      m[0] = t[1] * t[5] - t[2] * t[4];
+      m[1] = t[2] * t[3] - t[0] * t[5];
+      m[2] = t[0] * t[4] - t[1] * t[3];
+      detJ = sqrt(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]);
+    }
+    fac = p.weight[pt] * detJ * pq;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) nq[i] = m[i] / detJ;
+  }
+  // lane k = i n_dof + a: R(a, i) = sum_q (n_i (-fac))_q N_q[a]
+  {
+    const int k = lane < NT ? lane : 0, i = k / n_dof, a = k % n_dof;
+    double R = 0.0;
+    for (int q = 0; q < n_q; ++q) {
+      const double mf = -contact_lane_read(fac, q);
+      double aw = contact_lane_read(nq[0], q) * mf;
+#pragma unroll
+      for (int ii = 1; ii < DIM; ++ii) {
+        const double v = contact_lane_read(nq[ii], q) * mf;
+        aw = i == ii ? v : aw;
+      }
+      R += aw * p.N[((int64_t)f * n_q + q) * n_dof + a];
+    }
+    if (lane < NT) p.face_r[(int64_t)f * NT + lane] = R;      // [i][a]
+  }
+  // pressure integral and force of the face: lane 0, in the order of the points
+  {
+    double pint = 0.0, force[DIM];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) force[i] = 0.0;
+    for (int q = 0; q < n_q; ++q) {
+      const double fq = contact_lane_read(fac, q);
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) force[i] += fq * contact_lane_read(nq[i], q);
+      pint += fq;
+    }
+    if (lane == 0) {
+      p.face_scal[(int64_t)f * (1 + DIM)] = pint;
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) p.face_scal[(int64_t)f * (1 + DIM) + 1 + i] = force[i];
+    }
+  }
+}
+
+// analytic frozen-pressure tangent, one WAVE per face (R(a,i) = -w p N_a m_i, d m / d x_bj with p frozen).  Stage 1, lane =
+// quadrature point: the pressure and the two surface tangents at the point, from the face's nodal values handed round by
+// lane reads (lane c holds node c).  Stage 2, lane = node pair (a, b): its DIM x DIM block accumulated over the points in
+// registers, the point's seven numbers read from the lane that computed them.  (Before: every pair lane recomputed
+// pressure and tangents of every point from private arrays -- 0.44 ms for the 9 216 faces of configuration 4.)
 template<int DIM>
 __global__ __launch_bounds__(256) void contact_tangent_kernel(ContactArgs p) {
   const int lane = threadIdx.x & 63;
   const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (f >= p.n_faces) return;
-  double p_e[kMaxFaceDof];
-  bool any = false;
-  for (int a = 0; a < p.n_dof; ++a) {
-    p_e[a] = p.pressure[p.local[(int64_t)f * p.n_dof + a]];
-    any = any || (p_e[a] != 0.0);
+  const int n_dof = p.n_dof, n_q = p.n_q;   // (<= 16 nodes; <= 64 points: checked at create)
+  // lane c < n_dof: node c of the face
+  double pc = 0.0, xc[DIM];
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) xc[i] = 0.0;
+  if (lane < n_dof) {
+    pc = p.pressure[p.local[(int64_t)f * n_dof + lane]];
+    const int64_t node = p.dofs[(int64_t)f * n_dof + lane];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) xc[i] = p.u[node * DIM + i] + p.x_ref[node * DIM + i];   // integrator_utils.cpp:80-89
   }
-  if (!any) return;  // IsPressureZero (integrator_utils.cpp:112-119)
-  double x_e[DIM * kMaxFaceDof];
-  gather_x<DIM>(p, f, x_e);
-  const int n_pairs = p.n_dof * p.n_dof, NT = p.n_dof * DIM;
+  if (__ballot(pc != 0.0) == 0) return;  // IsPressureZero (integrator_utils.cpp:112-119)
+  // stage 1: lane q < n_q
+  double wq = 0.0, tq[(DIM - 1) * DIM];
+#pragma unroll
+  for (int k = 0; k < (DIM - 1) * DIM; ++k) tq[k] = 0.0;
+  {
+    const int q = lane < n_q ? lane : 0;
+    const int64_t pt = (int64_t)f * n_q + q;
+    const double* N = p.N + pt * n_dof;
+    const double* dN = p.dN + pt * n_dof * (DIM - 1);
+    double pq = 0.0;
+    for (int c = 0; c < n_dof; ++c) {
+      pq = __builtin_fma(N[c], contact_lane_read(pc, c), pq);
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) {
+        const double x = contact_lane_read(xc[i], c);
+#pragma unroll
+        for (int k = 0; k < DIM - 1; ++k) tq[k * DIM + i] = __builtin_fma(x, dN[k * n_dof + c], tq[k * DIM + i]);
+      }
+    }
+    wq = -p.weight[pt] * pq;
+  }
+  const int n_pairs = n_dof * n_dof, NT = n_dof * DIM;
   double* Kf = p.face_k + (int64_t)f * NT * NT;
-  for (int pair = lane; pair < n_pairs; pair += 64) {
-    const int a = pair / p.n_dof, b = pair % p.n_dof;
+  for (int pair0 = 0; pair0 < n_pairs; pair0 += 64) {
+    const int pair = pair0 + lane;
+    const bool on = pair < n_pairs;
+    const int a = on ? pair / n_dof : 0, b = on ? pair % n_dof : 0;
     double acc[DIM * DIM];
 #pragma unroll
     for (int k = 0; k < DIM * DIM; ++k) acc[k] = 0.0;
-    for (int q = 0; q < p.n_q; ++q) {
-      const int64_t pt = (int64_t)f * p.n_q + q;
-      const double* N = p.N + pt * p.n_dof;
-      const double* dN = p.dN + pt * p.n_dof * (DIM - 1);
-      double pq = 0;
-      for (int c = 0; c < p.n_dof; ++c) pq += N[c] * p_e[c];
-      const double wpn = -p.weight[pt] * pq * N[a];
-      double m[DIM], t[(DIM - 1) * DIM];
-      surface_normal<DIM>(p.n_dof, x_e, dN, m, t);
+    for (int q = 0; q < n_q; ++q) {
+      const int64_t pt = (int64_t)f * n_q + q;
+      const double wpn = contact_lane_read(wq, q) * p.N[pt * n_dof + a];
+      const double* dN = p.dN + pt * n_dof * (DIM - 1);
+      double t[(DIM - 1) * DIM];
+#pragma unroll
+      for (int k = 0; k < (DIM - 1) * DIM; ++k) t[k] = contact_lane_read(tq[k], q);
 #pragma unroll
       for (int j = 0; j < DIM; ++j) {
         double dm[DIM];
@@ -339,7 +460,7 @@ __global__ __launch_bounds__(256) void contact_tangent_kernel(ContactArgs p) {
           e[j] = 1.0;
           const double* t1 = t;
           const double* t2 = t + 3;
-          const double d1 = dN[b], d2 = dN[p.n_dof + b];
+          const double d1 = dN[b], d2 = dN[n_dof + b];
           dm[0] = d1 * (e[1] * t2[2] - e[2] * t2[1]) + d2 * (t1[1] * e[2] - t1[2] * e[1]);
           dm[1] = d1 * (e[2] * t2[0] - e[0] * t2[2]) + d2 * (t1[2] * e[0] - t1[0] * e[2]);
           dm[2] = d1 * (e[0] * t2[1] - e[1] * t2[0]) + d2 * (t1[0] * e[1] - t1[1] * e[0]);
@@ -348,10 +469,12 @@ __global__ __launch_bounds__(256) void contact_tangent_kernel(ContactArgs p) {
         for (int i = 0; i < DIM; ++i) acc[i * DIM + j] += wpn * dm[i];
       }
     }
+    if (on) {
 #pragma unroll
-    for (int i = 0; i < DIM; ++i)
+      for (int i = 0; i < DIM; ++i)
 #pragma unroll
-      for (int j = 0; j < DIM; ++j) Kf[(a * DIM + i) * NT + j * p.n_dof + b] = acc[i * DIM + j];
+        for (int j = 0; j < DIM; ++j) Kf[(a * DIM + i) * NT + j * n_dof + b] = acc[i * DIM + j];
+    }
   }
 }
 
@@ -606,8 +729,13 @@ static void contact_pass2(mimi_hip_contact_s* h, const double* u_dev, double* r_
   // analytic tangent: the residual by the face-per-thread kernel, the tangent by one wave per face
   const bool wave_tangent = with_grad && h->mode != MIMI_HIP_TANGENT_REFERENCE_FD;
   const int grad_flag = (with_grad && !wave_tangent) ? 1 : 0;
-  if (h->dim == 2) hipLaunchKernelGGL(contact_residual_kernel<2>, dim3(b3), dim3(64), 0, h->stream, a, grad_flag);
-  else hipLaunchKernelGGL(contact_residual_kernel<3>, dim3(b3), dim3(64), 0, h->stream, a, grad_flag);
+  const unsigned b3w = (unsigned)((h->n_faces + 3) / 4);
+  if (h->dim == 2) hipLaunchKernelGGL(contact_residual_wave_kernel<2>, dim3(b3w), dim3(256), 0, h->stream, a);
+  else hipLaunchKernelGGL(contact_residual_wave_kernel<3>, dim3(b3w), dim3(256), 0, h->stream, a);
+  if (grad_flag) {   // reference-FD tangent
+    if (h->dim == 2) hipLaunchKernelGGL(contact_residual_kernel<2>, dim3(b3), dim3(64), 0, h->stream, a, grad_flag);
+    else hipLaunchKernelGGL(contact_residual_kernel<3>, dim3(b3), dim3(64), 0, h->stream, a, grad_flag);
+  }
   if (wave_tangent) {
     const unsigned b4 = (unsigned)((h->n_faces + 3) / 4);
     if (h->dim == 2) hipLaunchKernelGGL(contact_tangent_kernel<2>, dim3(b4), dim3(256), 0, h->stream, a);
@@ -652,6 +780,7 @@ int mimi_hip_contact_create(const mimi_hip_contact_tables* t, int device, mimi_h
     if (t->dim != 2 && t->dim != 3) fail("Unsupported Dim: %d", t->dim);
     if (t->n_dof < 1 || t->n_dof > kMaxFaceDof) fail("face n_dof %d out of range [1,%d]", t->n_dof, kMaxFaceDof);
     if (t->n_faces < 1) fail("no marked boundary faces");
+    if (t->n_quad < 1 || t->n_quad > 64) fail("face quadrature points %d out of range [1,64]", t->n_quad);   // (a lane per point)
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
       fail("libmimi_hip: no HIP device visible -- this library has no CPU fallback");
