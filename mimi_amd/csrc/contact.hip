@@ -146,15 +146,24 @@ __global__ void contact_gap_area_kernel(ContactArgs p, int gap_norm_only) {
   if (idx >= (int64_t)p.n_faces * p.n_q) return;
   const int f = idx / p.n_q;
   const int64_t pt = idx;
-  double x_e[DIM * kMaxFaceDof];
-  gather_x<DIM>(p, f, x_e);
+  // x_e = u[v_dofs] + X_ref (integrator_utils.cpp:80-89) is used node by node as it arrives: the point's position and the
+  // two tangents J = x_e^T dN_dxi (integrator_utils.cpp:101-105) in one pass, no private array
   const double* N = p.N + pt * p.n_dof;
-  double xq[DIM];
+  const double* dN = p.dN + pt * p.n_dof * (DIM - 1);
+  double xq[DIM], t[(DIM - 1) * DIM];
 #pragma unroll
-  for (int i = 0; i < DIM; ++i) {
-    double s = 0;
-    for (int a = 0; a < p.n_dof; ++a) s += x_e[i * p.n_dof + a] * N[a];
-    xq[i] = s;
+  for (int i = 0; i < DIM; ++i) xq[i] = 0.0;
+#pragma unroll
+  for (int k = 0; k < (DIM - 1) * DIM; ++k) t[k] = 0.0;
+  for (int a = 0; a < p.n_dof; ++a) {
+    const int64_t node = p.dofs[(int64_t)f * p.n_dof + a];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) {
+      const double x = p.u[node * DIM + i] + p.x_ref[node * DIM + i];
+      xq[i] = __builtin_fma(x, N[a], xq[i]);
+#pragma unroll
+      for (int k = 0; k < DIM - 1; ++k) t[k * DIM + i] = __builtin_fma(x, dN[k * p.n_dof + a], t[k * DIM + i]);
+    }
   }
   double true_g, distance;
   nearest_body<DIM>(p, xq, true_g, distance);
@@ -164,8 +173,14 @@ __global__ void contact_gap_area_kernel(ContactArgs p, int gap_norm_only) {
     return;
   }
   double g = true_g < 0. ? true_g : 0.;
-  double m[DIM], t[(DIM - 1) * DIM];
-  const double detJ = surface_normal<DIM>(p.n_dof, x_e, p.dN + pt * p.n_dof * (DIM - 1), m, t);
+  // |J| (DenseMatrix::Weight) from the non-normalised normal (integrator_utils.hpp:216-251)
+  double detJ;
+  if constexpr (DIM == 2) {
+    detJ = sqrt(t[1] * t[1] + t[0] * t[0]);
+  } else {
+    const double m0 = t[1] * t[5] - t[2] * t[4], m1 = t[2] * t[3] - t[0] * t[5], m2 = t[0] * t[4] - t[1] * t[3];
+    detJ = sqrt(m0 * m0 + m1 * m1 + m2 * m2);
+  }
   const double fac = p.weight[pt] * detJ;
   p.pt_scal[pt] = fac;
   const double ratio = fabs(true_g) / distance;
