@@ -311,8 +311,9 @@ int mimi_hip_linear_destroy(mimi_hip_linear_t h);
 /* NULL = the handle's own stream */
 int mimi_hip_linear_set_stream(mimi_hip_linear_t h, void* hip_stream);
 /* what: 0 rows, 1 stored entries, 2 consecutive rows that share one column list (3 or 2: the dofs of a node in the byVDIM
- * numbering of py_nonlinear_solid.cpp:63 -- the products read the list once per group; 1: any other pattern).  -1: bad
- * argument. */
+ * numbering of py_nonlinear_solid.cpp:63 -- the products read the list once per group; 1: any other pattern), 3 whether
+ * that shared list is made of node triples 3 c, 3 c + 1, 3 c + 2 (1: the products read one index per node, a ninth of the
+ * index bytes).  -1: bad argument. */
 int64_t mimi_hip_linear_info(mimi_hip_linear_t h, int what);
 /* forms::Nonlinear::AddMult / AddMultGrad tail (forms/nonlinear.hpp:76-80,112-115): r[ess] = 0 (r may be NULL);
  * A.EliminateRowCol(ess, DIAG_ONE) on the CSR values (A_values may be NULL).  Host or device pointers. */

@@ -66,7 +66,9 @@ __device__ __forceinline__ double kr_total(const double* partial, double* sh) {
 // column indices and the gathered x are read once for the ROWS rows; four entries per lane are in flight per trip.  Every
 // lane adds its entries in increasing position and the lanes are combined by the same shuffle tree for both values of
 // ROWS, so a row's sum does not depend on which form ran.
-template<int ROWS>
+// NODECOL (ROWS == 3 only): the columns of a row come in triples 3 c, 3 c + 1, 3 c + 2 (the dofs of node c), and `col` is the
+// list of the nodes c instead -- a third of the index bytes of the group form, a ninth of the plain one.
+template<int ROWS, bool NODECOL>
 __device__ __forceinline__ void kr_row_products(int64_t row0, int lane, const int64_t* __restrict__ rowptr,
                                                 const int32_t* __restrict__ col, const double* __restrict__ val,
                                                 const double* __restrict__ x, double (&s)[ROWS]) {
@@ -78,13 +80,17 @@ __device__ __forceinline__ void kr_row_products(int64_t row0, int lane, const in
     v[j] = val + (j == 0 ? beg : rowptr[row0 + j]);
     s[j] = 0.0;
   }
-  const int32_t* c = col + beg;
+  const int32_t* c = col + (NODECOL ? beg / 9 : beg);
   // four entries per lane and trip, every load of the trip issued before the first product
   for (int k0 = lane; k0 < len; k0 += 256) {
     int32_t cc[4];
     double a[4][ROWS], xx[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) cc[u] = k0 + 64 * u < len ? c[k0 + 64 * u] : 0;
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + 64 * u;
+      if constexpr (NODECOL) cc[u] = k < len ? 3 * c[k / 3] + k % 3 : 0;
+      else cc[u] = k < len ? c[k] : 0;
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -103,7 +109,7 @@ __device__ __forceinline__ void kr_row_products(int64_t row0, int lane, const in
 }
 
 // y = Dinv (A x) (or A x when dinv == nullptr; y = Dinv (b - A x) when b != nullptr): one wave per unit of ROWS rows
-template<int ROWS>
+template<int ROWS, bool NODECOL>
 __global__ __launch_bounds__(256) void kr_spmv_kernel(int64_t n_units, const int64_t* __restrict__ rowptr,
                                                       const int32_t* __restrict__ col, const double* __restrict__ val,
                                                       const double* __restrict__ x, const double* __restrict__ b,
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) void kr_spmv_kernel(int64_t n_units, const int
   if (unit >= n_units) return;
   const int64_t row0 = unit * ROWS;
   double s[ROWS];
-  kr_row_products<ROWS>(row0, lane, rowptr, col, val, x, s);
+  kr_row_products<ROWS, NODECOL>(row0, lane, rowptr, col, val, x, s);
   if (lane == 0) {   // kr_wave_sum leaves the sums in lane 0
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void kr_spmv_kernel(int64_t n_units, const int
 }
 
 // y += alpha A x (mfem::SparseMatrix::AddMult)
-template<int ROWS>
+template<int ROWS, bool NODECOL>
 __global__ __launch_bounds__(256) void kr_add_mult_kernel(int64_t n_units, const int64_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ col, const double* __restrict__ val,
                                                           const double* __restrict__ x, double alpha, double* __restrict__ y) {
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256) void kr_add_mult_kernel(int64_t n_units, const
   if (unit >= n_units) return;
   const int64_t row0 = unit * ROWS;
   double s[ROWS];
-  kr_row_products<ROWS>(row0, lane, rowptr, col, val, x, s);
+  kr_row_products<ROWS, NODECOL>(row0, lane, rowptr, col, val, x, s);
   if (lane == 0) {
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) y[row0 + j] += alpha * s[j];
@@ -154,6 +160,27 @@ __global__ __launch_bounds__(256) void kr_groups_kernel(int64_t n, int g, const 
   if (!differ)
     for (int64_t k = lane; k < len; k += 64) differ |= col[beg + k] != col[beg0 + k];
   if (differ) atomicOr(status, bit);
+}
+
+// rows in groups of three with one column list: is that list made of triples 3 c, 3 c + 1, 3 c + 2?  (one wave per group;
+// a difference sets `bit` of *status); and the list of the c, at rowptr[3 u] / 9
+__global__ __launch_bounds__(256) void kr_nodecol_kernel(int64_t n_units, const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                         int bit, int* __restrict__ status, int32_t* __restrict__ ncol) {
+  const int lane = threadIdx.x & 63;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= n_units) return;
+  const int64_t beg = rowptr[3 * unit];
+  const int len = (int)(rowptr[3 * unit + 1] - beg);
+  if (!ncol) {
+    bool differ = len % 3 != 0 || beg % 9 != 0;
+    for (int m = lane; 3 * m + 2 < len; m += 64) {
+      const int32_t c0 = col[beg + 3 * m];
+      differ |= c0 % 3 != 0 || col[beg + 3 * m + 1] != c0 + 1 || col[beg + 3 * m + 2] != c0 + 2;
+    }
+    if (differ) atomicOr(status, bit);
+  } else {
+    for (int m = lane; m < len / 3; m += 64) ncol[beg / 9 + m] = col[beg + 3 * m] / 3;
+  }
 }
 
 // dinv[row] = 1 / A(row, row)   (mfem::DSmoother, type 0, scale 1)
@@ -317,6 +344,8 @@ struct mimi_hip_linear_s {
   DeviceBuffer<unsigned char> is_ess;
   int64_t n_ess = 0;
   int group = 1;          // rows g b .. g b + g - 1 share their column list (kr_groups_kernel; g = 3, 2 or 1): read once per group
+  bool nodecol = false;   // ... and, g = 3, the list is made of node triples: `ncol` holds the nodes (kr_nodecol_kernel)
+  DeviceBuffer<int32_t> ncol;
   DeviceBuffer<double> dinv, V, w, r, partials, totals, ycoef, stage_val, stage_b, stage_x;
   int* status_dev = nullptr;
   double* column_host[2] = {nullptr, nullptr};   // pinned: the Hessenberg column of the step before last and of the last one
@@ -359,15 +388,18 @@ int guarded_k(F&& f) {
 }
 
 void spmv(mimi_hip_linear_s* h, const double* val, const double* x, const double* b, const double* dinv, double* y) {
-  if (h->group == 3)
-    hipLaunchKernelGGL(kr_spmv_kernel<3>, dim3((unsigned)((h->n / 3 + 3) / 4)), dim3(256), 0, h->stream, h->n / 3, h->rowptr, h->col,
-                       val, x, b, dinv, y);
+  if (h->nodecol)
+    hipLaunchKernelGGL((kr_spmv_kernel<3, true>), dim3((unsigned)((h->n / 3 + 3) / 4)), dim3(256), 0, h->stream, h->n / 3, h->rowptr,
+                       h->ncol.ptr, val, x, b, dinv, y);
+  else if (h->group == 3)
+    hipLaunchKernelGGL((kr_spmv_kernel<3, false>), dim3((unsigned)((h->n / 3 + 3) / 4)), dim3(256), 0, h->stream, h->n / 3, h->rowptr,
+                       h->col, val, x, b, dinv, y);
   else if (h->group == 2)
-    hipLaunchKernelGGL(kr_spmv_kernel<2>, dim3((unsigned)((h->n / 2 + 3) / 4)), dim3(256), 0, h->stream, h->n / 2, h->rowptr, h->col,
-                       val, x, b, dinv, y);
+    hipLaunchKernelGGL((kr_spmv_kernel<2, false>), dim3((unsigned)((h->n / 2 + 3) / 4)), dim3(256), 0, h->stream, h->n / 2, h->rowptr,
+                       h->col, val, x, b, dinv, y);
   else
-    hipLaunchKernelGGL(kr_spmv_kernel<1>, dim3((unsigned)((h->n + 3) / 4)), dim3(256), 0, h->stream, h->n, h->rowptr, h->col, val, x,
-                       b, dinv, y);
+    hipLaunchKernelGGL((kr_spmv_kernel<1, false>), dim3((unsigned)((h->n + 3) / 4)), dim3(256), 0, h->stream, h->n, h->rowptr, h->col,
+                       val, x, b, dinv, y);
   MH_HIP(hipGetLastError());
 }
 
@@ -423,6 +455,20 @@ int mimi_hip_linear_create(int64_t n, const int64_t* csr_rowptr, const int32_t* 
     MH_HIP(hipMemcpyAsync(&status, h->status_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     MH_HIP(hipStreamSynchronize(h->stream));
     h->group = (n % 3 == 0 && !(status & 8)) ? 3 : (n % 2 == 0 && !(status & 4)) ? 2 : 1;
+    if (h->group == 3 && nnz % 9 == 0) {
+      hipLaunchKernelGGL(kr_nodecol_kernel, dim3((unsigned)((n / 3 + 3) / 4)), dim3(256), 0, h->stream, n / 3, h->rowptr, h->col, 16,
+                         h->status_dev, (int32_t*)nullptr);
+      MH_HIP(hipGetLastError());
+      MH_HIP(hipMemcpyAsync(&status, h->status_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      MH_HIP(hipStreamSynchronize(h->stream));
+      if (!(status & 16)) {
+        h->ncol.resize((size_t)(nnz / 9));
+        hipLaunchKernelGGL(kr_nodecol_kernel, dim3((unsigned)((n / 3 + 3) / 4)), dim3(256), 0, h->stream, n / 3, h->rowptr, h->col, 16,
+                           h->status_dev, h->ncol.ptr);
+        MH_HIP(hipGetLastError());
+        h->nodecol = true;
+      }
+    }
     h->is_ess.resize((size_t)n);
     MH_HIP(hipMemsetAsync(h->is_ess.ptr, 0, (size_t)n, h->stream));
     h->n_ess = n_ess;
@@ -460,6 +506,7 @@ int64_t mimi_hip_linear_info(mimi_hip_linear_t h, int what) {
     case 0: return h->n;
     case 1: return h->nnz;
     case 2: return h->group;
+    case 3: return h->nodecol ? 1 : 0;
     default: return -1;
   }
 }
@@ -496,15 +543,18 @@ int mimi_hip_linear_add_mult(mimi_hip_linear_t h, const double* A_values, const 
     Mirror<double> mA = Mirror<double>::in(A_values, (size_t)h->nnz, h->stage_val, h->stream);
     Mirror<double> mx = Mirror<double>::in(x, (size_t)h->n, h->stage_x, h->stream);
     Mirror<double> my = Mirror<double>::inout(y, (size_t)h->n, h->stage_b, h->stream);
-    if (h->group == 3)
-      hipLaunchKernelGGL(kr_add_mult_kernel<3>, dim3((unsigned)((h->n / 3 + 3) / 4)), dim3(256), 0, h->stream, h->n / 3, h->rowptr,
-                         h->col, mA.dev, mx.dev, alpha, my.dev);
+    if (h->nodecol)
+      hipLaunchKernelGGL((kr_add_mult_kernel<3, true>), dim3((unsigned)((h->n / 3 + 3) / 4)), dim3(256), 0, h->stream, h->n / 3,
+                         h->rowptr, h->ncol.ptr, mA.dev, mx.dev, alpha, my.dev);
+    else if (h->group == 3)
+      hipLaunchKernelGGL((kr_add_mult_kernel<3, false>), dim3((unsigned)((h->n / 3 + 3) / 4)), dim3(256), 0, h->stream, h->n / 3,
+                         h->rowptr, h->col, mA.dev, mx.dev, alpha, my.dev);
     else if (h->group == 2)
-      hipLaunchKernelGGL(kr_add_mult_kernel<2>, dim3((unsigned)((h->n / 2 + 3) / 4)), dim3(256), 0, h->stream, h->n / 2, h->rowptr,
-                         h->col, mA.dev, mx.dev, alpha, my.dev);
+      hipLaunchKernelGGL((kr_add_mult_kernel<2, false>), dim3((unsigned)((h->n / 2 + 3) / 4)), dim3(256), 0, h->stream, h->n / 2,
+                         h->rowptr, h->col, mA.dev, mx.dev, alpha, my.dev);
     else
-      hipLaunchKernelGGL(kr_add_mult_kernel<1>, dim3((unsigned)((h->n + 3) / 4)), dim3(256), 0, h->stream, h->n, h->rowptr, h->col,
-                         mA.dev, mx.dev, alpha, my.dev);
+      hipLaunchKernelGGL((kr_add_mult_kernel<1, false>), dim3((unsigned)((h->n + 3) / 4)), dim3(256), 0, h->stream, h->n, h->rowptr,
+                         h->col, mA.dev, mx.dev, alpha, my.dev);
     MH_HIP(hipGetLastError());
     my.finish(h->stream);
     if (mA.host || mx.host || my.host) MH_HIP(hipStreamSynchronize(h->stream));

@@ -49,6 +49,10 @@ class LinearSolver:
         """consecutive rows sharing one column list that the products read once (3, 2 or 1)"""
         return int(_capi.lib().mimi_hip_linear_info(self._h, 2))
 
+    def NodeColumns(self):
+        """True when the shared column list of a node's rows is made of node triples and is read as one index per node"""
+        return bool(_capi.lib().mimi_hip_linear_info(self._h, 3))
+
     def Eliminate(self, r=None, A_values=None):
         """r[ess] = 0; A.EliminateRowCol(ess, DIAG_ONE)"""
         self._follow_torch(r, A_values)

@@ -186,6 +186,7 @@ def test_hip_products_on_every_row_grouping(kind, group):
     A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
     S = LinearSolver(CSRPattern(rowptr, col, len(col)))
     assert S.RowGroup() == group
+    assert S.NodeColumns() == (kind == "3d")      # (node triples: read as one index per node)
     x = rng.standard_normal(n)
     y0 = rng.standard_normal(n)
     y = S.AddMult(val, x, y0.copy(), alpha=-0.75)
@@ -201,3 +202,29 @@ def test_hip_products_on_every_row_grouping(kind, group):
     xs = S.Mult(val2, b, np.empty(n))
     assert S.converged_ and S.final_iter_ < 50
     assert np.linalg.norm(A2 @ xs - b) <= 1e-7 * np.linalg.norm(b)
+
+
+@pytest.mark.gpu
+def test_hip_products_without_node_triples():
+    """rows in groups of three with one column list that is NOT made of node triples (every third column dropped): the
+    group form without the node-column shortcut"""
+    from mimi_amd.integrators import CSRPattern
+    from mimi_amd.linear import LinearSolver
+    rng = np.random.default_rng(23)
+    rowptr0, col0 = _vector_pattern(6, 5, 4, 3)
+    n = len(rowptr0) - 1
+    rows = []
+    for r in range(0, n, 3):
+        c = col0[rowptr0[r]:rowptr0[r + 1]]
+        keep = c[(np.arange(len(c)) % 3 != 1) | (c // 3 == r // 3)]        # drops the middle dof of the other nodes
+        rows.extend([keep] * 3)
+    rowptr = np.concatenate([[0], np.cumsum([len(c) for c in rows])]).astype(np.int64)
+    col = np.concatenate(rows).astype(np.int32)
+    val = rng.standard_normal(len(col))
+    A = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+    S = LinearSolver(CSRPattern(rowptr, col, len(col)))
+    assert S.RowGroup() == 3 and not S.NodeColumns()
+    x, y0 = rng.standard_normal(n), rng.standard_normal(n)
+    y = S.AddMult(val, x, y0.copy(), alpha=1.25)
+    exp = y0 + 1.25 * (A @ x)
+    assert np.abs(y - exp).max() <= 1e-13 * np.abs(exp).max()
