@@ -203,12 +203,20 @@ def _element_tables(patch, quadrature_order=-1, with_gradients=False, elements=N
     for s in m:
         em.append(e % s)
         e = e // s
+    def outer(f):
+        """[e, (z,) y, x, (c,) b, a] = product of the 1-D tables f[d][e, a_d, q_d] (plain broadcasting: the three-operand
+        einsum of this takes ten times as long)"""
+        t = [np.ascontiguousarray(g.transpose(0, 2, 1)) for g in f]            # [e, q_d, a_d]
+        r = t[1][:, :, None, :, None] * t[0][:, None, :, None, :]               # [e, y, x, b, a]
+        if dim == 3:
+            r = t[2][:, :, None, None, :, None, None] * r[:, None, :, :, None, :, :]   # [e, z, y, x, c, b, a]
+        return r
+
     if dim == 2:
-        N = np.einsum("eax,eby->eyxba", tabs[0][1][em[0]], tabs[1][1][em[1]])
         w = np.einsum("y,x->yx", tabs[1][3], tabs[0][3]).ravel()
     else:
-        N = np.einsum("eax,eby,ecz->ezyxcba", tabs[0][1][em[0]], tabs[1][1][em[1]], tabs[2][1][em[2]])
         w = np.einsum("z,y,x->zyx", tabs[2][3], tabs[1][3], tabs[0][3]).ravel()
+    N = outer([tabs[d][1][em[d]] for d in range(dim)])
     ne = len(em[0])
     N = N.reshape(ne, w.size, -1)
     # connectivity
@@ -225,11 +233,7 @@ def _element_tables(patch, quadrature_order=-1, with_gradients=False, elements=N
     dN = []
     for k in range(dim):
         f = [D[d] if d == k else B[d] for d in range(dim)]
-        if dim == 2:
-            g = np.einsum("eax,eby->eyxba", f[0][em[0]], f[1][em[1]])
-        else:
-            g = np.einsum("eax,eby,ecz->ezyxcba", f[0][em[0]], f[1][em[1]], f[2][em[2]])
-        dN.append(g.reshape(ne, w.size, -1))
+        dN.append(outer([f[d][em[d]] for d in range(dim)]).reshape(ne, w.size, -1))
     if getattr(patch, "weights", None) is not None:
         # rational basis: N = B w / sum(B w), with the quotient rule for the derivatives (precomputed.cpp:295-321 via MFEM)
         wa = patch.weights[conn]                                        # [e, a]
@@ -239,7 +243,7 @@ def _element_tables(patch, quadrature_order=-1, with_gradients=False, elements=N
               for g, dW in zip(dN, dWs)]
         N = N * wa[:, None, :] / Ws[:, :, None]
     X = patch.control_points[conn]                                      # [e, a, i]
-    J = np.stack([np.einsum("eai,eqa->eqi", X, g) for g in dN], axis=-1)   # [e, q, i, k]
+    J = np.stack([np.matmul(g, X) for g in dN], axis=-1)                # [e, q, i, k]
     det = np.linalg.det(J)
     if not np.all(det > 0):
         raise RuntimeError("geometry map has a non-positive Jacobian determinant")
@@ -288,35 +292,9 @@ class NonlinearSolid(Solid):
         # VectorDiffusionIntegrator(viscosity): C_(a,i),(b,j) = d_ij nu int grad N_a . grad N_b, integrated with the same
         # rule as the mass matrix -- exact on affine patches; mfem's own default rule for this integrator cannot be read
         # here and no reference fixture sets a viscosity: parity unpinned) and rhs (:221-283), in chunks of elements
-        nnz = len(col)
-        keys = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr)) * n + col
         viscosity = getattr(self.material, "viscosity", -1.0)
-        mass = np.zeros(nnz)
-        visc = np.zeros(nnz) if viscosity > 0.0 else None
-        rhs = np.zeros(n)
-        chunk = 8192
-        for e0 in range(0, patch.n_elements, chunk):
-            sl = slice(e0, min(e0 + chunk, patch.n_elements))
-            if visc is not None:
-                N, wd, conn, dN_dX = _element_tables(patch, with_gradients=True, elements=sl)
-                Ce = viscosity * np.einsum("eq,eqia,eqib->eab", wd, dN_dX, dN_dX)
-            else:
-                N, wd, conn = _element_tables(patch, elements=sl)
-            Me = self.material.density * np.einsum("eq,eqa,eqb->eab", wd, N, N)
-            # position of (row a, column b) of component 0; the rows of a node's other components follow it with the same
-            # column pattern: + c (row length) for the row, + c for the column
-            r0 = conn * dim
-            pos0 = np.searchsorted(keys, (r0[:, :, None] * n + r0[:, None, :]).ravel()).reshape(Me.shape)
-            row_len = (rowptr[r0 + 1] - rowptr[r0])[:, :, None]
-            for c in range(dim):
-                pos = (pos0 + c * row_len + c).ravel()
-                np.add.at(mass, pos, Me.ravel())
-                if visc is not None:
-                    np.add.at(visc, pos, Ce.ravel())
-            fe = np.einsum("eq,eqa->ea", wd, N)
-            for comp, value in bc.initial.body_force_.items():
-                np.add.at(rhs, (conn * dim + comp).ravel(), (fe * value).ravel())
-        del keys
+        mass, visc, rhs = _assemble_mass_viscosity_rhs(patch, rowptr, self.material.density, viscosity,
+                                                       bc.initial.body_force_)
         self.mass_ = mass
         _eliminate_row_col(rowptr, col, self.mass_, self.dirichlet_)
         self.visc_ = visc
@@ -554,6 +532,80 @@ class NonlinearSolid(Solid):
         out = np.zeros(len(order) * self._dim)
         out.reshape(-1, self._dim)[order] = np.asarray(vec).reshape(-1, self._dim)
         return out
+
+
+def _structured_positions(patch, rowptr, conn):
+    """Position in the CSR value array of (row = node conn[e, a] component 0, column = node conn[e, b] component 0) in the
+    structured pattern of a lexicographically numbered patch (CSRPattern.of_bspline_patch): the columns of a node's row are
+    the nodes of its window [A_d - p_d, A_d + p_d] (clipped), lexicographic, times the components -- so the position is
+    arithmetic, no search through the 10^8 column indices of a large mesh.  Returns pos0[e, a, b] and the row lengths."""
+    dim = patch.dim
+    row0 = conn * dim
+    n_e, n_a = conn.shape
+    rank = np.zeros((n_e, n_a, n_a), dtype=np.int64)
+    width = np.ones((n_e, n_a), dtype=np.int64)
+    rem = conn.copy()
+    for d in range(dim):
+        n_d, p_d = patch.n_ctrl[d], patch.degrees[d]
+        x = rem % n_d                       # coordinate of every node of the element in direction d
+        rem = rem // n_d
+        lo = np.maximum(x - p_d, 0)         # the window of a ROW node
+        w = np.minimum(x + p_d, n_d - 1) - lo + 1
+        rank += (x[:, None, :] - lo[:, :, None]) * width[:, :, None]
+        width = width * w
+    return rowptr[row0][:, :, None] + dim * rank, rowptr[row0 + 1] - rowptr[row0]
+
+
+def _assemble_mass_viscosity_rhs(patch, rowptr, density, viscosity, body_force, chunk=8192):
+    """mass (VectorMassIntegrator(rho), py_nonlinear_solid.cpp:155-173), damping (:176-192: VectorDiffusionIntegrator(
+    viscosity): C_(a,i),(b,j) = d_ij nu int grad N_a . grad N_b, integrated with the rule of the mass matrix -- exact on
+    affine patches; mfem's own default rule for this integrator cannot be read here and no reference fixture sets a
+    viscosity: parity unpinned) and the body-force vector (:221-283) of the whole patch, on the host.
+    Elements are taken COLOUR by colour (element index modulo p + 1 per direction): two elements of a colour share no
+    node, so their entries go to distinct positions and one vectorised `+=` adds them -- in a fixed order of the colours,
+    the same bits every run."""
+    dim = patch.dim
+    n = patch.n_vdofs
+    nnz = int(rowptr[-1])
+    mass = np.zeros(nnz)
+    visc = np.zeros(nnz) if viscosity > 0.0 else None
+    rhs = np.zeros(n)
+    spans = list(patch.n_spans)
+    e_all = np.arange(patch.n_elements)
+    em, rem = [], e_all
+    for d in range(dim):
+        em.append(rem % spans[d])
+        rem = rem // spans[d]
+    colour = np.zeros(patch.n_elements, dtype=np.int64)
+    mult = 1
+    for d in range(dim):
+        colour += (em[d] % (patch.degrees[d] + 1)) * mult
+        mult *= patch.degrees[d] + 1
+    order = np.argsort(colour, kind="stable")
+    bounds = np.concatenate([[0], np.cumsum(np.bincount(colour, minlength=mult))])
+    for cidx in range(mult):
+        els_c = order[bounds[cidx]:bounds[cidx + 1]]
+        for s0 in range(0, len(els_c), chunk):
+            els = els_c[s0:s0 + chunk]
+            if visc is not None:
+                N, wd, conn, dN_dX = _element_tables(patch, with_gradients=True, elements=els)
+                G = dN_dX.reshape(dN_dX.shape[0], -1, dN_dX.shape[3])                    # [e, (q, i), a]
+                Ce = viscosity * np.matmul((G * np.repeat(wd, dim, axis=1)[:, :, None]).transpose(0, 2, 1), G)
+            else:
+                N, wd, conn = _element_tables(patch, elements=els)
+            Me = density * np.matmul((N * wd[:, :, None]).transpose(0, 2, 1), N)           # [e, a, b]
+            pos0, row_len = _structured_positions(patch, rowptr, conn)
+            # the rows of a node's other components follow with the same column pattern: + c (row length) for the row,
+            # + c for the column
+            for c in range(dim):
+                pos = (pos0 + c * row_len[:, :, None] + c).ravel()
+                mass[pos] += Me.ravel()
+                if visc is not None:
+                    visc[pos] += Ce.ravel()
+            fe = np.einsum("eq,eqa->ea", wd, N)
+            for comp, value in body_force.items():
+                rhs[(conn * dim + comp).ravel()] += (fe * value).ravel()
+    return mass, visc, rhs
 
 
 def _eliminate_row_col(rowptr, col, vals, dofs):
