@@ -166,38 +166,47 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
     tab[tid] = ((isD ? p.tabD[dir] : p.tabB[dir]) + (int64_t)span * NB * NQ)[k];
   }
   __syncthreads();
+  // grad_xi u at the 125 points by sum factorisation, one direction per stage through LDS (V and W are free until the
+  // residual rows below): 9 x 4 multiply-adds per point and ~45 per lane in the two stages before, instead of 64 nodes
+  // x 12 per point (the direct sum was a sixth of this kernel's vector instructions)
+  {
+    double* SA = W;   // [variant of direction 0: B, D][i][q0][a1 + 4 a2]
+    double* SB = V;   // [D0 B1, B0 D1, B0 B1][i][q0 + 5 q1][a2]
+    for (int t = tid; t < 2 * 3 * NQ * NB * NB; t += 128) {
+      const int a12 = t & 15, r = t >> 4, q0 = r % NQ, vi = r / NQ;
+      const double* T = tab_ptr<3>(tab, 0, vi / 3) + q0;
+      const double* U = ue + (vi % 3) * ND + NB * a12;
+      double sv = 0.0;
+#pragma unroll
+      for (int a0 = 0; a0 < NB; ++a0) sv += T[a0 * NQ] * U[a0];
+      SA[t] = sv;
+    }
+    __syncthreads();
+    for (int t = tid; t < 3 * 3 * NQ * NQ * NB; t += 128) {
+      const int a2 = t & 3, r = t >> 2, q01 = r % (NQ * NQ), wi = r / (NQ * NQ), w = wi / 3, i = wi % 3;
+      const double* T = tab_ptr<3>(tab, 1, w == 1 ? 1 : 0) + q01 / NQ;
+      const double* S = SA + (((w == 0 ? 1 : 0) * 3 + i) * NQ + q01 % NQ) * (NB * NB) + NB * a2;
+      double sv = 0.0;
+#pragma unroll
+      for (int a1 = 0; a1 < NB; ++a1) sv += T[a1 * NQ] * S[a1];
+      SB[t] = sv;
+    }
+    __syncthreads();
+  }
   if (tid < NPT) {
-    const int q0 = tid % NQ, q1 = (tid / NQ) % NQ, q2 = tid / (NQ * NQ);
+    const int q2 = tid / (NQ * NQ), q01 = tid % (NQ * NQ);
     double H[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) H[k] = 0.0;
-    {
-      double b0[NB], d0[NB];
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int a = 0; a < NB; ++a) {
-        b0[a] = tab_ptr<3>(tab, 0, 0)[a * NQ + q0];
-        d0[a] = tab_ptr<3>(tab, 0, 1)[a * NQ + q0];
+      for (int k = 0; k < 3; ++k) {
+        const double* T = tab_ptr<3>(tab, 2, k == 2 ? 1 : 0) + q2;
+        const double* S = V + ((k * 3 + i) * (NQ * NQ) + q01) * NB;
+        double sv = 0.0;
+#pragma unroll
+        for (int a2 = 0; a2 < NB; ++a2) sv += T[a2 * NQ] * S[a2];
+        H[i * 3 + k] = sv;
       }
-      for (int a2 = 0; a2 < NB; ++a2) {
-        const double b2 = tab_ptr<3>(tab, 2, 0)[a2 * NQ + q2], d2 = tab_ptr<3>(tab, 2, 1)[a2 * NQ + q2];
-        for (int a1 = 0; a1 < NB; ++a1) {
-          const double b1 = tab_ptr<3>(tab, 1, 0)[a1 * NQ + q1], d1 = tab_ptr<3>(tab, 1, 1)[a1 * NQ + q1];
-          const double tbb = b1 * b2, tdb = d1 * b2, tbd = b1 * d2;
-#pragma unroll
-          for (int a0 = 0; a0 < NB; ++a0) {
-            const int a = a0 + NB * (a1 + NB * a2);
-            const double dn0 = d0[a0] * tbb, dn1 = b0[a0] * tdb, dn2 = b0[a0] * tbd;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-              const double uu = ue[i * ND + a];
-              H[i * 3 + 0] += uu * dn0;
-              H[i * 3 + 1] += uu * dn1;
-              H[i * 3 + 2] += uu * dn2;
-            }
-          }
-        }
-      }
-    }
     const double* g = p.geo + e * 10 * NPT + tid;
     double Ji[9];
 #pragma unroll
