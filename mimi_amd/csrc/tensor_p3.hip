@@ -111,9 +111,18 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
       N[m * 3 + n] = v;
       Q[m * 3 + n] = t;
     }
+  // every entry as five fused multiply-adds (six on the diagonal blocks) of factors scaled once: w det J into S and the
+  // volumetric / deviatoric / plastic coefficients into G, N and Ts
+  const double hbw = wdJ * hb, Kw = wdJ * Kc, ggw = wdJ * gg;
+  double hG[9], hN[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    hG[k] = hbw * G[k];
+    hN[k] = hbw * N[k];
+  }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    double S[3], Ts[3];
+    double S[3], Ts[3], KG[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
       double a = 0.0, b = 0.0;
@@ -122,8 +131,9 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
         a += w.sigma[i + k * 3] * G[m * 3 + k];
         b += w.s_trial[i + k * 3] * G[m * 3 + k];
       }
-      S[m] = a;
-      Ts[m] = b;
+      S[m] = wdJ * a;
+      Ts[m] = ggw * b;
+      KG[m] = Kw * G[m * 3 + i];
     }
 #pragma unroll
     for (int m = 0; m < 3; ++m)
@@ -131,11 +141,13 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
       for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
-          double v = G[n * 3 + j] * S[m] - G[m * 3 + j] * S[n];
-          v += Kc * G[m * 3 + i] * Ji[n * 3 + j];
-          v += hb * ((i == j ? N[m * 3 + n] : 0.0) + G[m * 3 + j] * Ji[n * 3 + i]);
-          v -= gg * Ts[m] * Q[n * 3 + j];
-          rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS] = wdJ * v;
+          double v = G[n * 3 + j] * S[m];
+          v = __builtin_fma(-G[m * 3 + j], S[n], v);
+          v = __builtin_fma(KG[m], Ji[n * 3 + j], v);
+          v = __builtin_fma(hG[m * 3 + j], Ji[n * 3 + i], v);
+          if (i == j) v += hN[m * 3 + n];
+          v = __builtin_fma(-Ts[m], Q[n * 3 + j], v);
+          rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS] = v;
         }
   }
 }
