@@ -838,13 +838,18 @@ def run_rank(args):
         if other:
             out["other_configs"] = other
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_child(args.workload, sweep=args.cpu_sweep)
-            out["cpu_baseline"]["gpu_over_cpu"] = main["value"] / out["cpu_baseline"]["value"]
-            # BASELINE.md holds no published figure for this metric; its section 2 names the number to compare with: the
-            # restated reference CPU path timed on this box (above), reference forward-FD Jacobian
-            out["vs_baseline"] = main["value"] / out["cpu_baseline"]["value"]
-            out["vs_baseline_note"] = ("value / cpu_baseline.value (BASELINE.md 2: no published number exists; the restated "
-                                       "reference OpenMP path on this box's host cores is the baseline)")
+            # a slow or failing host baseline must not throw the finished GPU measurement away
+            try:
+                out["cpu_baseline"] = cpu_baseline_child(args.workload, sweep=args.cpu_sweep)
+                out["cpu_baseline"]["gpu_over_cpu"] = main["value"] / out["cpu_baseline"]["value"]
+                # BASELINE.md holds no published figure for this metric; its section 2 names the number to compare with:
+                # the restated reference CPU path timed on this box (above), reference forward-FD Jacobian
+                out["vs_baseline"] = main["value"] / out["cpu_baseline"]["value"]
+                out["vs_baseline_note"] = ("value / cpu_baseline.value (BASELINE.md 2: no published number exists; the "
+                                           "restated reference OpenMP path on this box's host cores is the baseline)")
+            except (RuntimeError, subprocess.TimeoutExpired, ValueError, IndexError, KeyError, OSError) as exc:
+                out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+                out["vs_baseline"] = None
         else:
             out["cpu_baseline"] = None
         _emit(json_fd, out)

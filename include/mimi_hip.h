@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MIMI_HIP_ABI_VERSION 10
+#define MIMI_HIP_ABI_VERSION 11
 
 /* ---- errors ---------------------------------------------------------------- */
 const char* mimi_hip_last_error(void);
@@ -159,6 +159,15 @@ int mimi_hip_domain_add_residual(mimi_hip_domain_t h, const double* u, double* r
  * r += R(u); A_values += grad_factor * K(u)            (nonlinear_solid.cpp:162-177) */
 int mimi_hip_domain_add_residual_and_grad(mimi_hip_domain_t h, const double* u, double grad_factor,
                                           double* r, double* A_values);
+/* The same assembly with the old values of the matrix taken from a second array:
+ *   r += R(u); A_out = A_base + grad_factor * K(u)
+ * on every CSR row of a node the handle's elements touch (all rows for a whole-patch handle; other rows of A_out are
+ * left as they are).  This is operators::NonlinearSolid::ResidualAndGrad's "jacobian_ values <- mass values, then
+ * AddMultGrad" (operators/nonlinear_solid.cpp:257-258) without the copy pass: with both arrays on the device the row
+ * gathers read A_base where "+=" would read A_out -- no extra traffic.  A_base == A_out is the plain "+=".  Routes
+ * without a row gather (colour kernel, atomics fallback) and host-resident arrays copy A_base into A_out first. */
+int mimi_hip_domain_add_residual_and_grad_from(mimi_hip_domain_t h, const double* u, double grad_factor,
+                                               double* r, const double* A_base, double* A_out);
 /* DomainPostTimeAdvance(converged_u): commit material state (nonlinear_solid.cpp:179-199) */
 int mimi_hip_domain_post_time_advance(mimi_hip_domain_t h, const double* u);
 

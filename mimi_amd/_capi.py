@@ -64,7 +64,8 @@ EXPORTS = [
     "mimi_hip_domain_create", "mimi_hip_domain_create_bspline", "mimi_hip_domain_destroy",
     "mimi_hip_domain_set_dt", "mimi_hip_domain_set_tangent_mode", "mimi_hip_domain_set_stream",
     "mimi_hip_domain_synchronize", "mimi_hip_domain_add_residual",
-    "mimi_hip_domain_add_residual_and_grad", "mimi_hip_domain_post_time_advance",
+    "mimi_hip_domain_add_residual_and_grad", "mimi_hip_domain_add_residual_and_grad_from",
+    "mimi_hip_domain_post_time_advance",
     "mimi_hip_domain_get_state", "mimi_hip_domain_reset_state", "mimi_hip_domain_info",
     "mimi_hip_domain_set_phase_timing", "mimi_hip_domain_phase_ms", "mimi_hip_domain_phase_ms_detail",
     "mimi_hip_bspline_sparsity", "mimi_hip_bspline_sparsity_rows",
@@ -128,6 +129,7 @@ def lib():
     L.mimi_hip_domain_info.argtypes = [C.c_void_p, C.c_int]
     L.mimi_hip_domain_add_residual.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mimi_hip_domain_add_residual_and_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    L.mimi_hip_domain_add_residual_and_grad_from.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mimi_hip_domain_post_time_advance.argtypes = [C.c_void_p, C.c_void_p]
     L.mimi_hip_domain_set_dt.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
     L.mimi_hip_domain_set_tangent_mode.argtypes = [C.c_void_p, C.c_int]

@@ -876,6 +876,25 @@ int mimi_hip_contact_create(const mimi_hip_contact_tables* t, int device, mimi_h
       h->rowptr = h->rowptr_own.ptr;
     }
     MH_HIP(hipMemcpy(&h->nnz, h->rowptr + h->n_vdofs, sizeof(int64_t), hipMemcpyDeviceToHost));
+    {
+      // contact_gather_kernel keeps the CSR row of a marked dof in LDS (CG_MAX_ROW doubles): a caller's pattern with a
+      // longer marked row (multi-patch, degree >= 4) is refused here instead of overflowing the image at assembly time
+      std::vector<int64_t> rp_host;
+      const int64_t* rp = t->csr_rowptr;
+      if (is_device_pointer(t->csr_rowptr)) {
+        rp_host.resize((size_t)h->n_vdofs + 1);
+        MH_HIP(hipMemcpy(rp_host.data(), t->csr_rowptr, rp_host.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+        rp = rp_host.data();
+      }
+      int64_t longest = 0;
+      for (int32_t node : marked)
+        for (int i = 0; i < t->dim; ++i) {
+          const int64_t row = (int64_t)node * t->dim + i;
+          longest = std::max(longest, rp[row + 1] - rp[row]);
+        }
+      if (longest > CG_MAX_ROW)
+        fail("a CSR row of a marked contact dof holds %lld entries; the contact gather supports at most %d", (long long)longest, CG_MAX_ROW);
+    }
     DeviceBuffer<int32_t> col_tmp;
     const int32_t* col_dev = t->csr_col;
     if (!is_device_pointer(t->csr_col)) {

@@ -322,6 +322,8 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a_
   static const bool no_mfma_env = getenv("MIMI_HIP_GENERAL_NO_MFMA") && getenv("MIMI_HIP_GENERAL_NO_MFMA")[0] == '1';
   (void)no_mfma_env;
   const bool two_phase = ensure_general_two_phase(h, grad != 0);
+  if (!two_phase && grad) consume_base(h, a.A);      // (atomics into the values in place)
+  const double* A_old = (h->A_base && a.A) ? h->A_base : a.A;
   a.scratch_k = (two_phase && grad) ? h->scratch_k.ptr : nullptr;
   a.scratch_r = two_phase ? h->scratch_r.ptr : nullptr;
   // (called after the element kernel of every route below)
@@ -331,7 +333,7 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a_
     auto kernel = grad ? general_gather_kernel<DIM, 1> : general_gather_kernel<DIM, 0>;
     hipLaunchKernelGGL(kernel, dim3((unsigned)((n_rows + GG_WAVES - 1) / GG_WAVES)), dim3(64 * GG_WAVES), 0, h->stream, n_rows,
                        h->n_dof, h->rowptr, h->adj_ptr.ptr, h->adj.ptr, h->pair_pos.ptr, h->scratch_k.ptr, h->scratch_r.ptr,
-                       a.grad_factor, a.A, a.r);
+                       a.grad_factor, A_old, a.A, a.r);
     MH_HIP(hipGetLastError());
   };
   size_t lds = general_lds_bytes(DIM, h->n_dof, h->n_q, grad);
@@ -416,28 +418,52 @@ static bool launch_tensor_small(mimi_hip_domain_s* h, int mode, const double* u,
   }
   if (mode == 2) return true;
   const int64_t n_rows = h->n_vdofs;
+  const double* A_old = (h->A_base && A) ? h->A_base : A;
   const unsigned gblocks = (unsigned)((n_rows + GG_WAVES - 1) / GG_WAVES);
   if (h->dim == 2) {
     auto kernel = mode == 1 ? general_gather_kernel<2, 1> : general_gather_kernel<2, 0>;
     hipLaunchKernelGGL(kernel, dim3(gblocks), dim3(64 * GG_WAVES), 0, h->stream, n_rows, h->n_dof, h->rowptr, h->adj_ptr.ptr, h->adj.ptr,
-                       h->pair_pos.ptr, h->scratch_k.ptr, h->scratch_r.ptr, gf, A, r);
+                       h->pair_pos.ptr, h->scratch_k.ptr, h->scratch_r.ptr, gf, A_old, A, r);
   } else {
     auto kernel = mode == 1 ? general_gather_kernel<3, 1> : general_gather_kernel<3, 0>;
     hipLaunchKernelGGL(kernel, dim3(gblocks), dim3(64 * GG_WAVES), 0, h->stream, n_rows, h->n_dof, h->rowptr, h->adj_ptr.ptr, h->adj.ptr,
-                       h->pair_pos.ptr, h->scratch_k.ptr, h->scratch_r.ptr, gf, A, r);
+                       h->pair_pos.ptr, h->scratch_k.ptr, h->scratch_r.ptr, gf, A_old, A, r);
   }
   MH_HIP(hipGetLastError());
   return true;
 }
 
-static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double* A, double gf, bool with_grad) {
+// A_base (tangent assemblies only): nullptr = the plain "A += gf K"; otherwise A = A_base + gf K on the rows of the handle's
+// nodes.  Both arrays on the device: the row gathers read A_base where they would read A (no extra pass); any other
+// residence: A_base is copied into (the staging copy of) A first.
+static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double* A, double gf, bool with_grad,
+                       const double* A_base = nullptr) {
   MH_HIP(hipSetDevice(h->device));
   if (!u || !r || (with_grad && !A)) fail("null vector argument");
   h->integrated = false;   // the element pieces of an earlier mimi_hip_domain_integrate are overwritten by this call
   Mirror<double> mu = Mirror<double>::in(u, h->n_vdofs, h->stage_u, h->stream);
   Mirror<double> mr = Mirror<double>::inout(r, h->n_vdofs, h->stage_r, h->stream);
   Mirror<double> mA;
-  if (with_grad) mA = Mirror<double>::inout(A, h->nnz, h->stage_A, h->stream);
+  h->A_base = nullptr;
+  if (with_grad && A_base && A_base != A) {
+    if (is_device_pointer(A) && is_device_pointer(A_base)) {
+      mA = Mirror<double>::inout(A, h->nnz, h->stage_A, h->stream);
+      h->A_base = A_base;
+    } else if (is_device_pointer(A)) {
+      mA = Mirror<double>::inout(A, h->nnz, h->stage_A, h->stream);
+      MH_HIP(hipMemcpyAsync(A, A_base, (size_t)h->nnz * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    } else {
+      // host output: its staging copy starts from the base instead of from A's own contents
+      h->stage_A.resize(h->nnz);
+      MH_HIP(hipMemcpyAsync(h->stage_A.ptr, A_base, (size_t)h->nnz * sizeof(double), hipMemcpyDefault, h->stream));
+      mA.dev = h->stage_A.ptr;
+      mA.host = A;
+      mA.count = h->nnz;
+      mA.stage = &h->stage_A;
+    }
+  } else if (with_grad) {
+    mA = Mirror<double>::inout(A, h->nnz, h->stage_A, h->stream);
+  }
   const int grad = !with_grad ? 0 : (h->tangent_mode == MIMI_HIP_TANGENT_REFERENCE_FD ? 2 : 1);
   // (the colour-partitioned tensor kernel, the fallback when the CSR is not the structured pattern, has closed-form
   // materials only: the other materials then take the general kernels)
@@ -452,6 +478,7 @@ static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double*
     GeneralArgs a = general_args(h, mu.dev, mr.dev, mA.dev, gf);
     if (h->dim == 2) launch_general<2>(h, grad, a); else launch_general<3>(h, grad, a);
   }
+  h->A_base = nullptr;
   mr.finish(h->stream);
   if (with_grad) mA.finish(h->stream);
   const bool any_host = mu.host || mr.host || (with_grad && mA.host);
@@ -847,6 +874,20 @@ int mimi_hip_domain_add_residual_and_grad(mimi_hip_domain_t h, const double* u, 
   return guarded([&] {
     if (!h) fail("null handle");
     run_domain(h, u, r, A_values, grad_factor, true);
+  });
+}
+
+int mimi_hip_domain_add_residual_and_grad_from(mimi_hip_domain_t h, const double* u, double grad_factor, double* r,
+                                               const double* A_base, double* A_out) {
+  return guarded([&] {
+    if (!h) fail("null handle");
+    if (!A_base) fail("null vector argument");
+    try {
+      run_domain(h, u, r, A_out, grad_factor, true, A_base);
+    } catch (...) {
+      h->A_base = nullptr;
+      throw;
+    }
   });
 }
 

@@ -59,6 +59,10 @@ struct mimi_hip_domain_s {
   int phase_select = 0;
   int gather_begin[3] = {0, 0, 0}, gather_end[3] = {0, 0, 0};
   bool integrated = false;
+  // mimi_hip_domain_add_residual_and_grad_from: the array the row gathers read the old values from during this call
+  // (device; nullptr = the output array itself, the plain "+=").  Paths without a row gather take it by a copy
+  // (consume_base below).
+  const double* A_base = nullptr;
   // kernel family of the last assembly / state commit on this handle (mimi_hip_domain_info(h, 7)): 0 none yet,
   // 1 two-phase tensor degree 2, 2 two-phase tensor degree 3, 3 small-element tensor kernel, 4 general kernels,
   // 5 colour-partitioned tensor kernel
@@ -69,3 +73,12 @@ struct mimi_hip_domain_s {
 
   ~mimi_hip_domain_s();
 };
+
+namespace mimi_hip {
+// for an assembly route that adds into the value array in place (colour kernel, atomics): A <- A_base first, then "+="
+inline void consume_base(mimi_hip_domain_s* h, double* A) {
+  if (h->A_base && A && h->A_base != A)
+    MH_HIP(hipMemcpyAsync(A, h->A_base, (size_t)h->nnz * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  h->A_base = nullptr;
+}
+}  // namespace mimi_hip

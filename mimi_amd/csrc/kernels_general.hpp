@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64 * GG_WAVES) void general_gather_kernel(int64_t n
                                                                        const int64_t* __restrict__ adj_ptr, const int32_t* __restrict__ adj,
                                                                        const int32_t* __restrict__ pair_pos, const double* __restrict__ scratch_k,
                                                                        const double* __restrict__ scratch_r, double grad_factor,
-                                                                       double* __restrict__ A, double* __restrict__ r) {
+                                                                       const double* A_base, double* A, double* __restrict__ r) {
   __shared__ double img_all[WITH_K ? GG_WAVES : 1][GG_MAX_ROW];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * GG_WAVES + wave;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(64 * GG_WAVES) void general_gather_kernel(int64_t n
       __builtin_amdgcn_wave_barrier();
     }
     __builtin_amdgcn_wave_barrier();
-    for (int k = lane; k < len; k += 64) A[beg + k] += grad_factor * img[k];
+    for (int k = lane; k < len; k += 64) A[beg + k] = A_base[beg + k] + grad_factor * img[k];
   }
   // residual entry: the incident elements in adjacency order over the lanes, then a fixed-shape tree
   double rs = 0.0;

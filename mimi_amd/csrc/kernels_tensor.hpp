@@ -51,6 +51,8 @@ struct TensorArgs {
   const double* u;
   double* r;
   double* A;
+  const double* A_base;      // two-phase paths, phase 2: A[row] = A_base[row] + grad_factor * sum (A itself for the plain "+=";
+                             // another array for mimi_hip_domain_add_residual_and_grad_from)
   double grad_factor, dt;
   MaterialDev mat;
   StateView state;
@@ -717,6 +719,7 @@ inline TensorArgs tensor_args(mimi_hip_domain_s* h, const double* u, double* r, 
   a.u = u;
   a.r = r;
   a.A = A;
+  a.A_base = (h->A_base && A) ? h->A_base : A;
   a.grad_factor = gf;
   a.dt = h->dt;
   a.mat = h->mat;
@@ -734,6 +737,7 @@ inline void launch_tensor_p(mimi_hip_domain_s* h, int grad, TensorArgs a) {
   auto kernel = grad ? tensor_domain_kernel<P, 1> : tensor_domain_kernel<P, 0>;
   if (lds > 64 * 1024)
     ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
+  if (grad) consume_base(h, a.A);     // (read-modify-write in place: the base array, if any, is copied first)
   const int nu = a.box_n[a.u_axis], nv = a.box_n[a.v_axis];
   for (int cv = 0; cv < P + 1; ++cv)
     for (int cu = 0; cu < P + 1; ++cu) {

@@ -166,9 +166,14 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
   if (p.perm) {
 #pragma unroll
     for (int I = 0; I < 3; ++I) {
-      double* row = p.A + p.rowptr[gA * 3 + I];
+      const int64_t beg = p.rowptr[gA * 3 + I];
+      double* row = p.A + beg;
+      const double* base = p.A_base + beg;
       const unsigned char* pos = p.nbr_pos + A * 125;
-      for (int t = lane; t < L; t += 64) row[3 * (int)pos[t / 3] + t % 3] += p.grad_factor * sums[I * SROW + t];
+      for (int t = lane; t < L; t += 64) {
+        const int k = 3 * (int)pos[t / 3] + t % 3;
+        row[k] = base[k] + p.grad_factor * sums[I * SROW + t];
+      }
     }
   } else {
     // all 18 loads of the three rows in flight together (L <= 375 = 6 x 64 - 9), then the adds and the stores: one
@@ -178,9 +183,11 @@ __global__ __launch_bounds__(256) void tensor_p2_kernel(TensorArgs p, int64_t n_
     double old[3][NT];
 #pragma unroll
     for (int I = 0; I < 3; ++I) {
-      row[I] = p.A + p.rowptr[gA * 3 + I] + lane;
+      const int64_t beg = p.rowptr[gA * 3 + I] + lane;
+      row[I] = p.A + beg;
+      const double* base = p.A_base + beg;
 #pragma unroll
-      for (int q = 0; q < NT; ++q) old[I][q] = lane + 64 * q < L ? row[I][64 * q] : 0.0;
+      for (int q = 0; q < NT; ++q) old[I][q] = lane + 64 * q < L ? base[64 * q] : 0.0;
     }
 #pragma unroll
     for (int I = 0; I < 3; ++I)

@@ -102,6 +102,9 @@ MH_DEV double rate_contribution_derivative(const mimi_hip_material& m, double ra
 // conditioning of exp(q ln x) itself; < 1e-14 for the plastic strains that occur (>= 1e-13), far inside the 1e-9
 // (state), 1e-11 (tangent) and 1e-12 (residual) bars the parity tests hold this path to.
 MH_DEV double pow_positive(double x, double q) {
+  // arguments outside the range the reduction below is written for, answered as pow() answers them (a diverging
+  // return-map Newton can produce them): x = +inf here, |q ln x| beyond the exponent range below
+  if (x > 1.79769313486231570815e+308) return q > 0.0 ? x : (q < 0.0 ? 0.0 : 1.0);
   int e;
   double m = __builtin_frexp(x, &e);   // [1/2, 1)
   if (m < 0.70710678118654752440) {
@@ -124,7 +127,11 @@ MH_DEV double pow_positive(double x, double q) {
   constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const double ed = (double)e;
   const double lnx = __builtin_fma(ed, ln2_hi, p) + ed * ln2_lo;
-  const double y = q * lnx;
+  double y = q * lnx;
+  // e^y over- / underflows long before +-1500: clamped so that k fits an int and the remainder stays small; ldexp then
+  // returns inf / 0 as pow() does (a NaN passes through both comparisons and comes out as NaN)
+  if (y > 1500.0) y = 1500.0;
+  if (y < -1500.0) y = -1500.0;
   const double k = __builtin_rint(y * 1.44269504088896338700e+00);
   double r = __builtin_fma(-k, ln2_hi, y);
   r = __builtin_fma(-k, ln2_lo, r);

@@ -901,12 +901,17 @@ __global__ __launch_bounds__(256) void tp3_gather_kernel(TensorArgs p, int64_t n
     __builtin_amdgcn_wave_barrier();
     // u, r and the CSR may live in the caller's node numbering (perm: lexicographic -> caller's id, e.g. MFEM's NURBS dof
     // map): row perm[A], and entry t of the lexicographic window at the rank of its permuted column inside that row
-    double* dst = p.A + p.rowptr[(p.perm ? p.perm[A] : A) * 3 + I];
+    const int64_t beg = p.rowptr[(p.perm ? p.perm[A] : A) * 3 + I];
+    double* dst = p.A + beg;
+    const double* base = p.A_base + beg;     // (the row's old values: A itself, or the caller's base array)
     if (p.perm) {
       const uint16_t* pos = p.nbr_pos16 + A * 343;
-      for (int t = lane; t < L; t += 64) dst[3 * (int)pos[t / 3] + t % 3] += p.grad_factor * img[t];
+      for (int t = lane; t < L; t += 64) {
+        const int k = 3 * (int)pos[t / 3] + t % 3;
+        dst[k] = base[k] + p.grad_factor * img[t];
+      }
     } else {
-      for (int t = lane; t < L; t += 64) dst[t] += p.grad_factor * img[t];
+      for (int t = lane; t < L; t += 64) dst[t] = base[t] + p.grad_factor * img[t];
     }
   }
   // residual row: lane = element (dz, dy, dx) of the 4 x 4 x 4 neighbourhood, fixed-shape tree sum

@@ -210,6 +210,15 @@ class NonlinearSolid(NonlinearBase):
         check(_capi.lib().mimi_hip_domain_add_residual_and_grad(self._handle(), fptr(current_u), float(grad_factor),
                                                                 fptr(residual), fptr(grad_values)))
 
+    def AddDomainResidualAndGradFrom(self, current_u, grad_factor, residual, base_values, grad_values):
+        """r += R(u); grad_values = base_values + grad_factor K(u) on the rows of the handle's nodes: the operator's
+        "jacobian <- mass values, then AddMultGrad" (operators/nonlinear_solid.cpp:257-258) as ONE pass -- the row gathers
+        read base_values where "+=" would read grad_values (mimi_hip.h: mimi_hip_domain_add_residual_and_grad_from)."""
+        self._push_dt()
+        self._follow_torch(current_u, residual, grad_values, base_values)
+        check(_capi.lib().mimi_hip_domain_add_residual_and_grad_from(self._handle(), fptr(current_u), float(grad_factor),
+                                                                     fptr(residual), fptr(base_values), fptr(grad_values)))
+
     # -- nonlinear_solid.cpp:179-199 ---------------------------------------------------
     def DomainPostTimeAdvance(self, converged_u):
         # the reference's material keeps the dt_ of the latest Add* call (nonlinear_solid.cpp:154,167)
@@ -482,6 +491,7 @@ class MortarContact(NonlinearBase):
 
     def SetStream(self, stream):
         self._user_stream = bool(stream)
+        self._user_stream_value = int(stream) if stream else 0
         check(_capi.lib().mimi_hip_contact_set_stream(self._handle(), C.c_void_p(stream) if stream else None))
 
     def _follow_torch(self, *buffers):

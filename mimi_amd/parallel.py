@@ -428,6 +428,15 @@ class ShardedContact:
             staged = self.comm_device.type == "cpu"
             if staged:
                 c.Synchronize()
+            else:
+                # the copies and the all-reduce below run on torch's current stream, the kernels on the handle's: the two
+                # must be one stream (a handle without SetStream follows torch's by itself) -- refused otherwise, rather
+                # than summing nodal values pass 1 has not written yet
+                from ._capi import STREAM_NULL
+                cur = self.torch.cuda.current_stream(self.device).cuda_stream or STREAM_NULL
+                if getattr(c, "_user_stream", False) and c._user_stream_value != cur:
+                    raise RuntimeError("ShardedContact: the contact handle was given a stream (SetStream) that is not torch's "
+                                       "current stream on its device; set both to the same stream")
             self.buf.zero_()
             self.buf[:, self.slot] = self.nodal.to(self.comm_device)
             self.dist.all_reduce(self.buf, group=self.group)

@@ -400,9 +400,11 @@ class NonlinearSolid(Solid):
         xt = self._xa + self._fac0 * a
         y = self._torch.empty_like(a)
         self._linear_part(a, y)
-        self.d_jac_.copy_(self.d_mass_)               # std::copy_n(mass_A_, ...)
+        # std::copy_n(mass_A_, ...) followed by AddMultGrad, as one pass: J = M + fac0 K with the row gathers reading M
+        # where "+=" would read J (mimi_hip_domain_add_residual_and_grad_from) -- no 2 x nnz copy, and the domain
+        # integrator of a single-patch solid touches every row
         self._push(self.domain_)
-        self.domain_.AddDomainResidualAndGrad(xt, self._fac0, y, self.d_jac_)
+        self.domain_.AddDomainResidualAndGradFrom(xt, self._fac0, y, self.d_mass_, self.d_jac_)
         for c in self.contacts_:
             c.AddBoundaryResidualAndGrad(xt, self._fac0, y, self.d_jac_)
         self.linear_.Eliminate(y, self.d_jac_)        # forms/nonlinear.hpp:76-80,112-115

@@ -22,7 +22,8 @@ def declared_functions():
 def test_header_declares_the_expected_surface():
     names = declared_functions()
     for must in ("mimi_hip_domain_create", "mimi_hip_domain_create_bspline", "mimi_hip_domain_add_residual",
-                 "mimi_hip_domain_add_residual_and_grad", "mimi_hip_domain_post_time_advance",
+                 "mimi_hip_domain_add_residual_and_grad", "mimi_hip_domain_add_residual_and_grad_from",
+                 "mimi_hip_domain_post_time_advance",
                  "mimi_hip_contact_add_residual", "mimi_hip_contact_add_residual_and_grad",
                  "mimi_hip_contact_gap_norm", "mimi_hip_bspline_sparsity", "mimi_hip_last_error"):
         assert must in names
@@ -37,7 +38,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert not missing, missing
     assert sorted(_capi.EXPORTS) == declared_functions()
     lib.mimi_hip_abi_version.restype = ctypes.c_int
-    assert lib.mimi_hip_abi_version() == 10
+    assert lib.mimi_hip_abi_version() == 11
     # plain C ABI: no C++ / torch symbols leak through the public names
     out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
     public = [l.split()[-1] for l in out.splitlines() if " T " in l]

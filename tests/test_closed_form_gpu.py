@@ -193,7 +193,7 @@ def test_homogeneous_deformation_small(n_el, p, kind):
     check_block(n_el, p, kind, lengths=[1.0 + 0.5 * d for d in range(len(n_el))])
 
 
-FULL = {"northstar": ((128, 128, 16), 2, "neohookean"), "cfg4_domain": ((96, 96, 12), 2, "neohookean"),
+FULL = {"cfg2": ((64, 64, 8), 2, "neohookean"), "northstar": ((128, 128, 16), 2, "neohookean"), "cfg4_domain": ((96, 96, 12), 2, "neohookean"),
         "cfg3": ((128, 128, 16), 3, "j2"), "cfg3_neohookean": ((128, 128, 16), 3, "neohookean"),
         "cfg5": ((256, 256, 32), 2, "neohookean")}
 

@@ -524,3 +524,55 @@ def test_integrate_then_gather_in_parts_equals_one_call(case):
     g2 = NonlinearSolid("domain", product_material("neohook"), pat2, patch=P2d).Prepare()
     with pytest.raises(RuntimeError):
         g2.Integrate(torch.zeros(P2d.n_vdofs, dtype=torch.float64, device=dev))
+
+
+# (shape, degree, lengths, material, creator): one case per kernel family that assembles a tangent -- two-phase tensor
+# degree 2 (symmetric-half and nine-block), degree 3, the small-element tensor kernel, the general kernels
+FROM_CASES = [((4, 3, 5), 2, None, "neohook", "bspline"), ((3, 3, 4), 2, None, "j2", "bspline"),
+              ((3, 2, 3), 3, None, "neohook", "bspline"), ((3, 4), 2, None, "neohook", "bspline"),
+              ((2, 2), 3, [5.0, 1.0], "j2", "tables"), ((3, 2, 2), 2, None, "neohook", "tables")]
+
+
+@pytest.mark.parametrize("residence", ["device", "host", "mixed"])
+@pytest.mark.parametrize("case", FROM_CASES, ids=lambda c: "x".join(map(str, c[0])) + f"p{c[1]}-{c[3]}-{c[4]}")
+def test_residual_and_grad_from_a_base_array(case, residence):
+    """mimi_hip_domain_add_residual_and_grad_from: A_out = A_base + gf K, r += R -- the operator's "J <- M, then
+    AddMultGrad" (operators/nonlinear_solid.cpp:257-258) as one pass.  Random A_base, A_out pre-filled with garbage that
+    must not survive; compared (1e-11 / 1e-12) with the oracle's assembly on top of the same base and -- bitwise -- with
+    the plain "+=" entry applied to a copy of the base; the base array itself is left untouched."""
+    import torch
+    from oracle import ref_path as rp
+    n_el, p, lengths, matname, creator = case
+    P, D, G = make_pair(n_el, p, lengths, matname, creator)
+    D.set_dt(0.5)
+    G.dt_ = 0.5
+    u = synthetic_u(P, scale=0.05 if matname == "neohook" else 0.02)
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal(D.nnz) * 50.0
+    r0 = rng.standard_normal(P.n_vdofs)
+    gf = 0.37
+    r_o, A_o = r0.copy(), base.copy()
+    D.add_domain_residual_and_grad(u, gf, r_o, A_o, rp.TANGENT_EXACT)
+
+    dev = torch.device("cuda", 0)
+    to = lambda a, on_dev: torch.from_numpy(a.copy()).to(dev) if on_dev else a.copy()
+    base_dev, out_dev = {"device": (True, True), "host": (False, False), "mixed": (True, False)}[residence]
+    u_x, r_x = to(u, out_dev), to(r0, out_dev)
+    base_x = to(base, base_dev)
+    out_x = to(np.full(D.nnz, 1e30), out_dev)            # garbage: every entry must be overwritten
+    G.AddDomainResidualAndGradFrom(u_x, gf, r_x, base_x, out_x)
+    G.Synchronize()
+    host = lambda t: t.cpu().numpy() if isinstance(t, torch.Tensor) else t
+    assert relmax(host(r_x), r_o) < 1e-12
+    assert relmax(host(out_x), A_o) < 1e-11
+    assert np.array_equal(host(base_x), base)            # the base is read, never written
+    # the same bits as "copy, then +="
+    r_p, A_p = to(r0, out_dev), to(base, out_dev)
+    G.AddDomainResidualAndGrad(u_x, gf, r_p, A_p)
+    G.Synchronize()
+    assert np.array_equal(host(A_p), host(out_x)) and np.array_equal(host(r_p), host(r_x))
+    # A_base == A_out is the plain "+="
+    A_q, r_q = to(base, out_dev), to(r0, out_dev)
+    G.AddDomainResidualAndGradFrom(u_x, gf, r_q, A_q, A_q)
+    G.Synchronize()
+    assert np.array_equal(host(A_q), host(out_x))

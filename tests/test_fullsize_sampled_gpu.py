@@ -13,7 +13,7 @@ from _sampling import SampledRows, sample_nodes
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("workload,n_random", [("northstar", 24), ("cfg3", 4), ("cfg4_domain", 24), ("cfg5", 24)])
+@pytest.mark.parametrize("workload,n_random", [("cfg2", 24), ("northstar", 24), ("cfg3", 4), ("cfg4_domain", 24), ("cfg5", 24)])
 def test_sampled_rows_match_the_oracle(workload, n_random):
     import torch
     import bench

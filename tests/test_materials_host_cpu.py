@@ -110,3 +110,18 @@ def test_pow_positive_against_long_double_pow(host_lib):
     ulp = 1.1102230246251565e-16
     assert np.all(rel <= 3.0 * ulp * (np.abs(q * np.log(x)) + 1.0))
     assert rel.max() < 3e-14 and rel[:6].max() < 2e-15
+
+
+def test_pow_positive_outside_its_reduction_range(host_lib):
+    """Arguments a diverging return-map Newton can hand to pow_positive: x = +inf, and |q ln x| far
+    beyond the exponent range -- answered as the library pow answers them (inf / 0 / 1, NaN through), never by an
+    out-of-range double -> int conversion."""
+    x = np.array([np.inf, np.inf, np.inf, 1e300, 1e300, 1e-300, 1e-300, 2.0, 0.5, 1e308, np.nan, 3.0])
+    q = np.array([0.5, -0.5, 0.0, 1e10, -1e10, 1e10, -1e10, 1e300, 1e300, 2.0, 0.3, np.nan])
+    out = np.empty(x.size)
+    host_lib.host_pow_positive(x.size, x.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    with np.errstate(all="ignore"):
+        ref = np.power(x, q)
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.array_equal(out[ok], ref[ok])
