@@ -642,7 +642,11 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(DU[mn]) : "a"(aop[mn][1]), "v"(bS2U[v2]));
       asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(DV[mn]) : "a"(aop[mn][1]), "v"(bS2V[v2]));
     }
-    // the matrix results are read by the vector pipe from here on: the wait states the compiler would have placed
+    // the matrix results are read by the vector pipe from here on.  Nothing pads wait states behind asm matrix
+    // instructions, and the S1 statements above are not volatile (the compiler places most of them behind this pair):
+    // what holds the schedule to the 19 / 18 wait states gfx950 needs is the disassembly lint of
+    // tests/test_isa_lint_cpu.py (mimi_amd/isa_lint.py: nearest vector read of a result 42 wait states, nearest store 35,
+    // with or without this pair), not this statement -- it stays as a scheduling fence (memory clobber).
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // the operands of the next element travel while this one is contracted
     request(es + 1 < n_seq ? es + 1 : es);   // (the last element once more: no branch in the loop)

@@ -1,0 +1,85 @@
+"""ISA lint of the hand-scheduled fp64 matrix instructions (no GPU).
+
+csrc/tensor_p3.hip issues its 132 `v_mfma_f64_16x16x4_f64` per contraction block from inline asm, where LLVM's hazard
+recogniser pads nothing; mimi_amd/isa_lint.py checks the compiled code: every use of a matrix result is far enough behind
+its producer (wait states as the compiler counts them, requirements read back from the compiler's own padding of the
+builtin), no vector write / EXEC write sits too close in front of an asm matrix instruction, and the kernels spill no
+register.  The degree-2 kernels use the builtin -- compiler-padded code, which must pass the same lint with EVERY pair
+checked: that holds the lint's model against the compiler's (its nearest pairs sit exactly at 19 / 11 / 2 wait states).
+The reference has no analogue; this protects SURVEY 8 rows a7 / a8 at n_dof 64 and 27."""
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+from mimi_amd import isa_lint as L
+
+
+@pytest.fixture(scope="module")
+def need():
+    return L.calibrate()
+
+
+def test_requirements_read_back_from_the_compiler(need):
+    # gfx950: v_mfma_f64_16x16x4 runs 16 passes; result -> vector read 19, -> memory 18, -> A / B of a matrix instruction 19;
+    # vector write -> matrix read 2.  (If a compiler bump changes its padding, this says so before anything else.)
+    assert need["valu_read"] == 19 and need["mem_read"] == 18 and need["mfma_srcab"] == 19 and need["valu_def"] == 2
+
+
+def test_degree3_contraction_kernel_is_hazard_free_and_spill_free(need):
+    (bad, stats), = L.report("tensor_p3.hip", ["tp3_contract_kernel"], need, asm_only=True).values()
+    assert stats["mfma"] == 132 and stats["mfma_from_asm"] == 132          # (all of them hand-placed)
+    assert not bad, "\n".join(f"{w}: {d} < {r}\n  {a}\n  {b}" for a, b, d, r, w in bad[:10])
+    assert stats["vgpr_spill_count"] == 0
+    # the margins of the shipped schedule (informative: a change here is a change of the schedule, not yet a hazard)
+    assert stats["nearest_valu_read"] >= need["valu_read"] and stats["nearest_mem"] >= need["mem_read"]
+    print("tp3_contract_kernel", stats)
+
+
+def test_degree2_kernels_compiler_padded_code_passes_the_same_lint(need):
+    rep = L.report("domain.hip", ["tensor_wgsym_kernel", "tensor_wgs_kernel"], need, asm_only=False)
+    for kernel, (bad, stats) in rep.items():
+        assert stats["mfma"] > 200 and not bad, (kernel, bad[:5])
+        assert stats["vgpr_spill_count"] == 0
+        # the compiler pads to the requirement and no further: the lint's distances are the compiler's
+        assert stats["nearest_valu_read"] == need["valu_read"] and stats["nearest_valu_write"] == need["valu_write"]
+        assert stats["nearest_valu_def"] == need["valu_def"]
+        print(kernel, stats)
+
+
+_HAZARD = r"""
+#include <hip/hip_runtime.h>
+typedef double d4 __attribute__((ext_vector_type(4)));
+extern "C" __global__ void hazard_kernel(const double* a, const double* b, double* out) {
+  d4 c;
+  const double x = a[threadIdx.x], y = b[threadIdx.x];
+  asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, 0" : "=&v"(c) : "v"(x), "v"(y));
+  asm volatile("s_nop %0" :: "n"(PAD));
+  double s;
+  asm volatile("v_add_f64 %0, %1, %2" : "=v"(s) : "v"(c[0]), "v"(c[1]));
+  out[threadIdx.x] = s;
+}
+"""
+
+
+@pytest.mark.parametrize("pad", [15, 7, 0])
+def test_the_lint_turns_red_on_a_real_hazard(need, pad):
+    """an asm matrix instruction whose result a vector instruction reads after pad + 1 < 19 wait states"""
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "hazard.hip")
+        open(src, "w").write(_HAZARD)
+        asm = L.assembly(src, out=os.path.join(tmp, "hazard.s"), extra_flags=[f"-DPAD={pad}"])
+    bad, stats = L.lint_kernel(L.parse_kernel(asm, "hazard_kernel"), need, asm_only=True)
+    assert stats["mfma_from_asm"] == 1
+    assert bad and pad + 1 <= stats["nearest_valu_read"] < need["valu_read"]     # (the compiler may put a move in between)
+    assert any("read by a vector instruction" in what for *_, what in bad)
+
+
+def test_the_lint_stays_green_with_the_wait_states_in_place(need):
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "hazard.hip")
+        open(src, "w").write(_HAZARD.replace('asm volatile("s_nop %0" :: "n"(PAD));', 'asm volatile("s_nop 15\\n\\ts_nop 2");'))
+        asm = L.assembly(src, out=os.path.join(tmp, "hazard.s"))
+    bad, stats = L.lint_kernel(L.parse_kernel(asm, "hazard_kernel"), need, asm_only=True)
+    assert not bad and stats["nearest_valu_read"] >= 19
