@@ -608,8 +608,9 @@ __global__ __launch_bounds__(64) void tensor_domain_kernel(TensorArgs p) {
   if (status) atomicOr(p.status, status);
 }
 
-// DomainPostTimeAdvance: one lane per quadrature point, wave per element
-template<int P>
+// DomainPostTimeAdvance: one lane per quadrature point, wave per element (degree 2; degree 3: tensor_p3.hip).  FAMILY 0:
+// closed-form materials (materials.hpp), 1: the others (materials_other.hpp)
+template<int P, int FAMILY>
 __global__ __launch_bounds__(256) void tensor_post_kernel(TensorArgs p, int n_el) {
   using L = TensorLds<P>;
   constexpr int NB = L::NB, NQ = L::NQ, ND = L::ND, NQ3 = L::NQ3;
@@ -664,10 +665,8 @@ __global__ __launch_bounds__(256) void tensor_post_kernel(TensorArgs p, int n_el
         for (int m = 0; m < 3; ++m) s += H[i * 3 + m] * g[(int64_t)(m * 3 + J) * NQ3];
         F[i + J * 3] = s;
       }
-    if (p.mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN || p.mat.m.kind == MIMI_HIP_MAT_J2)
-      status |= accumulate_state<3>(p.mat, p.dt, p.state, e * NQ3 + q, F);
-    else
-      status |= accumulate_other<3>(p.mat, p.dt, p.state, e * NQ3 + q, F);
+    if constexpr (FAMILY == 0) status |= accumulate_state<3>(p.mat, p.dt, p.state, e * NQ3 + q, F);
+    else status |= accumulate_other<3>(p.mat, p.dt, p.state, e * NQ3 + q, F);
   }
   if (status) atomicOr(p.status, status);
 }

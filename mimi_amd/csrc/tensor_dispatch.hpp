@@ -51,11 +51,15 @@ inline int launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, double
 
 inline void launch_tensor_post(mimi_hip_domain_s* h, const double* u) {
   TensorArgs a = tensor_args(h, u, nullptr, nullptr, 0.0);
+  if (h->degree[0] == 3) {
+    launch_tensor_p3_post(h, a);
+    return;
+  }
   const int blocks = (h->n_el + 3) / 4;
-  if (h->degree[0] == 3)
-    hipLaunchKernelGGL(tensor_post_kernel<3>, dim3(blocks), dim3(256), 0, h->stream, a, h->n_el);
+  if (h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN || h->mat.m.kind == MIMI_HIP_MAT_J2)
+    hipLaunchKernelGGL((tensor_post_kernel<2, 0>), dim3(blocks), dim3(256), 0, h->stream, a, h->n_el);
   else
-    hipLaunchKernelGGL(tensor_post_kernel<2>, dim3(blocks), dim3(256), 0, h->stream, a, h->n_el);
+    hipLaunchKernelGGL((tensor_post_kernel<2, 1>), dim3(blocks), dim3(256), 0, h->stream, a, h->n_el);
   MH_HIP(hipGetLastError());
 }
 

@@ -34,6 +34,11 @@ namespace {
 
 typedef double t3_d4 __attribute__((ext_vector_type(4)));
 
+// the record is written once by the pre-pass and read once by the contraction, 21.6 GB at BASELINE configuration 3: stored
+// with the non-temporal hint (pre-pass 7.48 -> 7.14 ms, 7.6 -> 7.3 ms on a second box; the same hint on the contraction's
+// loads changes nothing, scratch/p3_variants.sh A/B in round 4)
+#define T3_REC_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
+
 constexpr int T3_NB = 4, T3_NQ = 5, T3_ND = 64, T3_NPT = 125, T3_PS = 128, T3_NROW = 192;
 constexpr int T3_REC = 90;                        // 81 Ahat + 9 Phat (the record layout of kernels_tensor_wgs.hpp)
 constexpr int T3_PIECE = 16 * 192 + 48 * 48;       // doubles per (element, i): rows a2 = 0, then rows a2 >= 1 at b2 = 0
@@ -85,7 +90,7 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
           for (int n = 0; n < 3; ++n) {
             double v = c2_w * G[m * 3 + i] * G[n * 3 + j] - c1_w * G[m * 3 + j] * G[n * 3 + i];
             if (i == j) v += mu_w * M[m * 3 + n];
-            rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS] = v;
+            T3_REC_STORE(&rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS], v);
           }
     return;
   }
@@ -147,12 +152,14 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
           v = __builtin_fma(hG[m * 3 + j], Ji[n * 3 + i], v);
           if (i == j) v += hN[m * 3 + n];
           v = __builtin_fma(-Ts[m], Q[n * 3 + j], v);
-          rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS] = v;
+          T3_REC_STORE(&rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS], v);
         }
   }
 }
 
-// FAMILY 0: closed-form materials (materials.hpp), 1: the others (materials_other.hpp).  GRAD 0: residual pieces only.
+// FAMILY 0: closed-form materials (materials.hpp), 1: the others (materials_other.hpp).  GRAD 0: residual pieces only;
+// 2: DomainPostTimeAdvance (nonlinear_solid.cpp:179-199) -- F at the points as for an assembly, then the material's state
+// commit, nothing else (the degree-2 commit kernel's direct 64-node sum per point spilled 821 registers at degree 3)
 template<int FAMILY, int GRAD>
 __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
   constexpr int NB = T3_NB, NQ = T3_NQ, ND = T3_ND, NPT = T3_NPT, PS = T3_PS;
@@ -234,16 +241,23 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
         for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * Ji[m * 3 + J];
         F[i + J * 3] = sf;
       }
-    double Pk[9], A[(GRAD && FAMILY == 1) ? 81 : 1];
+    if constexpr (GRAD == 2) {
+      int st;
+      if constexpr (FAMILY == 1) st = accumulate_other<3>(p.mat, p.dt, p.state, e * NPT + tid, F);
+      else st = accumulate_state<3>(p.mat, p.dt, p.state, e * NPT + tid, F);
+      if (st) atomicOr(p.status, st);
+      return;
+    }
+    double Pk[9], A[(GRAD == 1 && FAMILY == 1) ? 81 : 1];
     int status;
     if constexpr (FAMILY == 1) {
-      status = evaluate_other<3>(p.mat, p.dt, p.state, e * NPT + tid, F, Pk, GRAD ? A : nullptr, 1.0);
+      status = evaluate_other<3>(p.mat, p.dt, p.state, e * NPT + tid, F, Pk, GRAD == 1 ? A : nullptr, 1.0);
     } else {
       PointResult<3> w;
       status = evaluate_pk1<3>(p.mat, p.dt, p.state, e * NPT + tid, F, w);
 #pragma unroll
       for (int k = 0; k < 9; ++k) Pk[k] = w.P[k];
-      if constexpr (GRAD) t3_closed_form_record(p.mat.m, w, Ji, wd, p.scratch_pt + e * (int64_t)(T3_REC * PS) + tid);
+      if constexpr (GRAD == 1) t3_closed_form_record(p.mat.m, w, Ji, wd, p.scratch_pt + e * (int64_t)(T3_REC * PS) + tid);
     }
     if (status) atomicOr(p.status, status);
 #pragma unroll
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
         for (int J = 0; J < 3; ++J) t += Pk[i + J * 3] * Ji[m * 3 + J];
         PH[(i * 3 + m) * NPT + tid] = wd * t;
       }
-    if constexpr (GRAD && FAMILY == 1) {
+    if constexpr (GRAD == 1 && FAMILY == 1) {
       double* rec = p.scratch_pt + e * (int64_t)(T3_REC * PS) + tid;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -285,6 +299,7 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
       }
     }
   }
+  if constexpr (GRAD == 2) return;
   __syncthreads();
   // element residual pieces R_i[a] = sum_q sum_m dN_a/dxi_m Phat_i[m], one direction at a time
   for (int t = tid; t < 9 * NB * NQ * NQ; t += 128) {
@@ -977,6 +992,14 @@ void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {
     hipLaunchKernelGGL(tp3_gather_kernel<0>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, h->stream, a, n_rows);
   MH_HIP(hipGetLastError());
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[2], h->stream));
+}
+
+void launch_tensor_p3_post(mimi_hip_domain_s* h, TensorArgs a) {
+  const int kind = h->mat.m.kind;
+  const bool closed = kind == MIMI_HIP_MAT_NEOHOOKEAN || kind == MIMI_HIP_MAT_J2;
+  auto kernel = closed ? tp3_point_kernel<0, 2> : tp3_point_kernel<1, 2>;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)h->n_el), dim3(128), 0, h->stream, a);
+  MH_HIP(hipGetLastError());
 }
 
 }  // namespace mimi_hip

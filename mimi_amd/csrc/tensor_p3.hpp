@@ -10,5 +10,7 @@ namespace mimi_hip {
 bool tensor_p3_ready(const mimi_hip_domain_s* h);
 // grad 0: r += R(u); 1: also A += grad_factor K(u)
 void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a);
+// DomainPostTimeAdvance on the same handle: the pre-pass kernel in its commit mode
+void launch_tensor_p3_post(mimi_hip_domain_s* h, TensorArgs a);
 
 }  // namespace mimi_hip

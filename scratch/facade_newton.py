@@ -48,6 +48,35 @@ for step in range(2):
                               seconds_per_newton_iteration=dt / max(h["iterations"], 1),
                               gmres_iterations_last_solve=nl.linear_.final_iter_ if iterative else None,
                               norm0=h["norm0"], norm=h["norm"])
+# the operator's residual+Jacobian (operators/nonlinear_solid.cpp:240-283) on its own: J = M + fac0 K in one pass (ABI 11,
+# mimi_hip_domain_add_residual_and_grad_from), against the reference's order "J <- M, then +=" done with a device copy
+import torch
+a = nl._torch.zeros_like(nl.d_x_)
+for _ in range(3):
+    nl._residual_and_grad(a)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    nl._residual_and_grad(a)
+torch.cuda.synchronize()
+out["residual_and_grad_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+xt = nl._xa + nl._fac0 * a
+y = nl._torch.zeros_like(a)
+for k in range(13):
+    if k == 3:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+    nl.d_jac_.copy_(nl.d_mass_)
+    nl.domain_.AddDomainResidualAndGrad(xt, nl._fac0, y, nl.d_jac_)
+torch.cuda.synchronize()
+out["copy_then_add_ms"] = (time.perf_counter() - t0) / 10 * 1e3
+for k in range(13):
+    if k == 3:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+    nl.domain_.AddDomainResidualAndGradFrom(xt, nl._fac0, y, nl.d_mass_, nl.d_jac_)
+torch.cuda.synchronize()
+out["from_base_ms"] = (time.perf_counter() - t0) / 10 * 1e3
 out["csr_bytes_over_pcie_after_setup"] = nl.pcie_csr_bytes_
 out["max_displacement"] = float(np.abs(nl.x).max())
 print(out)
