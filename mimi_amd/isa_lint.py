@@ -176,7 +176,7 @@ def lint_kernel(instrs, need, asm_only=False):
     Returns (violations, statistics)."""
     bad = []
     stats = {"mfma": 0, "mfma_from_asm": 0, "nearest_valu_read": None, "nearest_valu_write": None, "nearest_mem": None,
-             "nearest_mfma_ab": None, "nearest_exec_write": None, "nearest_valu_def": None}
+             "nearest_mfma_ab": None, "nearest_exec_write": None, "nearest_valu_def": None, "nearest_dpp_def": None}
 
     def note(key, dist):
         if stats[key] is None or dist < stats[key]:
@@ -216,10 +216,14 @@ def lint_kernel(instrs, need, asm_only=False):
                         check(ins, other, dist, "nearest_valu_write", need["valu_write"], "result overwritten by a vector instruction")
         elif is_valu(ins) and _vec(ins.defs):
             w = _vec(ins.defs)
-            for j, dist in _walk(instrs, i, 4 * need["valu_def"]):
+            for j, dist in _walk(instrs, i, 4 * max(need["valu_def"], need["dpp_def"])):
                 other = instrs[j]
                 if is_mfma(other) and _vec(other.uses) & w and (other.from_asm or not asm_only):
                     check(ins, other, dist, "nearest_valu_def", need["valu_def"], "matrix instruction reads a register a vector instruction just wrote")
+                # a DPP operand (the first source: the lanes it is taken from are other lanes' registers) written by a vector
+                # instruction less than two wait states before (the compiler pads its own DPP instructions, not asm ones)
+                if other.from_asm and "_dpp" in other.op and len(other.operands) > 1 and _vec(_regs(other.operands[1])) & w:
+                    check(ins, other, dist, "nearest_dpp_def", need["dpp_def"], "DPP operand read behind the vector instruction that wrote it")
         writes_exec = ins.op.startswith("v_cmpx") or (bool(ins.operands) and not ins.op.startswith(_NO_DST) and
                                                       re.match(r"exec(_lo|_hi)?$", ins.operands[0]) is not None)
         if writes_exec:
@@ -296,6 +300,8 @@ def calibrate():
             # a vector instruction that only OVERWRITES a result register: LLVM's DMFMA16x16WriteVgprVALUWriteWaitStates (not
             # probed: no source construct pins the registers); the compiler-padded kernels passing the lint bound it below
             "valu_write": 11,
+            # vector write -> DPP read of the same register: 2 wait states (the ISA's rule for every DPP instruction)
+            "dpp_def": 2,
             "exec_valu": 4, "exec_salu": 8}
     return need
 
