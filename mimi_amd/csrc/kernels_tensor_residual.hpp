@@ -219,14 +219,19 @@ __global__ __launch_bounds__(256) void tensor_residual_gather_kernel(TensorArgs 
 // Same fixed summation orders in every run: bitwise reproducible.  Closed-form hyperelastic law only (the return mapping of
 // the J2 family is latency-bound and wants many waves: those stay with one wave per element, above).
 struct ResidualColLds {
+  // strides padded against bank conflicts (64 banks of 4 bytes for 8-byte reads within a half wave, 32 for writes within
+  // 16 lanes): the rows of a half wave, whose work items differ in im / w, must land on different banks
+  static constexpr int SBI = 20, SBS = 9 * SBI;       // SB: [slot][w 3 + i][20: q01 in the first 16]
+  static constexpr int PHS = 80;                      // PH: [im][80: point in the first 64]
+  static constexpr int VA = 20, VS = 3 * VA;          // V: [im][a2][20: q01 in the first 16]
   static constexpr int off_ue = 0;                    // [3 slots][3 i][9 a01]
   static constexpr int off_sa = off_ue + 81;          // [3 slots][2 v][3 i][4 q0][3 a1]
-  static constexpr int off_sb = off_sa + 3 * 72;      // [3 slots][3 w][3 i][16 q01]
-  static constexpr int off_acc = off_sb + 3 * 144;    // [3 slots][3 i][9 a01]
-  static constexpr int off_ph = off_acc + 81;         // PH [9 im][64]; later W [9 im][9 a12][4 q0]
-  static constexpr int off_v = off_ph + 576;          // V [9 im][3 a2][16 q01]
-  static constexpr int off_dump = off_v + 432;        // where lanes without a work item store
-  static constexpr int per_wave = off_dump + 2;       // 1 822 doubles = 14.6 KB
+  static constexpr int off_sb = off_sa + 3 * 72;      // [3 slots][3 w][3 i][q01]
+  static constexpr int off_acc = off_sb + 3 * SBS;    // [3 slots][3 i][9 a01]
+  static constexpr int off_ph = off_acc + 81;         // PH [9 im][point]; later W [9 im][9 a12][4 q0]
+  static constexpr int off_v = off_ph + 9 * PHS;      // V [9 im][3 a2][q01]
+  static constexpr int off_dump = off_v + 9 * VS;     // where lanes without a work item store
+  static constexpr int per_wave = off_dump + 2;       // 2 180 doubles = 17.4 KB
 };
 
 template<int N>
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(256) void tensor_residual_col_kernel(TensorArgs p, 
       const double in[3] = {S[0], S[1], S[2]};
       double out[4];
       rc_3to4(TB1s, in, out);
-      double* dst = b_ok ? SB + slot * 144 + (bw * 3 + bi) * 16 + bq0 : dump;
+      double* dst = b_ok ? SB + slot * L::SBS + (bw * 3 + bi) * L::SBI + bq0 : dump;
       const int st = b_ok ? 4 : 0;
 #pragma unroll
       for (int q = 0; q < 4; ++q) dst[q * st] = out[q];
@@ -405,17 +410,17 @@ __global__ __launch_bounds__(256) void tensor_residual_col_kernel(TensorArgs p, 
     double F[9];
     {
       double H[9];
-      const double* S0 = SB + o0 * 144 + q01;
-      const double* S1 = SB + o1 * 144 + q01;
-      const double* S2 = SB + o2 * 144 + q01;
+      const double* S0 = SB + o0 * L::SBS + q01;
+      const double* S1 = SB + o1 * L::SBS + q01;
+      const double* S2 = SB + o2 * L::SBS + q01;
 #pragma unroll
       for (int k = 0; k < 3; ++k)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           const double Tk = k == 2 ? TD2r : TB2r;
-          double h = rc_mul<0>(Tk, S0[(k * 3 + i) * 16]);
-          rc_fmac<1>(h, Tk, S1[(k * 3 + i) * 16]);
-          rc_fmac<2>(h, Tk, S2[(k * 3 + i) * 16]);
+          double h = rc_mul<0>(Tk, S0[(k * 3 + i) * L::SBI]);
+          rc_fmac<1>(h, Tk, S1[(k * 3 + i) * L::SBI]);
+          rc_fmac<2>(h, Tk, S2[(k * 3 + i) * L::SBI]);
           H[i * 3 + k] = h;
         }
 #pragma unroll
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(256) void tensor_residual_col_kernel(TensorArgs p, 
         double sp = 0.0;
 #pragma unroll
         for (int J = 0; J < 3; ++J) sp += w.P[I + J * 3] * Ji[m * 3 + J];
-        PH[(I * 3 + m) * NQ3 + lane] = wd * sp;
+        PH[(I * 3 + m) * L::PHS + lane] = wd * sp;
       }
     __builtin_amdgcn_wave_barrier();
     // contract q2: row = im (three passes of four rows; the last has one), lane of the row = q01; all a2 per lane
@@ -453,12 +458,12 @@ __global__ __launch_bounds__(256) void tensor_residual_col_kernel(TensorArgs p, 
       const bool ok = 4 * it + row < 9;
       double Tz = (im % 3) == 2 ? TD2 : TB2;
       RC_DPP_FENCE1(Tz);
-      const double* src = PH + im * NQ3 + c16;
+      const double* src = PH + im * L::PHS + c16;
       const double in[4] = {src[0], src[16], src[32], src[48]};
       double o3[3];
       rc_4to3(Tz, in, o3);
-      double* dst = ok ? V + im * 48 + c16 : dump;
-      const int st = ok ? 16 : 0;
+      double* dst = ok ? V + im * L::VS + c16 : dump;
+      const int st = ok ? L::VA : 0;
 #pragma unroll
       for (int a2 = 0; a2 < 3; ++a2) dst[a2 * st] = o3[a2];
     }
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(256) void tensor_residual_col_kernel(TensorArgs p, 
       const int cc = c16 < 12 ? c16 : 0, a2 = cc >> 2, r0 = cc & 3;
       double Ty = (im % 3) == 1 ? TD1 : TB1;
       RC_DPP_FENCE1(Ty);
-      const double* src = V + im * 48 + a2 * 16 + r0;
+      const double* src = V + im * L::VS + a2 * L::VA + r0;
       const double in[4] = {src[0], src[4], src[8], src[12]};
       double o3[3];
       rc_4to3(Ty, in, o3);
@@ -555,6 +560,7 @@ inline void launch_tensor_residual(mimi_hip_domain_s* h, TensorArgs a) {
     a.scratch_r = h->scratch_r.ptr;
     const unsigned blocks = (unsigned)((n_cols + 3) / 4);
     const size_t lds = (size_t)4 * ResidualColLds::per_wave * sizeof(double);
+    if (lds > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(tensor_residual_col_kernel<MIMI_HIP_MAT_NEOHOOKEAN>), (int)lds);
     hipLaunchKernelGGL(tensor_residual_col_kernel<MIMI_HIP_MAT_NEOHOOKEAN>, dim3(blocks), dim3(256), lds, h->stream, a, n_cols);
     MH_HIP(hipGetLastError());
     const int64_t n_nodes = (int64_t)(a.box_n[0] + 2) * (a.box_n[1] + 2) * (a.box_n[2] + 2);   // nodes of the shard
