@@ -228,10 +228,11 @@ struct ResidualColLds {
   static constexpr int off_sa = off_ue + 81;          // [3 slots][2 v][3 i][4 q0][3 a1]
   static constexpr int off_sb = off_sa + 3 * 72;      // [3 slots][3 w][3 i][q01]
   static constexpr int off_acc = off_sb + 3 * SBS;    // [3 slots][3 i][9 a01]
-  static constexpr int off_ph = off_acc + 81;         // PH [9 im][point]; later W [9 im][9 a12][4 q0]
-  static constexpr int off_v = off_ph + 9 * PHS;      // V [9 im][3 a2][q01]
-  static constexpr int off_dump = off_v + 9 * VS;     // where lanes without a work item store
-  static constexpr int per_wave = off_dump + 2;       // 2 180 doubles = 17.4 KB
+  static constexpr int off_ph = off_acc + 81;         // PH [3 m][point] of one row component
+  static constexpr int off_v = off_ph + 3 * PHS;      // V [3 m][3 a2][q01] of one row component
+  static constexpr int off_w = off_v + 3 * VS;        // W [9 im][9 a12][4 q0]
+  static constexpr int off_dump = off_w + 324;        // where lanes without a work item store
+  static constexpr int per_wave = off_dump + 2;       // 1 664 doubles = 13.3 KB: three workgroups of four waves per CU
 };
 
 template<int N>
@@ -247,6 +248,7 @@ MH_DEV double rc_mul(double table, double w) {               // table[lane N of 
 // A DPP operand must not be read within two wait states of the vector instruction that wrote it, and nothing pads inline
 // asm: the table registers pass through this statement after they are written (tests/test_isa_lint_cpu.py checks it)
 #define RC_DPP_FENCE1(a) asm volatile("s_nop 1" : "+v"(a))
+#define RC_DPP_FENCE3(a, b, c) asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c))
 #define RC_DPP_FENCE4(a, b, c, d) asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 
 // out[q] = sum_a T[a][q] in[a]  (3 -> 4: the forward stages) with T entry a * 4 + q
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(256) void tensor_residual_col_kernel(TensorArgs p, 
   double* SB = base + L::off_sb;
   double* acc = base + L::off_acc;
   double* PH = base + L::off_ph;
-  double* W = base + L::off_ph;
+  double* W = base + L::off_w;
   double* V = base + L::off_v;
   double* dump = base + L::off_dump;
   const int ex = col % p.box_n[0], ey = col / p.box_n[0], nz = p.box_n[2];
@@ -315,8 +317,10 @@ __global__ __launch_bounds__(256) void tensor_residual_col_kernel(TensorArgs p, 
   const int bw = row < 3 ? row : 2, bidx = c16 < 12 ? c16 : 0, bi = bidx >> 2, bq0 = bidx & 3;
   const bool b_ok = row < 3 && c16 < 12;
   double TB1s = bw == 1 ? TD1 : TB1;
+  const int vm = row < 3 ? row : 2;          // the residual stages: row = m
+  double Ty = vm == 1 ? TD1 : TB1;           // contraction of q1: the D table for m = 1
   RC_DPP_FENCE4(TB0, TD0, TB1, TD1);
-  RC_DPP_FENCE4(TA0, TB1s, TB0, TD0);
+  RC_DPP_FENCE4(TA0, TB1s, Ty, TD0);
   // contract a0, then a1, of the plane in ring slot `slot`
   auto ingest = [&](int slot) {
     {
@@ -381,8 +385,9 @@ __global__ __launch_bounds__(256) void tensor_residual_col_kernel(TensorArgs p, 
 #pragma unroll
     for (int k = 0; k < 9; ++k) Ji[k] = Jn[k];
     const double wd = wdn;
-    double TB2 = TB2n, TD2 = TD2n, TB2r = TB2rn, TD2r = TD2rn;
-    RC_DPP_FENCE4(TB2, TD2, TB2r, TD2r);
+    double TB2r = TB2rn, TD2r = TD2rn;
+    double Tz = vm == 2 ? TD2n : TB2n;       // contraction of q2: row = m, the D table for m = 2
+    RC_DPP_FENCE3(Tz, TB2r, TD2r);
     {
       double* d = lane < ND ? ue + o2 * 27 + lane : dump;
       *d = un;
@@ -440,52 +445,44 @@ __global__ __launch_bounds__(256) void tensor_residual_col_kernel(TensorArgs p, 
       mat.m.kind = KIND;
       status |= evaluate_pk1<3>(mat, p.dt, p.state, e * NQ3 + lane, F, w);
     }
-    // Phat[I][m] of the point -> LDS, [im][point]
+    // one row component I at a time (LDS for three waves per SIMD): Phat[I][m] of the point -> LDS [m][point]; contract q2
+    // (row = m, lane of the row = q01; all a2 per lane); contract q1 (row = m, lane of the row = (a2, q0), 12 of 16; all a1
+    // per lane) -> W[I 3 + m], which stays for the last stage
 #pragma unroll
-    for (int I = 0; I < 3; ++I)
+    for (int I = 0; I < 3; ++I) {
 #pragma unroll
       for (int m = 0; m < 3; ++m) {
         double sp = 0.0;
 #pragma unroll
         for (int J = 0; J < 3; ++J) sp += w.P[I + J * 3] * Ji[m * 3 + J];
-        PH[(I * 3 + m) * L::PHS + lane] = wd * sp;
+        PH[m * L::PHS + lane] = wd * sp;
       }
-    __builtin_amdgcn_wave_barrier();
-    // contract q2: row = im (three passes of four rows; the last has one), lane of the row = q01; all a2 per lane
+      __builtin_amdgcn_wave_barrier();
+      {
+        const double* src = PH + vm * L::PHS + c16;
+        const double in[4] = {src[0], src[16], src[32], src[48]};
+        double o3[3];
+        rc_4to3(Tz, in, o3);
+        double* dst = row < 3 ? V + vm * L::VS + c16 : dump;
+        const int st = row < 3 ? L::VA : 0;
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
-      const int im = min(4 * it + row, 8);
-      const bool ok = 4 * it + row < 9;
-      double Tz = (im % 3) == 2 ? TD2 : TB2;
-      RC_DPP_FENCE1(Tz);
-      const double* src = PH + im * L::PHS + c16;
-      const double in[4] = {src[0], src[16], src[32], src[48]};
-      double o3[3];
-      rc_4to3(Tz, in, o3);
-      double* dst = ok ? V + im * L::VS + c16 : dump;
-      const int st = ok ? L::VA : 0;
+        for (int a2 = 0; a2 < 3; ++a2) dst[a2 * st] = o3[a2];
+      }
+      __builtin_amdgcn_wave_barrier();
+      {
+        const bool ok = row < 3 && c16 < 12;
+        const int cc = c16 < 12 ? c16 : 0, a2 = cc >> 2, r0 = cc & 3;
+        const double* src = V + vm * L::VS + a2 * L::VA + r0;
+        const double in[4] = {src[0], src[4], src[8], src[12]};
+        double o3[3];
+        rc_4to3(Ty, in, o3);
+        double* dst = ok ? W + ((I * 3 + vm) * 9 + 3 * a2) * 4 + r0 : dump;
+        const int st = ok ? 4 : 0;
 #pragma unroll
-      for (int a2 = 0; a2 < 3; ++a2) dst[a2 * st] = o3[a2];
+        for (int a1 = 0; a1 < 3; ++a1) dst[a1 * st] = o3[a1];
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
-    // contract q1: row = im, lane of the row = (a2, q0) (12 of 16); all a1 per lane.  W overlays PH (dead by now)
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-      const int im = min(4 * it + row, 8);
-      const bool ok = 4 * it + row < 9 && c16 < 12;
-      const int cc = c16 < 12 ? c16 : 0, a2 = cc >> 2, r0 = cc & 3;
-      double Ty = (im % 3) == 1 ? TD1 : TB1;
-      RC_DPP_FENCE1(Ty);
-      const double* src = V + im * L::VS + a2 * L::VA + r0;
-      const double in[4] = {src[0], src[4], src[8], src[12]};
-      double o3[3];
-      rc_4to3(Ty, in, o3);
-      double* dst = ok ? W + (im * 9 + 3 * a2) * 4 + r0 : dump;
-      const int st = ok ? 4 : 0;
-#pragma unroll
-      for (int a1 = 0; a1 < 3; ++a1) dst[a1 * st] = o3[a1];
-    }
-    __builtin_amdgcn_wave_barrier();
     // contract q0 and sum over m: lane = (I, a12) (27 lanes); all a0 per lane; into the ring of plane accumulators
     {
       const int fl = lane < ND ? lane : 0, I = fl / 9, a12 = fl % 9, a2 = a12 / 3, a1 = a12 % 3;
