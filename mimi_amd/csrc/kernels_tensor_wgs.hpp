@@ -770,6 +770,9 @@ MH_DEV void wgs_stage_carry(const WgsLane& lc, const double (&C)[9], double* st_
   }
 }
 
+// the element pieces are written once here and read once by phase 2 (8 GB at the north-star size): stored with the
+// non-temporal hint (same-box A/B in round 4, scratch/p2_ablate.py: step 7.18 -> 7.09 ms, both phases gain)
+#define WGS_PIECE_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
 // buffer (compact: nine rows of 81, eighteen rows of 27) -> this piece's runs in the element block E (P2Block)
 MH_DEV void wgs_flush_final(int lane, const double* ST, double* E, int I) {
   constexpr int NROW = 81, ND = 27;
@@ -786,10 +789,10 @@ MH_DEV void wgs_flush_final(int lane, const double* ST, double* E, int I) {
     for (int q = 0; q < 3; ++q) v1[q] = ST[q * 3 * NROW + src3];
     double* d = E + I * NROW;
 #pragma unroll
-    for (int a = 0; a < 9; ++a) d[(unsigned)(a * 3 * NROW + lane)] = v0[a];
+    for (int a = 0; a < 9; ++a) WGS_PIECE_STORE(&d[(unsigned)(a * 3 * NROW + lane)], v0[a]);
 #pragma unroll
     for (int q = 0; q < 3; ++q)
-      if (ok3) d[(unsigned)(q * 9 * NROW + dst3)] = v1[q];
+      if (ok3) WGS_PIECE_STORE(&d[(unsigned)(q * 9 * NROW + dst3)], v1[q]);
   }
   {
     // rows a2 >= 1, b2 = 0: E[2187 + (a - 9) 81 + I 27 + k], k < 27: two rows per instruction (lanes 0..26, 32..58)
@@ -801,7 +804,7 @@ MH_DEV void wgs_flush_final(int lane, const double* ST, double* E, int I) {
     double* d = E + P2Block::off_b20 + I * ND + half * NROW + k;
 #pragma unroll
     for (int r = 0; r < 9; ++r)
-      if (ok) d[(unsigned)(2 * r * NROW)] = w[r];
+      if (ok) WGS_PIECE_STORE(&d[(unsigned)(2 * r * NROW)], w[r]);
   }
 }
 

@@ -38,6 +38,8 @@ typedef double t3_d4 __attribute__((ext_vector_type(4)));
 // with the non-temporal hint (pre-pass 7.48 -> 7.14 ms, 7.6 -> 7.3 ms on a second box; the same hint on the contraction's
 // loads changes nothing, scratch/p3_variants.sh A/B in round 4)
 #define T3_REC_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
+// (the same hint on the contraction's piece stores -- 128-byte runs -- costs 5 ms, 19.5 -> 24.9 ms, and on the gather's piece
+// loads nothing: profiles/r04_cfg3_nt_variants.txt)
 
 constexpr int T3_NB = 4, T3_NQ = 5, T3_ND = 64, T3_NPT = 125, T3_PS = 128, T3_NROW = 192;
 constexpr int T3_REC = 90;                        // 81 Ahat + 9 Phat (the record layout of kernels_tensor_wgs.hpp)
