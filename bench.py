@@ -99,7 +99,7 @@ def recorded_pmc(workload, world, grad, material):
     kernel's 8-byte accesses by scratch/fetch_calib.hip).  bench.py cannot run the profiler on itself, so these are
     RECORDED numbers: returned with their source, and dropped (None) when the kernel sources changed since."""
     key = f"{workload}/{material}/{'grad' if grad else 'residual'}/n{world}"
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f).get(key)
@@ -120,9 +120,20 @@ def recorded_pmc(workload, world, grad, material):
     return None
 
 
-# fp64 work the sum-factorised kernels usefully do per element (SURVEY 8d's F_alg prices the dense
-# B^T A B form: 2.9 / 29 MFLOP) and the chip's fp64 pipe: 1024 SIMDs x 32 flop per cycle x 2.4 GHz = 78.6 TFLOP/s
-USEFUL_FLOP = {2: 0.5e6, 3: 2.8e6}
+def useful_flop(p, dim=3):
+    """fp64 work of the sum-factorised tangent contraction per element, counted from its three stages (DESIGN.md 4.1 / 4.2;
+    SURVEY 8d's F_alg prices the dense B^T A B form instead: 2.9 / 29 MFLOP).  With n = p + 1 nodes and q = p + 2 points per
+    direction, per (i, j) block of the element matrix:
+      S1 contracts q2:  9 (m, n) terms x q^2 points (q0, q1) x n^2 pairs (a2, b2) x q multiply-adds
+      S2 contracts q1:  9 (m, n) terms x q points q0 x n^2 (a1, b1) x n^2 (a2, b2) x q multiply-adds
+      S3 contracts q0:  4 table variants x n^2 (a0, b0) x n^4 pairs x q multiply-adds
+    times 9 blocks, 2 flop per multiply-add: 0.513 MFLOP at p = 2, 2.84 MFLOP at p = 3 (the point work -- F, the material,
+    the pulled-back tangent, the residual -- is < 4 % of that and left out)."""
+    n, q = p + 1, p + 2
+    return 2.0 * dim * dim * (9 * q ** 3 * n ** 2 + 9 * q ** 2 * n ** 4 + 4 * q * n ** 6)
+
+
+# the chip's fp64 pipe: 1024 SIMDs x 32 flop per cycle x 2.4 GHz = 78.6 TFLOP/s
 FP64_PEAK, N_SIMD, CLOCK_HZ = 78.6e12, 1024, 2.4e9
 
 
@@ -141,8 +152,8 @@ def binding_rooflines(p, elements, phase_ms, pmc):
     gath = [k for k in raw if "gather" in k or "p2_kernel" in k]
     cycles = sum(v["mfma_instructions_per_element"] * 64.0 + v["valu_instructions_per_element"] * 4.0 for v in integ.values())
     phase1 = {"resource": "fp64 pipe (matrix and vector fp64 instructions share it on gfx950)", "ms": phase_ms[0],
-              "useful_flop_frac": USEFUL_FLOP.get(p, 0.0) * elements / t1 / FP64_PEAK if t1 > 0 else None,
-              "useful_flop_per_element": USEFUL_FLOP.get(p),
+              "useful_flop_frac": useful_flop(p) * elements / t1 / FP64_PEAK if t1 > 0 else None,
+              "useful_flop_per_element": useful_flop(p),
               "issued_frac": cycles * elements / (N_SIMD * CLOCK_HZ * t1) if integ and t1 > 0 else None,
               "issued_cycles_per_element": cycles if integ else None,
               "peak": "78.6 TFLOP/s = 1024 SIMDs x 32 flop/cycle x 2.4 GHz"}

@@ -129,9 +129,12 @@ constexpr int WGS_REC_FIELDS = 90;
 constexpr int WGS_KIND_RECORD = 100;   // compile-time "material kind" of the kernels that read such records
 
 // FAMILY 0: J2 (24-field record, closed forms in wave X); 1: the other materials (90-field record)
+// FAMILY 0: J2 (closed form); 2..5: that one of the other materials as a compile-time constant (all four in one kernel
+// spilled 168 .. 298 registers, one at a time none)
 template<int FAMILY>
 __global__ __launch_bounds__(256) void tensor_point_kernel(TensorArgs p, int n_el) {
   constexpr int P = 2, NB = 3, NQ = 4, ND = 27, NQ3 = 64;
+  constexpr int FK = FAMILY >= 2 ? FAMILY : -1;
   __shared__ double ue_all[4][3 * ND];
   __shared__ double tab_all[4][6 * NB * NQ];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -182,36 +185,56 @@ __global__ __launch_bounds__(256) void tensor_point_kernel(TensorArgs p, int n_e
       for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * g[(int64_t)(m * 3 + J) * NQ3];
       F[i + J * 3] = sf;
     }
-  if constexpr (FAMILY == 1) {
-    double Pk[9], A[81];
-    const int status = evaluate_other<3>(p.mat, p.dt, p.state, e * NQ3 + lane, F, Pk, A, 1.0);
+  if constexpr (FAMILY != 0) {
+    // the tangent one direction (j, L) at a time, pulled back and accumulated over L as it arrives (27 accumulators per j
+    // instead of all 81 entries of dP/dF: see tp3_point_kernel, tensor_p3.hip)
+    double Pk[9];
+    OtherTangent<3> ot;
+    const int status = other_tangent_begin<3, FK>(p.mat, p.dt, p.state, e * NQ3 + lane, F, Pk, ot);
     double* rec = p.scratch_pt + e * (int64_t)(WGS_REC_FIELDS * NQ3) + lane;
     const double wd = g[(int64_t)9 * NQ3];
     double Ji[9];
+#pragma unroll
     for (int k = 0; k < 9; ++k) Ji[k] = g[(int64_t)k * NQ3];
-    for (int i = 0; i < 3; ++i) {
-      for (int j = 0; j < 3; ++j) {
-        // B[m][L] = sum_J Jinv[m][J] A_iJjL, then Ahat[m][n] = wd sum_L B[m][L] Jinv[n][L]
-        double B[9];
-        for (int m = 0; m < 3; ++m)
-          for (int L = 0; L < 3; ++L) {
-            double t = 0.0;
-            for (int J = 0; J < 3; ++J) t += Ji[m * 3 + J] * A[((i * 3 + J) * 3 + j) * 3 + L];
-            B[m * 3 + L] = t;
-          }
-        for (int m = 0; m < 3; ++m)
-          for (int n = 0; n < 3; ++n) {
-            double t = 0.0;
-            for (int L = 0; L < 3; ++L) t += B[m * 3 + L] * Ji[n * 3 + L];
-            rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * NQ3] = wd * t;
+#pragma unroll 1
+    for (int j = 0; j < 3; ++j) {
+      double acc[27];
+#pragma unroll
+      for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+#pragma unroll 1
+      for (int L = 0; L < 3; ++L) {
+        double dP[9];
+        other_tangent_dir<3, FK>(p.mat, p.dt, F, ot, j, L, dP);
+        double jl[3];     // Jinv[n][L]
+#pragma unroll
+        for (int n = 0; n < 3; ++n) jl[n] = L == 0 ? Ji[n * 3] : (L == 1 ? Ji[n * 3 + 1] : Ji[n * 3 + 2]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            double b = 0.0;
+#pragma unroll
+            for (int J = 0; J < 3; ++J) b += Ji[m * 3 + J] * dP[i + J * 3];
+#pragma unroll
+            for (int n = 0; n < 3; ++n) acc[(i * 3 + m) * 3 + n] += b * jl[n];
           }
       }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * NQ3] = wd * acc[(i * 3 + m) * 3 + n];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
       for (int m = 0; m < 3; ++m) {
         double t = 0.0;
+#pragma unroll
         for (int J = 0; J < 3; ++J) t += Pk[i + J * 3] * Ji[m * 3 + J];
         rec[(int64_t)(81 + i * 3 + m) * NQ3] = wd * t;
       }
-    }
     if (status) atomicOr(p.status, status);
   } else {
     PointResult<3> w;
@@ -955,8 +978,12 @@ inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a) {
     h->scratch_pt.resize((size_t)h->n_el * (record ? WGS_REC_FIELDS : WGS_PT_FIELDS) * 64);
     a.scratch_pt = h->scratch_pt.ptr;
     if (h->phase_select != 2) {
-      hipLaunchKernelGGL(record ? tensor_point_kernel<1> : tensor_point_kernel<0>, dim3((unsigned)((h->n_el + 3) / 4)), dim3(256), 0,
-                         h->stream, a, (int)h->n_el);
+      void (*point_kernel)(TensorArgs, int) =
+          kind == MIMI_HIP_MAT_J2 ? tensor_point_kernel<0>
+          : kind == MIMI_HIP_MAT_STVK ? tensor_point_kernel<MIMI_HIP_MAT_STVK>
+          : kind == MIMI_HIP_MAT_J2LINEAR ? tensor_point_kernel<MIMI_HIP_MAT_J2LINEAR>
+          : kind == MIMI_HIP_MAT_J2SIMO ? tensor_point_kernel<MIMI_HIP_MAT_J2SIMO> : tensor_point_kernel<MIMI_HIP_MAT_J2LOG>;
+      hipLaunchKernelGGL(point_kernel, dim3((unsigned)((h->n_el + 3) / 4)), dim3(256), 0, h->stream, a, (int)h->n_el);
       MH_HIP(hipGetLastError());
     }
   }

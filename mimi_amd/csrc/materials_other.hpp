@@ -501,9 +501,11 @@ MH_DEV int j2log_stress(const MaterialDev& md, double dt, const T* F, OtherState
   return status;
 }
 
-template<int DIM, bool ACCUMULATE, class T>
+// FK >= 0: the material kind as a compile-time constant (the other materials' code is then dead: a kernel that holds all
+// four spills registers the largest one alone does not need -- measured in round 4 on the pre-pass kernels); -1: md.m.kind
+template<int DIM, bool ACCUMULATE, class T, int FK = -1>
 MH_DEV int other_stress(const MaterialDev& md, double dt, const T* F, OtherState& st, T* P, OtherCache& cc) {
-  switch (md.m.kind) {
+  switch (FK >= 0 ? FK : md.m.kind) {
   case MIMI_HIP_MAT_STVK:
     if constexpr (!ACCUMULATE) stvk_stress<DIM>(md.m, F, P);
     return 0;
@@ -515,21 +517,21 @@ MH_DEV int other_stress(const MaterialDev& md, double dt, const T* F, OtherState
 
 // One call per quadrature point: P (column-major) and, when A != nullptr, wd * dP_iJ/dF_jL into
 // A[((i*DIM + J)*DIM + j)*DIM + L] (the layout of tangent_of)
-template<int DIM>
+template<int DIM, int FK = -1>
 MH_DEV int evaluate_other(const MaterialDev& md, double dt, const StateView& sv, int64_t pt, const double* F, double* P,
                           double* A, double wd) {
   constexpr int DD = DIM * DIM;
   OtherState st;
   other_state_load<DIM>(md, sv, pt, st);
   OtherCache cc;
-  int status = other_stress<DIM, false>(md, dt, F, st, P, cc);
+  int status = other_stress<DIM, false, double, FK>(md, dt, F, st, P, cc);
   if (A) {
     for (int jL = 0; jL < DD; ++jL) {   // F(j, L) is stored at j + L*DIM
       Dual Fd[DD], Pd[DD];
 #pragma unroll
       for (int k = 0; k < DD; ++k) Fd[k] = Dual{F[k], k == jL ? 1.0 : 0.0};
       int ignored = 0;
-      ignored |= other_stress<DIM, false>(md, dt, Fd, st, Pd, cc);
+      ignored |= other_stress<DIM, false, Dual, FK>(md, dt, Fd, st, Pd, cc);
       const int j = jL % DIM, L = jL / DIM;
 #pragma unroll
       for (int i = 0; i < DIM; ++i)
@@ -540,14 +542,42 @@ MH_DEV int evaluate_other(const MaterialDev& md, double dt, const StateView& sv,
   return status;
 }
 
+// The same, for callers that consume the tangent one direction at a time instead of holding all DIM^4 entries (the
+// pre-pass kernels: 81 doubles per lane in 3-D were most of their spilled registers): other_tangent_begin leaves P and the
+// state / cache the directional passes share; other_tangent_dir(j, L) returns dP_iJ / dF_jL for every (i, J), column-major.
 template<int DIM>
+struct OtherTangent {
+  OtherState st;
+  OtherCache cc;
+};
+
+template<int DIM, int FK = -1>
+MH_DEV int other_tangent_begin(const MaterialDev& md, double dt, const StateView& sv, int64_t pt, const double* F, double* P,
+                               OtherTangent<DIM>& t) {
+  other_state_load<DIM>(md, sv, pt, t.st);
+  return other_stress<DIM, false, double, FK>(md, dt, F, t.st, P, t.cc);
+}
+
+template<int DIM, int FK = -1>
+MH_DEV void other_tangent_dir(const MaterialDev& md, double dt, const double* F, OtherTangent<DIM>& t, int j, int L, double* dP) {
+  constexpr int DD = DIM * DIM;
+  Dual Fd[DD], Pd[DD];
+  const int jL = j + L * DIM;
+#pragma unroll
+  for (int k = 0; k < DD; ++k) Fd[k] = Dual{F[k], k == jL ? 1.0 : 0.0};
+  (void)other_stress<DIM, false, Dual, FK>(md, dt, Fd, t.st, Pd, t.cc);
+#pragma unroll
+  for (int k = 0; k < DD; ++k) dP[k] = Pd[k].d;
+}
+
+template<int DIM, int FK = -1>
 MH_DEV int accumulate_other(const MaterialDev& md, double dt, const StateView& sv, int64_t pt, const double* F) {
-  if (md.m.kind == MIMI_HIP_MAT_STVK) return 0;
+  if ((FK >= 0 ? FK : md.m.kind) == MIMI_HIP_MAT_STVK) return 0;
   OtherState st;
   other_state_load<DIM>(md, sv, pt, st);
   double unused[DIM * DIM];
   OtherCache cc;
-  const int status = other_stress<DIM, true>(md, dt, F, st, unused, cc);
+  const int status = other_stress<DIM, true, double, FK>(md, dt, F, st, unused, cc);
   other_state_store<DIM>(md, sv, pt, st);
   return status;
 }

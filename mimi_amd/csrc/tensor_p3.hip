@@ -159,12 +159,15 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
   }
 }
 
-// FAMILY 0: closed-form materials (materials.hpp), 1: the others (materials_other.hpp).  GRAD 0: residual pieces only;
+// FAMILY 0: closed-form materials (materials.hpp); 2..5: that one of the other materials (materials_other.hpp) as a
+// compile-time constant -- with all four in one kernel the register allocation spilled 142 .. 360 registers, one at a time
+// none.  GRAD 0: residual pieces only;
 // 2: DomainPostTimeAdvance (nonlinear_solid.cpp:179-199) -- F at the points as for an assembly, then the material's state
 // commit, nothing else (the degree-2 commit kernel's direct 64-node sum per point spilled 821 registers at degree 3)
 template<int FAMILY, int GRAD>
 __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
   constexpr int NB = T3_NB, NQ = T3_NQ, ND = T3_ND, NPT = T3_NPT, PS = T3_PS;
+  constexpr int FK = FAMILY >= 2 ? FAMILY : -1;
   __shared__ double ue[3 * ND];
   __shared__ double tab[6 * NB * NQ];       // [dir][B, D][a][q]
   __shared__ double PH[9 * NPT];            // Phat [i*3 + m][point]
@@ -245,15 +248,52 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
       }
     if constexpr (GRAD == 2) {
       int st;
-      if constexpr (FAMILY == 1) st = accumulate_other<3>(p.mat, p.dt, p.state, e * NPT + tid, F);
+      if constexpr (FAMILY != 0) st = accumulate_other<3, FK>(p.mat, p.dt, p.state, e * NPT + tid, F);
       else st = accumulate_state<3>(p.mat, p.dt, p.state, e * NPT + tid, F);
       if (st) atomicOr(p.status, st);
       return;
     }
-    double Pk[9], A[(GRAD == 1 && FAMILY == 1) ? 81 : 1];
+    double Pk[9];
     int status;
-    if constexpr (FAMILY == 1) {
-      status = evaluate_other<3>(p.mat, p.dt, p.state, e * NPT + tid, F, Pk, GRAD == 1 ? A : nullptr, 1.0);
+    if constexpr (FAMILY != 0 && GRAD == 1) {
+      // the other materials' tangent one direction (j, L) at a time, pulled back and accumulated over L as it arrives:
+      // Ahat_i[m][j][n] = wd sum_L (sum_J Jinv[m][J] dP_iJ/dF_jL) Jinv[n][L] -- 27 accumulators per j instead of the 81
+      // entries of dP/dF (which, with the material's own working set, spilled 360 registers)
+      OtherTangent<3> ot;
+      status = other_tangent_begin<3, FK>(p.mat, p.dt, p.state, e * NPT + tid, F, Pk, ot);
+      double* rec = p.scratch_pt + e * (int64_t)(T3_REC * PS) + tid;
+#pragma unroll 1
+      for (int j = 0; j < 3; ++j) {
+        double acc[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+#pragma unroll 1
+        for (int L = 0; L < 3; ++L) {
+          double dP[9];
+          other_tangent_dir<3, FK>(p.mat, p.dt, F, ot, j, L, dP);
+          double jl[3];     // Jinv[n][L] (selects: a register array indexed by a loop variable would go to scratch memory)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) jl[n] = L == 0 ? Ji[n * 3] : (L == 1 ? Ji[n * 3 + 1] : Ji[n * 3 + 2]);
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+              double b = 0.0;
+#pragma unroll
+              for (int J = 0; J < 3; ++J) b += Ji[m * 3 + J] * dP[i + J * 3];
+#pragma unroll
+              for (int n = 0; n < 3; ++n) acc[(i * 3 + m) * 3 + n] += b * jl[n];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int n = 0; n < 3; ++n) rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS] = wd * acc[(i * 3 + m) * 3 + n];
+      }
+    } else if constexpr (FAMILY != 0) {
+      status = evaluate_other<3, FK>(p.mat, p.dt, p.state, e * NPT + tid, F, Pk, nullptr, 1.0);
     } else {
       PointResult<3> w;
       status = evaluate_pk1<3>(p.mat, p.dt, p.state, e * NPT + tid, F, w);
@@ -271,35 +311,6 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
         for (int J = 0; J < 3; ++J) t += Pk[i + J * 3] * Ji[m * 3 + J];
         PH[(i * 3 + m) * NPT + tid] = wd * t;
       }
-    if constexpr (GRAD == 1 && FAMILY == 1) {
-      double* rec = p.scratch_pt + e * (int64_t)(T3_REC * PS) + tid;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          // B[m][L] = sum_J Jinv[m][J] A_iJjL, then Ahat[m][n] = wd sum_L B[m][L] Jinv[n][L]
-          double B[9];
-#pragma unroll
-          for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int L = 0; L < 3; ++L) {
-              double t = 0.0;
-#pragma unroll
-              for (int J = 0; J < 3; ++J) t += Ji[m * 3 + J] * A[((i * 3 + J) * 3 + j) * 3 + L];
-              B[m * 3 + L] = t;
-            }
-#pragma unroll
-          for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int n = 0; n < 3; ++n) {
-              double t = 0.0;
-#pragma unroll
-              for (int L = 0; L < 3; ++L) t += B[m * 3 + L] * Ji[n * 3 + L];
-              rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS] = wd * t;
-            }
-        }
-      }
-    }
   }
   if constexpr (GRAD == 2) return;
   __syncthreads();
@@ -957,6 +968,19 @@ bool tensor_p3_ready(const mimi_hip_domain_s* h) {
          (h->structured_csr || h->structured_perm) && h->first_is_identity;
 }
 
+// the pre-pass kernel of a material kind (one instantiation per kind: see tp3_point_kernel)
+template<int GRAD>
+static auto t3_point_kernel_of(int kind) -> void (*)(TensorArgs) {
+  switch (kind) {
+  case MIMI_HIP_MAT_NEOHOOKEAN:
+  case MIMI_HIP_MAT_J2: return tp3_point_kernel<0, GRAD>;
+  case MIMI_HIP_MAT_STVK: return tp3_point_kernel<MIMI_HIP_MAT_STVK, GRAD>;
+  case MIMI_HIP_MAT_J2LINEAR: return tp3_point_kernel<MIMI_HIP_MAT_J2LINEAR, GRAD>;
+  case MIMI_HIP_MAT_J2SIMO: return tp3_point_kernel<MIMI_HIP_MAT_J2SIMO, GRAD>;
+  default: return tp3_point_kernel<MIMI_HIP_MAT_J2LOG, GRAD>;
+  }
+}
+
 void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {
   const int kind = h->mat.m.kind;
   const bool closed = kind == MIMI_HIP_MAT_NEOHOOKEAN || kind == MIMI_HIP_MAT_J2;
@@ -973,9 +997,7 @@ void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {
   }
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[0], h->stream));
   if (h->phase_select != 2) {
-    auto kernel = grad ? (closed ? tp3_point_kernel<0, 1> : tp3_point_kernel<1, 1>)
-                       : (closed ? tp3_point_kernel<0, 0> : tp3_point_kernel<1, 0>);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)h->n_el), dim3(128), 0, h->stream, a);
+    hipLaunchKernelGGL(grad ? t3_point_kernel_of<1>(kind) : t3_point_kernel_of<0>(kind), dim3((unsigned)h->n_el), dim3(128), 0, h->stream, a);
     MH_HIP(hipGetLastError());
   }
   h->phase_has_prepass = true;
@@ -999,8 +1021,7 @@ void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {
 void launch_tensor_p3_post(mimi_hip_domain_s* h, TensorArgs a) {
   const int kind = h->mat.m.kind;
   const bool closed = kind == MIMI_HIP_MAT_NEOHOOKEAN || kind == MIMI_HIP_MAT_J2;
-  auto kernel = closed ? tp3_point_kernel<0, 2> : tp3_point_kernel<1, 2>;
-  hipLaunchKernelGGL(kernel, dim3((unsigned)h->n_el), dim3(128), 0, h->stream, a);
+  hipLaunchKernelGGL(t3_point_kernel_of<2>(kind), dim3((unsigned)h->n_el), dim3(128), 0, h->stream, a);
   MH_HIP(hipGetLastError());
 }
 
