@@ -793,9 +793,10 @@ MH_DEV void wgs_stage_carry(const WgsLane& lc, const double (&C)[9], double* st_
   }
 }
 
-// the element pieces are written once here and read once by phase 2 (8 GB at the north-star size): stored with the
-// non-temporal hint (same-box A/B in round 4, scratch/p2_ablate.py: step 7.18 -> 7.09 ms, both phases gain)
-#define WGS_PIECE_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
+// (the pieces stored with the non-temporal hint: step 7.18 -> 7.09 ms on one box, but WRITE_SIZE of this kernel 8.2 -> 9.9 GB
+// -- the runs of 81 / 27 doubles are not whole lines and the hint takes them past the write combining of L2 --: not kept,
+// profiles/r04_northstar_nt_pieces.txt)
+#define WGS_PIECE_STORE(ptr, v) (*(ptr) = (v))
 // buffer (compact: nine rows of 81, eighteen rows of 27) -> this piece's runs in the element block E (P2Block)
 MH_DEV void wgs_flush_final(int lane, const double* ST, double* E, int I) {
   constexpr int NROW = 81, ND = 27;
