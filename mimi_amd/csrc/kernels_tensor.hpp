@@ -608,69 +608,6 @@ __global__ __launch_bounds__(64) void tensor_domain_kernel(TensorArgs p) {
   if (status) atomicOr(p.status, status);
 }
 
-// DomainPostTimeAdvance: one lane per quadrature point, wave per element (degree 2; degree 3: tensor_p3.hip).  FAMILY 0:
-// closed-form materials (materials.hpp), 1: the others (materials_other.hpp)
-template<int P, int FAMILY>
-__global__ __launch_bounds__(256) void tensor_post_kernel(TensorArgs p, int n_el) {
-  using L = TensorLds<P>;
-  constexpr int NB = L::NB, NQ = L::NQ, ND = L::ND, NQ3 = L::NQ3;
-  __shared__ double ue_all[4][3 * ND];
-  __shared__ double tab_all[4][6 * NB * NQ];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t e = (int64_t)blockIdx.x * 4 + wave;
-  if (e >= n_el) return;
-  double* ue = ue_all[wave];
-  double* tab = tab_all[wave];
-  int el[3];
-  el[0] = e % p.box_n[0];
-  el[1] = (e / p.box_n[0]) % p.box_n[1];
-  el[2] = e / ((int64_t)p.box_n[0] * p.box_n[1]);
-  const int32_t* dofs = p.dofs + e * ND;
-  for (int a = lane; a < ND; a += 64) {
-    const int64_t node = dofs[a];
-    for (int c = 0; c < 3; ++c) ue[c * ND + a] = p.u[node * 3 + c];
-  }
-  for (int t = lane; t < 6 * NB * NQ; t += 64) {
-    const int dir = t / (2 * NB * NQ), rem = t % (2 * NB * NQ), isD = rem / (NB * NQ), k = rem % (NB * NQ);
-    const int span = p.box_begin[dir] + el[dir];
-    tab[t] = ((isD ? p.tabD[dir] : p.tabB[dir]) + (int64_t)span * NB * NQ)[k];
-  }
-  __builtin_amdgcn_s_waitcnt(0);
-  __builtin_amdgcn_wave_barrier();
-  int status = 0;
-  for (int q = lane; q < NQ3; q += 64) {
-    const int q0 = q % NQ, q1 = (q / NQ) % NQ, q2 = q / (NQ * NQ);
-    double H[9];
-    for (int k = 0; k < 9; ++k) H[k] = 0.0;
-    for (int a2 = 0; a2 < NB; ++a2)
-      for (int a1 = 0; a1 < NB; ++a1)
-        for (int a0 = 0; a0 < NB; ++a0) {
-          const int a = a0 + NB * (a1 + NB * a2);
-          const double b0 = tab_ptr<P>(tab, 0, 0)[a0 * NQ + q0], d0 = tab_ptr<P>(tab, 0, 1)[a0 * NQ + q0];
-          const double b1 = tab_ptr<P>(tab, 1, 0)[a1 * NQ + q1], d1 = tab_ptr<P>(tab, 1, 1)[a1 * NQ + q1];
-          const double b2 = tab_ptr<P>(tab, 2, 0)[a2 * NQ + q2], d2 = tab_ptr<P>(tab, 2, 1)[a2 * NQ + q2];
-          const double dn0 = d0 * b1 * b2, dn1 = b0 * d1 * b2, dn2 = b0 * b1 * d2;
-          for (int i = 0; i < 3; ++i) {
-            const double uu = ue[i * ND + a];
-            H[i * 3 + 0] += uu * dn0;
-            H[i * 3 + 1] += uu * dn1;
-            H[i * 3 + 2] += uu * dn2;
-          }
-        }
-    const double* g = p.geo + e * 10 * NQ3 + q;
-    double F[9];
-    for (int i = 0; i < 3; ++i)
-      for (int J = 0; J < 3; ++J) {
-        double s = (i == J) ? 1.0 : 0.0;
-        for (int m = 0; m < 3; ++m) s += H[i * 3 + m] * g[(int64_t)(m * 3 + J) * NQ3];
-        F[i + J * 3] = s;
-      }
-    if constexpr (FAMILY == 0) status |= accumulate_state<3>(p.mat, p.dt, p.state, e * NQ3 + q, F);
-    else status |= accumulate_other<3>(p.mat, p.dt, p.state, e * NQ3 + q, F);
-  }
-  if (status) atomicOr(p.status, status);
-}
-
 inline bool tensor_supported(int dim, const int* degree, int nq) {
   // 3-D degree 2 (kernels_tensor_wgs*.hpp), 3-D degree 3 (tensor_p3.hip); 2-D degree 1..3 and 3-D degree 1
   // (kernels_tensor_small.hpp)

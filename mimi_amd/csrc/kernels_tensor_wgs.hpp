@@ -128,10 +128,12 @@ MH_DEV void wgs_point_load(const double* rec, int lane, PointResult<3>& w, doubl
 constexpr int WGS_REC_FIELDS = 90;
 constexpr int WGS_KIND_RECORD = 100;   // compile-time "material kind" of the kernels that read such records
 
-// FAMILY 0: J2 (24-field record, closed forms in wave X); 1: the other materials (90-field record)
-// FAMILY 0: J2 (closed form); 2..5: that one of the other materials as a compile-time constant (all four in one kernel
-// spilled 168 .. 298 registers, one at a time none)
-template<int FAMILY>
+// FAMILY 0: J2 (24-field record, closed forms in wave X); 2..5: that one of the other materials (90-field record) as a
+// compile-time constant (all four in one kernel spilled 168 .. 298 registers, one at a time none).
+// COMMIT 1: DomainPostTimeAdvance (nonlinear_solid.cpp:179-199) -- F at the points as for an assembly, then the material's
+// state commit and nothing else (round 4: the separate commit kernel's unrolled 27-node sum took 432 registers, one wave per
+// SIMD: 4.8 ms for the 16.8 M points of the north-star mesh with J2)
+template<int FAMILY, int COMMIT = 0>
 __global__ __launch_bounds__(256) void tensor_point_kernel(TensorArgs p, int n_el) {
   constexpr int P = 2, NB = 3, NQ = 4, ND = 27, NQ3 = 64;
   constexpr int FK = FAMILY >= 2 ? FAMILY : -1;
@@ -161,7 +163,9 @@ __global__ __launch_bounds__(256) void tensor_point_kernel(TensorArgs p, int n_e
   const int q0 = lane % NQ, q1 = (lane / NQ) % NQ, q2 = lane / (NQ * NQ);
   double H[9];
   for (int k = 0; k < 9; ++k) H[k] = 0.0;
+#pragma unroll 1
   for (int a2 = 0; a2 < NB; ++a2)
+#pragma unroll 1
     for (int a1 = 0; a1 < NB; ++a1)
       for (int a0 = 0; a0 < NB; ++a0) {
         const int a = a0 + NB * (a1 + NB * a2);
@@ -185,6 +189,13 @@ __global__ __launch_bounds__(256) void tensor_point_kernel(TensorArgs p, int n_e
       for (int m = 0; m < 3; ++m) sf += H[i * 3 + m] * g[(int64_t)(m * 3 + J) * NQ3];
       F[i + J * 3] = sf;
     }
+  if constexpr (COMMIT) {
+    int st;
+    if constexpr (FAMILY != 0) st = accumulate_other<3, FK>(p.mat, p.dt, p.state, e * NQ3 + lane, F);
+    else st = accumulate_state<3>(p.mat, p.dt, p.state, e * NQ3 + lane, F);
+    if (st) atomicOr(p.status, st);
+    return;
+  }
   if constexpr (FAMILY != 0) {
     // the tangent one direction (j, L) at a time, pulled back and accumulated over L as it arrives (27 accumulators per j
     // instead of all 81 entries of dP/dF: see tp3_point_kernel, tensor_p3.hip)
@@ -1000,6 +1011,18 @@ inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a) {
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[1], h->stream));
   if (h->phase_select != 1) launch_tensor_p2(h, a);
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[2], h->stream));
+}
+
+// DomainPostTimeAdvance at degree 2: the pre-pass kernel in its commit mode
+inline void launch_tensor_p2_post(mimi_hip_domain_s* h, TensorArgs a) {
+  const int kind = h->mat.m.kind;
+  void (*kernel)(TensorArgs, int) =
+      (kind == MIMI_HIP_MAT_J2 || kind == MIMI_HIP_MAT_NEOHOOKEAN) ? tensor_point_kernel<0, 1>
+      : kind == MIMI_HIP_MAT_STVK ? tensor_point_kernel<MIMI_HIP_MAT_STVK, 1>
+      : kind == MIMI_HIP_MAT_J2LINEAR ? tensor_point_kernel<MIMI_HIP_MAT_J2LINEAR, 1>
+      : kind == MIMI_HIP_MAT_J2SIMO ? tensor_point_kernel<MIMI_HIP_MAT_J2SIMO, 1> : tensor_point_kernel<MIMI_HIP_MAT_J2LOG, 1>;
+  hipLaunchKernelGGL(kernel, dim3((unsigned)((h->n_el + 3) / 4)), dim3(256), 0, h->stream, a, (int)h->n_el);
+  MH_HIP(hipGetLastError());
 }
 
 }  // namespace mimi_hip

@@ -11,6 +11,7 @@ inline bool two_phase_supported(const mimi_hip_domain_s* h);                    
 inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a);               // kernels_tensor_wgs.hpp
 inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a);             // kernels_tensor_wgsym.hpp
 inline void launch_tensor_residual(mimi_hip_domain_s* h, TensorArgs a);          // kernels_tensor_residual.hpp
+inline void launch_tensor_p2_post(mimi_hip_domain_s* h, TensorArgs a);           // kernels_tensor_wgs.hpp
 static void ensure_pair_pos(mimi_hip_domain_s* h);                                // domain.hip
 
 // can this handle's assembly run on the tensor kernels?  (p = 3 has the two-phase kernels only)
@@ -55,12 +56,7 @@ inline void launch_tensor_post(mimi_hip_domain_s* h, const double* u) {
     launch_tensor_p3_post(h, a);
     return;
   }
-  const int blocks = (h->n_el + 3) / 4;
-  if (h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN || h->mat.m.kind == MIMI_HIP_MAT_J2)
-    hipLaunchKernelGGL((tensor_post_kernel<2, 0>), dim3(blocks), dim3(256), 0, h->stream, a, h->n_el);
-  else
-    hipLaunchKernelGGL((tensor_post_kernel<2, 1>), dim3(blocks), dim3(256), 0, h->stream, a, h->n_el);
-  MH_HIP(hipGetLastError());
+  launch_tensor_p2_post(h, a);
 }
 
 }  // namespace mimi_hip
