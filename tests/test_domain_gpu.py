@@ -186,7 +186,7 @@ def test_element_boxes_add_up_to_the_whole(axis, matname):
     u = synthetic_u(P, scale=0.05 if matname == "neohook" else 0.02)
     r_o, A_o = np.zeros(P.n_vdofs), np.zeros(D.nnz)
     D.add_domain_residual_and_grad(u, 1.0, r_o, A_o, rp.TANGENT_EXACT)
-    r_g, A_g = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    r_g, A_g, r_only = np.zeros(P.n_vdofs), np.zeros(D.nnz), np.zeros(P.n_vdofs)
     cuts = [0, 2, n_el[axis]] if axis != 2 else [0, 2, 3, n_el[axis]]   # a one-element slab along the walked axis too
     for b, e in zip(cuts[:-1], cuts[1:]):
         begin, end = [0, 0, 0], list(n_el)
@@ -195,8 +195,12 @@ def test_element_boxes_add_up_to_the_whole(axis, matname):
         assert G.path_ == 1
         G.dt_ = 0.5
         G.AddDomainResidualAndGrad(u, 1.0, r_g, A_g)
+        # the residual-only assembly of the same box (neo-Hookean: one wave per element column of the BOX, the columns cut
+        # where the box ends along the walked axis; J2: one wave per element)
+        G.AddDomainResidual(u, r_only)
     assert relmax(r_g, r_o) < 1e-12
     assert relmax(A_g, A_o) < 1e-11
+    assert relmax(r_only, r_o) < 1e-12
 
 
 def test_element_boxes_p3_general_path(monkeypatch):
@@ -576,3 +580,23 @@ def test_residual_and_grad_from_a_base_array(case, residence):
     G.AddDomainResidualAndGradFrom(u_x, gf, r_q, A_q, A_q)
     G.Synchronize()
     assert np.array_equal(host(A_q), host(out_x))
+
+
+def test_residual_only_column_kernel_is_bitwise_reproducible_and_agrees_with_the_tangent_assembly():
+    """AddDomainResidual of the neo-Hookean law (round 4: one wave per element column, plane accumulators, 9-column node
+    gather -- nonlinear_solid.cpp:151-160): the same bits in every run, and the residual the residual+Jacobian assembly
+    produces for the same u to rounding (two different kernels: 1e-13 of the largest entry)."""
+    P, D, G = make_pair((7, 5, 6), 2, None, "neohook", "bspline")
+    u = synthetic_u(P)
+    runs = []
+    for _ in range(3):
+        r = np.zeros(P.n_vdofs)
+        G.AddDomainResidual(u, r)
+        runs.append(r)
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+    r2, A2 = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+    G.AddDomainResidualAndGrad(u, 1.0, r2, A2)
+    assert relmax(runs[0], r2) < 1e-13
+    r_o = np.zeros(P.n_vdofs)
+    D.add_domain_residual(u, r_o)
+    assert relmax(runs[0], r_o) < 1e-12
