@@ -815,8 +815,11 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
 // phase 2
 // ------------------------------------------------------------------------------------------------
 // One wave per (node A of the shard's node box, component i).  WITH_K 0: residual rows only.
+// Four waves per SIMD (round 4): 133 registers left room for three; capped at 128 (two spilled) the gather of BASELINE
+// configuration 3 takes 9.61 instead of 10.15 ms on the same box, same bits (it waits on memory three quarters of its cycles;
+// its 33 KB of LDS per workgroup admit four workgroups per CU)
 template<int WITH_K>
-__global__ __launch_bounds__(256) void tp3_gather_kernel(TensorArgs p, int64_t n_rows) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void tp3_gather_kernel(TensorArgs p, int64_t n_rows) {
   constexpr int P = 3, NB = T3_NB, ND = T3_ND;
   constexpr int LMAX = 3 * 343;
   __shared__ double img_all[WITH_K ? 4 : 1][LMAX + 3];
