@@ -314,9 +314,17 @@ MH_DEV void neo_hookean_stress(const mimi_hip_material& m, const double* F, Poin
 
 // J2::PlasticStress<false> when ACCUMULATE == false; <true> otherwise (then the state
 // arguments are updated in place and no stress is produced).
-template<int DIM, bool ACCUMULATE>
+// Park: a caller's hook around the return mapping.  The scalar Newton solve needs none of the tensors of the trial state,
+// but they are live across it (F^-1 and the trial deviator: 36 registers in 3-D); a kernel that wants a third wave per SIMD
+// hands them to LDS for the duration of the solve (tp3_point_kernel, tensor_p3.hip).  NoPark: nothing happens.
+struct NoPark {
+  template<int DD> MH_DEV void save(const double (&)[DD], const double (&)[DD]) const {}
+  template<int DD> MH_DEV void restore(double (&)[DD], double (&)[DD]) const {}
+};
+
+template<int DIM, bool ACCUMULATE, class Park = NoPark>
 MH_DEV int j2_stress(const MaterialDev& md, double dt, const double* F, double* ep, double& eqps,
-                     double& temperature, PointResult<DIM>& w) {
+                     double& temperature, PointResult<DIM>& w, const Park& park = Park{}) {
   const mimi_hip_material& m = md.m;
   constexpr int DD = DIM * DIM;
   double eps[DD], s[DD];
@@ -344,8 +352,6 @@ MH_DEV int j2_stress(const MaterialDev& md, double dt, const double* F, double* 
   for (int i = 0; i < DD; ++i) nrm += s[i] * s[i];
   nrm = sqrt(nrm);
   const double q = sqrt(3.0 / 2.0) * nrm;
-#pragma unroll
-  for (int i = 0; i < DD; ++i) w.s_trial[i] = s[i];
   w.q = q;
   w.plastic = false;
   w.delta = 0;
@@ -355,10 +361,19 @@ MH_DEV int j2_stress(const MaterialDev& md, double dt, const double* F, double* 
   const double tolerance = md.sigma_y_ref * 1.e-10;
   int status = 0;
   const RmPoint at0 = rm_eval(m, c, 0.0);
-  if (at0.R.v > tolerance) {
+  const bool yields = at0.R.v > tolerance;
+  RmPoint sol;
+  double delta = 0.0;
+  // (what is needed behind the solve: F^-1 and the deviator for the stress; the plastic strain and the deviator for a commit)
+  if constexpr (ACCUMULATE) park.save(reinterpret_cast<double (&)[DD]>(*ep), s); else park.save(w.Finv, s);
+  if (yields) {
     const double upper = (q - at0.H.v * c.thermo) / (3.0 * m.G);
-    RmPoint sol;
-    const double delta = scalar_solve(m, c, at0, 0.0, 0.0, upper, 1.e-10, tolerance, 100, status, sol);
+    delta = scalar_solve(m, c, at0, 0.0, 0.0, upper, 1.e-10, tolerance, 100, status, sol);
+  }
+  if constexpr (ACCUMULATE) park.restore(reinterpret_cast<double (&)[DD]>(*ep), s); else park.restore(w.Finv, s);
+#pragma unroll
+  for (int i = 0; i < DD; ++i) w.s_trial[i] = s[i];
+  if (yields) {
     w.plastic = true;
     w.delta = delta;
     const double npf = 1.5 / q;
@@ -490,9 +505,9 @@ MH_DEV void tangent_row_of(const mimi_hip_material& m, const PointResult<DIM>& w
 }
 
 // One call per quadrature point.  pt indexes the SoA state; F is (i,J) column-major.
-template<int DIM>
+template<int DIM, class Park = NoPark>
 MH_DEV int evaluate_pk1(const MaterialDev& md, double dt, const StateView& st, int64_t pt, const double* F,
-                        PointResult<DIM>& w) {
+                        PointResult<DIM>& w, const Park& park = Park{}) {
   if (md.m.kind == MIMI_HIP_MAT_NEOHOOKEAN) {
     neo_hookean_stress<DIM>(md.m, F, w);
     return 0;
@@ -501,18 +516,19 @@ MH_DEV int evaluate_pk1(const MaterialDev& md, double dt, const StateView& st, i
 #pragma unroll
   for (int c = 0; c < DIM * DIM; ++c) ep[c] = st.plastic_strain[c * st.n_pts + pt];
   double eqps = st.eqps[pt], T = st.temperature[pt];
-  return j2_stress<DIM, false>(md, dt, F, ep, eqps, T, w);
+  return j2_stress<DIM, false, Park>(md, dt, F, ep, eqps, T, w, park);
 }
 
-template<int DIM>
-MH_DEV int accumulate_state(const MaterialDev& md, double dt, const StateView& st, int64_t pt, const double* F) {
+template<int DIM, class Park = NoPark>
+MH_DEV int accumulate_state(const MaterialDev& md, double dt, const StateView& st, int64_t pt, const double* F,
+                            const Park& park = Park{}) {
   if (md.m.kind != MIMI_HIP_MAT_J2) return 0;
   double ep[DIM * DIM];
 #pragma unroll
   for (int c = 0; c < DIM * DIM; ++c) ep[c] = st.plastic_strain[c * st.n_pts + pt];
   double eqps = st.eqps[pt], T = st.temperature[pt];
   PointResult<DIM> w;
-  const int status = j2_stress<DIM, true>(md, dt, F, ep, eqps, T, w);
+  const int status = j2_stress<DIM, true, Park>(md, dt, F, ep, eqps, T, w, park);
   if (w.plastic) {
 #pragma unroll
     for (int c = 0; c < DIM * DIM; ++c) st.plastic_strain[c * st.n_pts + pt] = ep[c];

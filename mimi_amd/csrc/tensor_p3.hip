@@ -159,6 +159,39 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
   }
 }
 
+// What the J2 return mapping does not need while it iterates, handed to LDS for its duration (materials.hpp j2_stress, Park):
+// a 3 x 3 tensor (9) and the trial deviator (6: it is symmetric to the bit -- 0.5 (F_ij + F_ji) - ep_ij with ep built from
+// it), [k][128] in the pool behind PH.  Used by the state commit (GRAD 2: plastic strain + deviator): 158 registers instead
+// of 213, a third wave per SIMD, 5.67 -> 4.96 ms at BASELINE configuration 3 (the kernel is latency-bound: ONE wave per
+// SIMD costs 1.75 x, measured).  The assembling modes do not take it: parked (F^-1 + deviator) they need 179 / 181
+// registers, still two waves, and lose 0.3 - 0.4 ms to the detour; capped at 168 they spill 10 - 16 registers inside the
+// solve and gain nothing (profiles/r04_cfg3_prepass_variants.txt).
+struct T3Park {
+  double* slot;
+  MH_DEV void save(const double (&Finv)[9], const double (&s)[9]) const {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) slot[k * 128] = Finv[k];
+    slot[9 * 128] = s[0];
+    slot[10 * 128] = s[4];
+    slot[11 * 128] = s[8];
+    slot[12 * 128] = s[1];
+    slot[13 * 128] = s[2];
+    slot[14 * 128] = s[5];
+    asm volatile("" ::: "memory");
+  }
+  MH_DEV void restore(double (&Finv)[9], double (&s)[9]) const {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Finv[k] = slot[k * 128];
+    s[0] = slot[9 * 128];
+    s[4] = slot[10 * 128];
+    s[8] = slot[11 * 128];
+    s[1] = s[3] = slot[12 * 128];
+    s[2] = s[6] = slot[13 * 128];
+    s[5] = s[7] = slot[14 * 128];
+  }
+};
+
 // FAMILY 0: closed-form materials (materials.hpp); 2..5: that one of the other materials (materials_other.hpp) as a
 // compile-time constant -- with all four in one kernel the register allocation spilled 142 .. 360 registers, one at a time
 // none.  GRAD 0: residual pieces only;
@@ -170,9 +203,12 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
   constexpr int FK = FAMILY >= 2 ? FAMILY : -1;
   __shared__ double ue[3 * ND];
   __shared__ double tab[6 * NB * NQ];       // [dir][B, D][a][q]
-  __shared__ double PH[9 * NPT];            // Phat [i*3 + m][point]
-  __shared__ double V[9 * NB * NQ * NQ];    // [i*3 + m][a2][q0 + 5 q1]
-  __shared__ double W[9 * NB * NB * NQ];    // [i*3 + m][a1 + 4 a2][q0]
+  // one pool: PH | V | W | 300 more.  V, W and the tail are free while the points are evaluated (the grad u stages are done,
+  // the residual stages not begun): the J2 return mapping parks F^-1 and the trial deviator there (T3Park)
+  __shared__ double pool[9 * NPT + 9 * NB * NQ * NQ + 9 * NB * NB * NQ + 300];
+  double* PH = pool;                        // Phat [i*3 + m][point]
+  double* V = pool + 9 * NPT;               // [i*3 + m][a2][q0 + 5 q1]
+  double* W = V + 9 * NB * NQ * NQ;         // [i*3 + m][a1 + 4 a2][q0]
   const int tid = threadIdx.x;
   const int64_t e = blockIdx.x;
   int el[3];
@@ -217,9 +253,9 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
     }
     __syncthreads();
   }
+  double H[9];
   if (tid < NPT) {
     const int q2 = tid / (NQ * NQ), q01 = tid % (NQ * NQ);
-    double H[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -231,6 +267,9 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
         for (int a2 = 0; a2 < NB; ++a2) sv += T[a2 * NQ] * S[a2];
         H[i * 3 + k] = sv;
       }
+  }
+  if constexpr (GRAD == 2) __syncthreads();      // (V and W are free from here on: T3Park)
+  if (tid < NPT) {
     const double* g = p.geo + e * 10 * NPT + tid;
     double Ji[9];
 #pragma unroll
@@ -249,7 +288,7 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
     if constexpr (GRAD == 2) {
       int st;
       if constexpr (FAMILY != 0) st = accumulate_other<3, FK>(p.mat, p.dt, p.state, e * NPT + tid, F);
-      else st = accumulate_state<3>(p.mat, p.dt, p.state, e * NPT + tid, F);
+      else st = accumulate_state<3>(p.mat, p.dt, p.state, e * NPT + tid, F, T3Park{V + tid});
       if (st) atomicOr(p.status, st);
       return;
     }
