@@ -551,7 +551,14 @@ MH_DEV double t3_bc(double table) {   // table[lane N of the row] in every lane 
   return c;
 }
 // the wait states between a matrix write and a store / LDS read of its result (nothing is padded inside asm)
-MH_DEV void t3_results_guard() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+// (round 4: sized by the disassembly lint, tests/test_isa_lint_cpu.py -- without it the first stores of the plane tiles come 3
+// wait states behind their matrix instructions, 18 are required: 16 more.  It was `s_nop 15; s_nop 15`, 32 wait states,
+// before the lint could say how many are needed.  T3_LINT_DROP_RESULTS_GUARD: the lint's own negative test compiles it away.)
+#ifdef T3_LINT_DROP_RESULTS_GUARD
+MH_DEV void t3_results_guard() { asm volatile("" ::: "memory"); }
+#else
+MH_DEV void t3_results_guard() { asm volatile("s_nop 15" ::: "memory"); }
+#endif
 
 // Lane layout of v_mfma_f64_16x16x4 (gfx950): A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15],
 // D register r: [row = (lane >> 4) + 4 r][col = lane & 15].
@@ -710,11 +717,12 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(DV[mn]) : "a"(aop[mn][1]), "v"(bS2V[v2]));
     }
     // the matrix results are read by the vector pipe from here on.  Nothing pads wait states behind asm matrix
-    // instructions, and the S1 statements above are not volatile (the compiler places most of them behind this pair):
-    // what holds the schedule to the 19 / 18 wait states gfx950 needs is the disassembly lint of
-    // tests/test_isa_lint_cpu.py (mimi_amd/isa_lint.py: nearest vector read of a result 42 wait states, nearest store 35,
-    // with or without this pair), not this statement -- it stays as a scheduling fence (memory clobber).
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    // instructions, and the S1 statements above are not volatile: what holds the schedule to the 19 / 18 wait states
+    // gfx950 needs is the disassembly lint of tests/test_isa_lint_cpu.py (mimi_amd/isa_lint.py: the nearest vector read of an
+    // S1 result is 42 wait states away -- the loads and the address arithmetic of the next element sit in between).  Rounds
+    // 2-3 had `s_nop 15; s_nop 15` here; the lint showed that pair protects nothing (the compiler moved most of the S1
+    // instructions behind it anyway), so only the scheduling fence is left.
+    asm volatile("" ::: "memory");
     // the operands of the next element travel while this one is contracted
     request(es + 1 < n_seq ? es + 1 : es);   // (the last element once more: no branch in the loop)
     const int64_t e = e0 + e_step * es;

@@ -34,7 +34,21 @@ def test_degree3_contraction_kernel_is_hazard_free_and_spill_free(need):
     assert stats["vgpr_spill_count"] == 0
     # the margins of the shipped schedule (informative: a change here is a change of the schedule, not yet a hazard)
     assert stats["nearest_valu_read"] >= need["valu_read"] and stats["nearest_mem"] >= need["mem_read"]
+    assert stats["nearest_dpp_def"] is None or stats["nearest_dpp_def"] >= need["dpp_def"]
     print("tp3_contract_kernel", stats)
+
+
+def test_the_lint_turns_red_on_the_shipped_kernel_without_its_results_guard(need):
+    """tensor_p3.hip's t3_results_guard (one `s_nop 15` behind the S3 matrix instructions of the plane tiles) is what keeps
+    the stores of those tiles 18 wait states behind their producers: compiled away (-DT3_LINT_DROP_RESULTS_GUARD, a switch
+    that exists for this test) the first stores follow after 3, and the lint must say so.  (The `s_nop` pair rounds 2-3 had
+    behind S1 protected nothing -- the lint showed 42 wait states to the first reader with or without it -- and is gone;
+    the pair behind S3 was 32 wait states where 16 are needed.)"""
+    asm = L.assembly("tensor_p3.hip", out=os.path.join(tempfile.gettempdir(), "tensor_p3.noguard.lint.s"),
+                     extra_flags=["-DT3_LINT_DROP_RESULTS_GUARD"])
+    bad, stats = L.lint_kernel(L.parse_kernel(asm, "tp3_contract_kernel"), need, asm_only=True)
+    assert len(bad) > 20 and stats["nearest_mem"] < need["mem_read"]
+    assert all("memory / LDS" in what for *_, what in bad)
 
 
 def test_degree2_kernels_compiler_padded_code_passes_the_same_lint(need):
