@@ -665,7 +665,9 @@ struct WgsLane {
   int baseT0, strideT0, baseT1, basecT;
 };
 
-MH_DEV WgsLane wgs_lane_constants() {
+// for_dump: the lanes / registers without an entry get zero offsets and strides (what they index is the dump region of
+// wgs_contract_block, never a staging buffer)
+MH_DEV WgsLane wgs_lane_constants(bool for_dump = false) {
   constexpr int NB = 3, ND = 27, NROW = 81;
   WgsLane c;
   c.lane = threadIdx.x & 63;
@@ -694,6 +696,10 @@ MH_DEV WgsLane wgs_lane_constants() {
   // carried rows: grp 0 row 4 (1,1) -> (1,1); grp 1 row 5 (1,2) -> (2,1); grp 3 row 7 (2,1) -> (1,2); grp 2 row 8 (2,2)
   //   s' = (a' - 9) 162 + (b2' - 1) 27 + b1' 9 + b0' 3 + i,  a' = b0 + 3 b1 + 9 b2,  b2' = a2
   c.basecT = b0 * 162 + a0 * 3 + (grp == 0 ? 0 : grp == 1 ? 9 * 162 : grp == 3 ? ND : 9 * 162 + ND);   // per b1: 486; per a1: 9
+  if (for_dump) {
+    if (!c.col_ok) c.base0 = c.stride0 = c.baseT0 = c.strideT0 = 0;
+    if (!c.col_ok || grp != 2) c.base1 = c.baseT1 = 0;
+  }
   return c;
 }
 
@@ -704,13 +710,21 @@ MH_DEV WgsLane wgs_lane_constants() {
 // MODE 2 (diagonal block, i == j): the block is symmetric itself, K[(a1 ..), (b1 ..)] = K[(b1 ..), (a1 ..)]^T, so
 // only the six chains with a1 >= b1 are contracted and those with a1 > b1 are also stored transposed
 // (st_t == st_n, jt == jn).
-template<int MODE>
+// DUMP (round 4, symmetric-half kernel): the staging stores carry no execution mask -- the lanes that hold no
+// entry (7 of every 16 columns; for the second register every lane group but 2) store to a 512-double dump region instead
+// (their lane constants are zero, wgs_lane_constants(true)).  Thirty mask regions per element and contraction wave
+// (s_and_saveexec / s_cbranch_execz / s_or: ~90 scalar instructions and as many scheduling boundaries) are gone.
+template<int MODE, bool DUMP = false>
 MH_DEV void wgs_contract_block(const WgsLane& lc, const double (&ah)[9], const double (&aS0)[4], const double (&aS2)[4],
                                const double (&uB1)[3][4], const double (&uD1)[3][4], double (&C)[9],
-                               double* st_n, int jn, double* st_t, int jt) {
+                               double* st_n, int jn, double* st_t, int jt, double* dump = nullptr) {
   constexpr int NB = 3, NQ = 4, ND = 27, NROW = 81;
   const mh_d4 zero4 = {0.0, 0.0, 0.0, 0.0};
   const int grp = lc.grp;
+  double* const dn0 = lc.col_ok ? st_n : dump;
+  double* const dn1 = (lc.col_ok && grp == 2) ? st_n : dump;
+  double* const dt0 = lc.col_ok ? st_t : dump;
+  double* const dt1 = (lc.col_ok && grp == 2) ? st_t : dump;
   mh_d4 D1[9];
 #pragma unroll
   for (int mn = 0; mn < 9; ++mn) {
@@ -732,11 +746,20 @@ MH_DEV void wgs_contract_block(const WgsLane& lc, const double (&ah)[9], const d
       // (the nine-block kernel, MODE 0, has no registers for the two lane masks: it keeps the select + add form)
       const double out0 = MODE == 0 ? Kt[a1][0] + (grp != 2 ? cin : 0.0) : __builtin_fma(cin, lc.take_c0, Kt[a1][0]);
       const double out1 = MODE == 0 ? Kt[a1][1] + (grp == 0 ? c_rot : 0.0) : __builtin_fma(c_rot, lc.take_c1, Kt[a1][1]);
-      if (lc.col_ok) st_n[lc.base0 + a1 * lc.stride0 + b1 * 9 + jn] = out0;
-      if (lc.col_ok && grp == 2) st_n[lc.base1 + a1 * (3 * ND) + b1 * 9 + jn] = out1;
-      if (MODE == 1 || (MODE == 2 && a1 > b1)) {
-        if (lc.col_ok) st_t[lc.baseT0 + b1 * lc.strideT0 + a1 * 9 + jt] = out0;
-        if (lc.col_ok && grp == 2) st_t[lc.baseT1 + b1 * (3 * NROW) + a1 * 9 + jt] = out1;
+      if constexpr (DUMP) {
+        dn0[lc.base0 + a1 * lc.stride0 + b1 * 9 + jn] = out0;
+        dn1[lc.base1 + a1 * (3 * ND) + b1 * 9 + jn] = out1;
+        if (MODE == 1 || (MODE == 2 && a1 > b1)) {
+          dt0[lc.baseT0 + b1 * lc.strideT0 + a1 * 9 + jt] = out0;
+          dt1[lc.baseT1 + b1 * (3 * NROW) + a1 * 9 + jt] = out1;
+        }
+      } else {
+        if (lc.col_ok) st_n[lc.base0 + a1 * lc.stride0 + b1 * 9 + jn] = out0;
+        if (lc.col_ok && grp == 2) st_n[lc.base1 + a1 * (3 * ND) + b1 * 9 + jn] = out1;
+        if (MODE == 1 || (MODE == 2 && a1 > b1)) {
+          if (lc.col_ok) st_t[lc.baseT0 + b1 * lc.strideT0 + a1 * 9 + jt] = out0;
+          if (lc.col_ok && grp == 2) st_t[lc.baseT1 + b1 * (3 * NROW) + a1 * 9 + jt] = out1;
+        }
       }
       C[a1b1] = grp == 2 ? o2_rot : out1;
     }

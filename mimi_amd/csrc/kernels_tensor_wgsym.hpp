@@ -49,7 +49,8 @@ struct WgsymLds {
   static constexpr int r_size = 3 * (3 * NQ3 + 3 * NB * NQ * NQ + 3 * NB2 * NQ);
   static constexpr int off_ah = off_r + r_size;             // [6 blocks (i, j <= i)][9 (m,n)][64]  X -> Y
   static constexpr int off_st = off_ah + 6 * 9 * NQ3;       // [3 i][1216] store transposition      Y
-  static constexpr int total = off_st + 3 * WgsLds::st_size;
+  static constexpr int off_dump = off_st + 3 * WgsLds::st_size;   // where lanes without an entry store (wgs_contract_block)
+  static constexpr int total = off_dump + 512;
   // first Ahat entry of block (i, j), j <= i
   MH_DEV static constexpr int ah_block(int i, int j) { return (i * (i + 1) / 2 + j) * 9; }
 };
@@ -265,7 +266,7 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols)
   constexpr int P = 2, NB = 3, NQ = 4, NB2 = 9, ND = 27, NQ3 = 64, NROW = 81, NK = ND * NROW;
   // step O blocks: Y0 (1,0), Y1 (2,0), Y2 (2,1)
   constexpr int I1 = W == 0 ? 1 : 2, J1 = W == 2 ? 1 : 0;
-  const WgsLane lc = wgs_lane_constants();
+  const WgsLane lc = wgs_lane_constants(true);
   const int lane = lc.lane;
   const int sl = p.seg_len, nseg = p.box_n[2] / sl;
   const int n_seq = n_cols * sl;   // sequence index g = unit-in-workgroup * seg_len + position (see wgsym_x_loop)
@@ -330,7 +331,7 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols)
       // no barriers around the diagonal block: it reads operands nobody rewrites before O(it)'s first barrier and
       // writes only slots of this wave's own buffer that no other wave touches (the transposed entries other
       // waves add to it during O steps use the other two column components)
-      wgs_contract_block<WGSYM_DIAG_MODE>(lc, ah, aS0, aS2, uB1, uD1, C0, st_of(W), W, st_of(W), W);
+      wgs_contract_block<WGSYM_DIAG_MODE, true>(lc, ah, aS0, aS2, uB1, uD1, C0, st_of(W), W, st_of(W), W, lds + L::off_dump);
     }
     // ---- O(it), lock step: off-diagonal block, stored as computed and transposed ------------------------------
     {
@@ -338,7 +339,7 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols)
 #pragma unroll
       for (int k = 0; k < 9; ++k) ah[k] = AH1[k * NQ3 + lane];
       wgs_barrier();
-      wgs_contract_block<1>(lc, ah, aS0, aS2, uB1, uD1, C1, st_of(I1), J1, st_of(J1), I1);
+      wgs_contract_block<1, true>(lc, ah, aS0, aS2, uB1, uD1, C1, st_of(I1), J1, st_of(J1), I1, lds + L::off_dump);
       wgs_barrier();
       if (it % sl == sl - 1) {
         // last element of a unit (column, or column segment): the carried rows have no successor -- straight from the registers into the third
