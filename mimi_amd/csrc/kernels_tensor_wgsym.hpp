@@ -273,11 +273,16 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols)
   const double* AH0 = lds + L::off_ah + L::ah_block(W, W) * NQ3;
   const double* AH1 = lds + L::off_ah + L::ah_block(I1, J1) * NQ3;
   auto st_of = [&](int piece) -> double* { return lds + L::off_st + piece * WgsLds::st_size; };
-  auto block_of = [&](int g) -> double* {
-    const int unit = col0 + g / sl, col = unit / nseg;
-    const int64_t e = col % p.box_n[0] + (int64_t)p.box_n[0] * (col / p.box_n[0] + (int64_t)p.box_n[1] * ((unit % nseg) * sl + g % sl));
-    return p.scratch_k + e * (int64_t)P2Block::size;
+  // the element of sequence index g, kept incrementally (round 4: four integer divisions by run-time numbers per element
+  // and wave were ~80 scalar instructions of the loop): first element of a unit by division, then + one layer per step
+  auto unit_first = [&](int u) -> int64_t {
+    const int unit = col0 + u, col = unit / nseg;
+    return col % p.box_n[0] + (int64_t)p.box_n[0] * (col / p.box_n[0] + (int64_t)p.box_n[1] * ((unit % nseg) * sl));
   };
+  const int64_t e_step = (int64_t)p.box_n[0] * p.box_n[1];
+  auto block_at = [&](int64_t e) -> double* { return p.scratch_k + e * (int64_t)P2Block::size; };
+  int pos = 0, unit_i = 0;        // position inside the unit (= it % seg_len), unit inside the workgroup
+  int64_t e_cur = unit_first(0), e_prev = e_cur;
   const int mrow = lane & 15, mk = lane >> 4;
   const bool mrow_ok = mrow < NB2;
   const int mra = mrow_ok ? mrow / NB : 0, mrb = mrow_ok ? mrow % NB : 0;
@@ -293,12 +298,12 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols)
   for (int it = 0; it < n_seq; ++it) {
     // ---- D(it), free running: flush element it - 1, tables of element it, diagonal block ----------------------
     {
-      if (it >= 1) wgs_flush_final(lane, st_of(W), block_of(it - 1), W);
+      if (it >= 1) wgs_flush_final(lane, st_of(W), block_at(e_prev), W);
       const double* tab = lds + L::off_tab + (it & 1) * 6 * NB * NQ;
       // the tables of directions 0 and 1 belong to the element COLUMN: read (24 LDS reads, 48 v_readfirstlane, the pair
       // products of direction 0) at the first element of a unit only -- every vector instruction of a contraction wave
       // is on the kernel's critical path; direction 2 changes with every element
-      if (it % sl == 0) {
+      if (pos == 0) {
         const double Ba = tab_ptr<P>(tab, 0, 0)[mra * NQ + mk], Da = tab_ptr<P>(tab, 0, 1)[mra * NQ + mk];
         const double Bb = tab_ptr<P>(tab, 0, 0)[mrb * NQ + mk], Db = tab_ptr<P>(tab, 0, 1)[mrb * NQ + mk];
         aS0[0] = mrow_ok ? Ba * Bb : 0.0;
@@ -341,19 +346,27 @@ MH_DEV void wgsym_y_loop(const TensorArgs& p, double* lds, int col0, int n_cols)
       wgs_barrier();
       wgs_contract_block<1, true>(lc, ah, aS0, aS2, uB1, uD1, C1, st_of(I1), J1, st_of(J1), I1, lds + L::off_dump);
       wgs_barrier();
-      if (it % sl == sl - 1) {
+      if (pos == sl - 1) {
         // last element of a unit (column, or column segment): the carried rows have no successor -- straight from the registers into the third
         // part of the pieces (no LDS, no lock step) -- and the next column starts with an empty carry
-        double* E = block_of(it);
+        double* E = block_at(e_cur);
         wgs_stage_carry<WGSYM_DIAG_MODE>(lc, C0, P2Block::carry_of(E, W), W, P2Block::carry_of(E, W), W);
         wgs_stage_carry<1>(lc, C1, P2Block::carry_of(E, I1), J1, P2Block::carry_of(E, J1), I1);
 #pragma unroll
         for (int k = 0; k < NB2; ++k) C0[k] = C1[k] = 0.0;
       }
     }
+    e_prev = e_cur;
+    if (++pos == sl) {
+      pos = 0;
+      ++unit_i;
+      if (unit_i < n_cols) e_cur = unit_first(unit_i);
+    } else {
+      e_cur += e_step;
+    }
   }
   // ---- after the last element (no more lock steps): its pieces from the buffers ------------------------------------
-  wgs_flush_final(lane, st_of(W), block_of(n_seq - 1), W);
+  wgs_flush_final(lane, st_of(W), block_at(e_prev), W);
 }
 
 template<int KIND>
