@@ -85,3 +85,14 @@ def test_binding_rooflines_use_the_live_phase_times():
     assert bench.binding_rooflines(2, 1, None, pmc) is None
     none = bench.binding_rooflines(2, 262144, (4.79, 2.77), None)
     assert none["phase1"]["issued_frac"] is None and none["phase2"]["frac"] is None
+
+
+def test_algorithmic_counts_of_survey_8d():
+    """SURVEY 8d's per-element figures the roofline objects are priced with, and the useful-flop count derived from the three
+    contraction stages (bench.useful_flop): 59 012 / 6 524 B at p = 2, 308 240 (+ 11 000 J2 state) / 13 328 B at p = 3;
+    0.513 / 2.84 MFLOP."""
+    import bench
+    assert bench.b_alg(3, 2, grad=True) == 59012 and bench.b_alg(3, 2, grad=False) == 6524
+    assert bench.b_alg(3, 3, grad=True) == 308240 and bench.b_alg(3, 3, grad=False) == 13328
+    assert bench.b_alg(3, 3, grad=True, stateful=True) == 319240
+    assert bench.useful_flop(2) == 513216.0 and bench.useful_flop(3) == 2835360.0

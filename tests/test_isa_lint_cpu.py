@@ -97,3 +97,31 @@ def test_the_lint_stays_green_with_the_wait_states_in_place(need):
         asm = L.assembly(src, out=os.path.join(tmp, "hazard.s"))
     bad, stats = L.lint_kernel(L.parse_kernel(asm, "hazard_kernel"), need, asm_only=True)
     assert not bad and stats["nearest_valu_read"] >= 19
+
+
+_DPP = r"""
+#include <hip/hip_runtime.h>
+extern "C" __global__ void dpp_kernel(const double* a, double* out) {
+  double t = a[threadIdx.x], w = a[threadIdx.x + 64], acc = 0.5;
+  asm volatile("v_add_f64 %0, %0, %0" : "+v"(t));                 // a vector write of the DPP operand ...
+#ifdef FENCE
+  asm volatile("s_nop 1" : "+v"(t));
+#endif
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t), "v"(w));   // ... read here
+  out[threadIdx.x] = acc;
+}
+"""
+
+
+@pytest.mark.parametrize("fence", [False, True])
+def test_dpp_operand_hazard(need, fence):
+    """the rule the residual column kernel's table registers are held to (RC_DPP_FENCE*): a DPP operand read less than two
+    wait states behind the vector instruction that wrote it is flagged, with the `s_nop 1` in between it is not"""
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "dpp.hip")
+        open(src, "w").write(_DPP)
+        asm = L.assembly(src, out=os.path.join(tmp, "dpp.s"), extra_flags=["-DFENCE"] if fence else ["-DNOFENCE"])
+    bad, stats = L.lint_kernel(L.parse_kernel(asm, "dpp_kernel"), need, asm_only=True)
+    assert bool(bad) == (not fence)
+    if not fence:
+        assert any("DPP operand" in what for *_, what in bad)
