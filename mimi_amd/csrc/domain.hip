@@ -312,6 +312,18 @@ static bool ensure_general_two_phase(mimi_hip_domain_s* h, bool with_k) {
   return true;
 }
 
+// calls f(std::integral_constant<int, kind>) for the handle's material among the four that are not closed-form: the general
+// kernels take the kind as a compile-time constant (one instantiation per material: no spilled registers)
+template<class F>
+static void by_other_kind(int kind, F f) {
+  switch (kind) {
+  case MIMI_HIP_MAT_STVK: f(std::integral_constant<int, MIMI_HIP_MAT_STVK>{}); break;
+  case MIMI_HIP_MAT_J2LINEAR: f(std::integral_constant<int, MIMI_HIP_MAT_J2LINEAR>{}); break;
+  case MIMI_HIP_MAT_J2SIMO: f(std::integral_constant<int, MIMI_HIP_MAT_J2SIMO>{}); break;
+  default: f(std::integral_constant<int, MIMI_HIP_MAT_J2LOG>{}); break;
+  }
+}
+
 #ifndef GEN_BIG_PP
 #define GEN_BIG_PP 8
 #define GEN_BIG_THREADS 512
@@ -351,8 +363,14 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a_
       MH_HIP(hipGetLastError());
     };
     const bool other = !material_closed_form(h->mat.m.kind);
-    if (grad == 0) { if (other) gow(domain_general_kernel<DIM, 0, 3, 256, 1, 0, 1>); else gow(domain_general_kernel<DIM, 0, 3, 256, 0, 0, 1>); }
-    else { if (other) gow(domain_general_kernel<DIM, 1, 3, 256, 1, 0, 1>); else gow(domain_general_kernel<DIM, 1, 3, 256, 0, 0, 1>); }
+    if (!other) {
+      if (grad == 0) gow(domain_general_kernel<DIM, 0, 3, 256, 0, 0, 1>); else gow(domain_general_kernel<DIM, 1, 3, 256, 0, 0, 1>);
+    } else {
+      by_other_kind(h->mat.m.kind, [&](auto K) {
+        constexpr int FK = decltype(K)::value;
+        if (grad == 0) gow(domain_general_kernel<DIM, 0, 3, 256, FK, 0, 1>); else gow(domain_general_kernel<DIM, 1, 3, 256, FK, 0, 1>);
+      });
+    }
     gather();
     return;
   }
@@ -366,11 +384,14 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a_
   static const bool no_mfma = getenv("MIMI_HIP_GENERAL_NO_MFMA") && getenv("MIMI_HIP_GENERAL_NO_MFMA")[0] == '1';
   if (!material_closed_form(h->mat.m.kind)) {
     // the other materials: same kernel, stress and tangent from materials_other.hpp
-    if (grad == 0) go(domain_general_kernel<DIM, 0, 3, 256, 1>);
-    else if (grad == 1 && DIM == 3 && h->n_dof == 64 && !no_mfma) go(domain_general_kernel<3, 1, GEN_BIG_PP, GEN_BIG_THREADS, 1, 1>, GEN_BIG_THREADS);
-    else if (grad == 1 && h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, GEN_BIG_PP, GEN_BIG_THREADS, 1>, GEN_BIG_THREADS);
-    else if (grad == 1) go(domain_general_kernel<DIM, 1, 3, 256, 1>);
-    else go(domain_general_kernel<DIM, 2, 3, 256, 1>);
+    by_other_kind(h->mat.m.kind, [&](auto K) {
+      constexpr int FK = decltype(K)::value;
+      if (grad == 0) go(domain_general_kernel<DIM, 0, 3, 256, FK>);
+      else if (grad == 1 && DIM == 3 && h->n_dof == 64 && !no_mfma) go(domain_general_kernel<3, 1, GEN_BIG_PP, GEN_BIG_THREADS, FK, 1>, GEN_BIG_THREADS);
+      else if (grad == 1 && h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, GEN_BIG_PP, GEN_BIG_THREADS, FK>, GEN_BIG_THREADS);
+      else if (grad == 1) go(domain_general_kernel<DIM, 1, 3, 256, FK>);
+      else go(domain_general_kernel<DIM, 2, 3, 256, FK>);
+    });
     gather();
     return;
   }

@@ -102,7 +102,9 @@ MH_DEV void compute_F_general(int n_dof, const double* __restrict__ g /* [DIM][n
 // PP: node pairs per lane and pass of the node-pair phase (3 covers up to 768 pairs = p <= 2 in 3-D; 8 halves the
 // passes of larger elements)
 // THREADS: workgroup size (256; 512 for elements with more than 768 node pairs: one pass of the node-pair phase for p = 3)
-// FAMILY: 0 neo-Hookean / J2 (closed-form tangents, materials.hpp); 1 the other materials (materials_other.hpp)
+// FAMILY: 0 neo-Hookean / J2 (closed-form tangents, materials.hpp); 2..5 that one of the other materials
+//         (materials_other.hpp) as a compile-time constant -- all four behind a switch in one kernel spilled 170 - 640
+//         registers (round 4: one instantiation per material)
 // MF: 1 = node-pair phase on the fp64 matrix instruction (3-D, 64 nodes per element = p 3, 512 threads): per quadrature
 //     point K[(a), (b, i, j)] += sum_J g[J][a] * (sum_L A_q[iJ, jL] g[L][b]) is a 64 x 576 x 3 product; wave w owns the
 //     16 column nodes b of tile w & 3 and two of the four 16-row tiles, 18 accumulator tiles (2 x 9 (i, j)) in registers
@@ -148,9 +150,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
     double F[DD];
     compute_F_general<DIM>(n_dof, gE + (int64_t)q * n_tdof, u_e, F);
     const double wd = wE[q];
-    if constexpr (FAMILY == 1) {
+    if constexpr (FAMILY != 0) {
       double P[DD];
-      status |= evaluate_other<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F, P, GRAD == 1 ? Aw + q * D4 : nullptr, wd);
+      status |= evaluate_other<DIM, (FAMILY >= 2 ? FAMILY : -1)>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F, P, GRAD == 1 ? Aw + q * D4 : nullptr, wd);
 #pragma unroll
       for (int k = 0; k < DD; ++k) Pw[q * DD + k] = wd * P[k];
       continue;
@@ -381,9 +383,9 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
         double F[DD];
         compute_F_general<DIM>(n_dof, gE + (int64_t)q * n_tdof, u_e, F);
         const double wd = wE[q];
-        if constexpr (FAMILY == 1) {
+        if constexpr (FAMILY != 0) {
           double P[DD];
-          status |= evaluate_other<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F, P, nullptr, wd);
+          status |= evaluate_other<DIM, (FAMILY >= 2 ? FAMILY : -1)>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F, P, nullptr, wd);
 #pragma unroll
           for (int k = 0; k < DD; ++k) Pw[q * DD + k] = wd * P[k];
         } else {
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(256) void post_time_advance_general_kernel(GeneralA
   for (int q = tid; q < n_q; q += blockDim.x) {
     double F[DIM * DIM];
     compute_F_general<DIM>(n_dof, p.dN_dX + ((int64_t)e * n_q + q) * n_tdof, u_e, F);
-    if constexpr (FAMILY == 1) status |= accumulate_other<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F);
+    if constexpr (FAMILY != 0) status |= accumulate_other<DIM, (FAMILY >= 2 ? FAMILY : -1)>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F);
     else status |= accumulate_state<DIM>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F);
   }
   if (status) atomicOr(p.status, status);
