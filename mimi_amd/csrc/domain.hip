@@ -416,9 +416,18 @@ static void launch_tensor_small_dp(mimi_hip_domain_s* h, int mode, TensorArgs a)
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), lds, h->stream, a, (int)h->n_el);
     MH_HIP(hipGetLastError());
   };
-  if (mode == 0) { if (other) go(tensor_small_kernel<DIM, P, 1, 0>); else go(tensor_small_kernel<DIM, P, 0, 0>); }
-  else if (mode == 1) { if (other) go(tensor_small_kernel<DIM, P, 1, 1>); else go(tensor_small_kernel<DIM, P, 0, 1>); }
-  else { if (other) go(tensor_small_kernel<DIM, P, 1, 2>); else go(tensor_small_kernel<DIM, P, 0, 2>); }
+  if (!other) {
+    if (mode == 0) go(tensor_small_kernel<DIM, P, 0, 0>);
+    else if (mode == 1) go(tensor_small_kernel<DIM, P, 0, 1>);
+    else go(tensor_small_kernel<DIM, P, 0, 2>);
+  } else {
+    by_other_kind(h->mat.m.kind, [&](auto K) {
+      constexpr int FK = decltype(K)::value;
+      if (mode == 0) go(tensor_small_kernel<DIM, P, FK, 0>);
+      else if (mode == 1) go(tensor_small_kernel<DIM, P, FK, 1>);
+      else go(tensor_small_kernel<DIM, P, FK, 2>);
+    });
+  }
 }
 
 static bool launch_tensor_small(mimi_hip_domain_s* h, int mode, const double* u, double* r, double* A, double gf) {

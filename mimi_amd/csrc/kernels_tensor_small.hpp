@@ -118,12 +118,12 @@ __global__ __launch_bounds__(256) void tensor_small_kernel(TensorArgs p, int n_e
       }
     const int64_t pt = e * NPT + lane;
     if constexpr (MODE == 2) {
-      if constexpr (FAMILY == 1) status |= accumulate_other<DIM>(p.mat, p.dt, p.state, pt, F);
+      if constexpr (FAMILY != 0) status |= accumulate_other<DIM, (FAMILY >= 2 ? FAMILY : -1)>(p.mat, p.dt, p.state, pt, F);
       else status |= accumulate_state<DIM>(p.mat, p.dt, p.state, pt, F);
     } else {
       double Pk[DD], A[MODE == 1 ? D4 : 1];
-      if constexpr (FAMILY == 1) {
-        status |= evaluate_other<DIM>(p.mat, p.dt, p.state, pt, F, Pk, MODE == 1 ? A : nullptr, 1.0);
+      if constexpr (FAMILY != 0) {     // (2..5: that material as a compile-time constant, as in the other kernel families)
+        status |= evaluate_other<DIM, (FAMILY >= 2 ? FAMILY : -1)>(p.mat, p.dt, p.state, pt, F, Pk, MODE == 1 ? A : nullptr, 1.0);
       } else {
         PointResult<DIM> w;
         status |= evaluate_pk1<DIM>(p.mat, p.dt, p.state, pt, F, w);
