@@ -156,3 +156,52 @@ def test_contact_at_cfg4_size_matches_the_oracle():
     assert np.abs(r_g - r_o).max() / np.abs(r_o).max() < 1e-12
     assert np.allclose(G.AveragePressure(), Cn.pressure, rtol=1e-12, atol=1e-12)
     assert np.abs(A_g - A_o).max() / np.abs(A_o).max() < 1e-11
+
+
+def test_from_base_entry_at_cfg2_size():
+    """mimi_hip_domain_add_residual_and_grad_from (ABI 11: the operator's J = M + fac0 K in one pass,
+    operators/nonlinear_solid.cpp:257-258) at BASELINE configuration 2's size, device-resident: complete sampled CSR rows of
+    A_out equal base + gf K (oracle element blocks, 1e-11), every entry of A_out was written (pre-filled with 1e30), the base
+    array is untouched, and the result is the bits of "copy, then +="."""
+    import torch
+    import bench
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    from oracle import iga
+    n_el, p, material = bench.WORKLOADS["cfg2"]
+    dev = torch.device("cuda", 0)
+    patch = mimi_amd.BSplinePatch.block(n_el, p)
+    pattern = CSRPattern.of_bspline_patch(patch, on_device=True)
+    G = NonlinearSolid("domain", bench.make_material(material), pattern, patch=patch).Prepare()
+    G.dt_ = 0.5
+    u_host = bench.synthetic_u(patch)
+    u = torch.from_numpy(u_host).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    base = torch.randn(pattern.nnz, dtype=torch.float64, device=dev, generator=gen) * 100.0
+    base_copy = base.clone()
+    gf = 0.37
+    r = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
+    A = torch.full((pattern.nnz,), 1e30, dtype=torch.float64, device=dev)
+    G.AddDomainResidualAndGradFrom(u, gf, r, base, A)
+    r2 = torch.zeros_like(r)
+    A2 = base.clone()
+    G.AddDomainResidualAndGrad(u, gf, r2, A2)
+    G.Synchronize()
+    assert torch.equal(base, base_copy)
+    assert torch.equal(A, A2) and torch.equal(r, r2)
+    assert float(A.abs().max()) < 1e29
+    P = iga.Patch.block(n_el, p)
+    nodes = sample_nodes(P.n, 8, seed=5)
+    S = SampledRows(P, bench._oracle_material(material), nodes, u_host)
+    rowptr = pattern.rowptr if isinstance(pattern.rowptr, torch.Tensor) else torch.from_numpy(np.asarray(pattern.rowptr))
+    col = pattern.col if isinstance(pattern.col, torch.Tensor) else torch.from_numpy(np.asarray(pattern.col))
+    worst = scale = 0.0
+    for k, node in enumerate(S.node_ids):
+        for i in range(3):
+            row = node * 3 + i
+            lo, hi = int(rowptr[row]), int(rowptr[row + 1])
+            exp, _ = S.row(k, i, col[lo:hi].cpu().numpy())
+            got = (A[lo:hi] - base[lo:hi]).cpu().numpy() / gf
+            scale = max(scale, float(np.abs(exp).max()))
+            worst = max(worst, float(np.abs(got - exp).max()))
+    assert worst / scale < 1e-11
