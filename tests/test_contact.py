@@ -278,6 +278,66 @@ def test_contact_tilted_plane_known_answer_gpu(n_el, p, axis, along):
     _check_tilted_plane(P, axis, point, normal, penalty, G.MarkedNodes(), G.AveragePressure(), G.last_area_, G.last_force_, r, 1e-11)
 
 
+# ---- what the frozen-pressure tangent must satisfy whatever the body: objectivity ---------------------------------------
+# With the nodal pressures frozen (mortar_contact.cpp:281-294: the reference differentiates ElementResidual with p fixed) the
+# residual r_i(u) = int N_i p n |J| dA depends on u only through the surface element n |J| = x_,xi1 x x_,xi2 of the
+# deformed face.  That is invariant under a rigid translation and turns with a rigid rotation, so the tangent A = dr/du of
+# ANY correct implementation satisfies   A t = 0   and   A (omega x x) = omega x r   (x = X + u; in 2-D omega x (a, b) =
+# omega (-b, a)) -- no oracle, no reference data: a property of the formula in mortar_contact.hpp:100-131.
+def _check_objectivity(P, rowptr, col, A, r, u, tol):
+    import scipy.sparse as sp
+    n = P.n_vdofs
+    M = sp.csr_matrix((A, col, rowptr), shape=(n, n))
+    x = (P.ctrl + np.asarray(u).reshape(-1, P.dim))
+    rr = np.asarray(r).reshape(-1, P.dim)
+    scale = np.abs(A).max() * np.abs(x).max()
+    assert np.abs(rr).max() > 0 and np.abs(A).max() > 0
+    for d in range(P.dim):
+        t = np.zeros((P.n_nodes, P.dim))
+        t[:, d] = 1.0
+        assert np.abs(M @ t.ravel()).max() < tol * scale
+    if P.dim == 2:
+        w = np.stack([-x[:, 1], x[:, 0]], axis=1)
+        expect = np.stack([-rr[:, 1], rr[:, 0]], axis=1)
+        assert np.abs(M @ w.ravel() - expect.ravel()).max() < tol * scale
+    else:
+        for omega in np.eye(3):
+            w = np.cross(omega, x)
+            expect = np.cross(omega, rr)
+            assert np.abs(M @ w.ravel() - expect.ravel()).max() < tol * scale
+
+
+@pytest.mark.parametrize("n_el,p,axis", CASES)
+def test_oracle_contact_tangent_is_objective(n_el, p, axis):
+    from oracle import iga, ref_path as rp
+    P = iga.Patch.block(n_el, p)
+    rowptr, col = P.sparsity()
+    Cn = rp.ContactOracle(P, axis, 1, sphere_over_top(P, axis), penalty=1e4, rowptr=rowptr, col=col)
+    u = synthetic_u(P, scale=0.01)
+    r, A = np.zeros(P.n_vdofs), np.zeros(rowptr[-1])
+    Cn.add_boundary_residual_and_grad(u, 1.0, r, A, rp.TANGENT_EXACT)
+    _check_objectivity(P, rowptr, col, A, r, u, 1e-11)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_el,p,axis", CASES)
+def test_contact_tangent_is_objective_gpu(n_el, p, axis):
+    """the same property of the HIP path's analytic frozen-pressure tangent: no oracle in the loop"""
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, MortarContact, RigidSphere
+    from oracle import iga
+    P = iga.Patch.block(n_el, p)                       # (node bookkeeping of the check only)
+    rowptr, col = P.sparsity()
+    body = sphere_over_top(P, axis)
+    patch = mimi_amd.BSplinePatch.block(n_el, p)
+    pattern = CSRPattern(rowptr.astype(np.int64), col.astype(np.int32), rowptr[-1])
+    G = MortarContact(RigidSphere(body["center"], body["radius"], 1e4), "contact", pattern, patch, axis, 1).Prepare()
+    u = synthetic_u(P, scale=0.01)
+    r, A = np.zeros(P.n_vdofs), np.zeros(rowptr[-1])
+    G.AddBoundaryResidualAndGrad(u, 1.0, r, A)
+    _check_objectivity(P, rowptr, col, A, r, u, 1e-11)
+
+
 # ---- rigid SPLINE bodies (NearestDistanceToSplines, coefficients/nearest_distance.hpp:215-288) ---------------------
 def nurbs_circle(center, R):
     """the standard 9-point quadratic NURBS circle, counter-clockwise (outward normal (t_y, -t_x))"""
