@@ -74,6 +74,27 @@ def test_rigid_translation_in_null_space(setup):
         assert float(y.abs().max()) < 1e-10 * Aabs * 375
 
 
+def test_rigid_rotation_equivariance(setup):
+    """Frame indifference of the hyperelastic law, P(Q F) = Q P(F) (materials.cpp:96-118: the neo-Hookean stress is a function
+    of F F^T invariants times F and F^-T): the internal force turns with a rigid rotation of the current configuration, so the
+    assembled tangent maps an infinitesimal rotation of x = X + u to the rotated residual, K (omega x x) = omega x r -- at the
+    full north-star size, for the three axes, with neither oracle nor reference data."""
+    torch = setup["torch"]
+    patch = setup["patch"]
+    X = torch.from_numpy(np.ascontiguousarray(patch.control_points, dtype=np.float64).reshape(-1, 3)).to(setup["dev"])
+    x = X + setup["u"].view(-1, 3)
+    r = setup["r"].view(-1, 3)
+    scale = float(setup["A"].abs().max()) * float(x.abs().max()) * 375
+    for k in range(3):
+        omega = torch.zeros(3, dtype=torch.float64, device=setup["dev"])
+        omega[k] = 1.0
+        w = torch.cross(omega.expand_as(x), x, dim=1).reshape(-1).contiguous()
+        y = csr_matvec(setup, setup["A"], w)
+        expect = torch.cross(omega.expand_as(r), r, dim=1).reshape(-1)
+        assert float((y - expect).abs().max()) < 1e-10 * scale
+        assert float(y.abs().max()) > 1e-3 * float(r.abs().max())        # (not vacuous: the rotated residual is not small)
+
+
 def test_tangent_major_symmetry(setup):
     torch = setup["torch"]
     g = torch.Generator(device="cpu").manual_seed(5)
