@@ -94,3 +94,35 @@ def test_p3_element_slabs_add_up():
     hi.AddDomainResidualAndGrad(u, 1.0, r_s, A_s)
     assert relmax(r_s, r_w) < 1e-13
     assert relmax(A_s, A_w) < 1e-13
+
+
+@pytest.mark.parametrize("matname", ["neohook", "stvk"])
+def test_p3_frame_indifference(matname):
+    """Objectivity of the hyperelastic laws, P(Q F) = Q P(F), through the degree-3 kernels with no oracle in the loop: the
+    assembled tangent maps an infinitesimal rigid rotation of x = X + u to the rotated residual, K (omega x x) = omega x r,
+    and a rigid translation to zero (16 x 12 x 9 elements: interior nodes with the full 4 x 4 x 4 neighbourhood, several
+    columns per direction, the z-carry over nine elements)."""
+    import scipy.sparse as sp
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    n_el = (16, 12, 9)
+    patch = mimi_amd.BSplinePatch.block(n_el, 3)
+    pattern = CSRPattern.of_bspline_patch(patch)
+    G = NonlinearSolid("domain", product_material(matname), pattern, patch=patch).Prepare()
+    assert G.path_ == 1
+    u = 0.05 * np.random.default_rng(20241008).standard_normal(patch.n_vdofs)
+    r, A = np.zeros(patch.n_vdofs), np.zeros(pattern.nnz)
+    G.AddDomainResidualAndGrad(u, 1.0, r, A)
+    M = sp.csr_matrix((A, np.asarray(pattern.col), np.asarray(pattern.rowptr)), shape=(patch.n_vdofs, patch.n_vdofs))
+    x = patch.control_points + u.reshape(-1, 3)
+    rr = r.reshape(-1, 3)
+    scale = np.abs(A).max() * np.abs(x).max() * 100
+    assert np.abs(rr).max() > 0
+    for k in range(3):
+        t = np.zeros((patch.n_nodes, 3))
+        t[:, k] = 1.0
+        assert np.abs(M @ t.ravel()).max() < 1e-11 * scale
+        omega = np.eye(3)[k]
+        y = M @ np.cross(omega, x).ravel()
+        assert np.abs(y - np.cross(omega, rr).ravel()).max() < 1e-11 * scale
+        assert np.abs(y).max() > 1e-3 * np.abs(rr).max()
