@@ -95,6 +95,31 @@ def test_rigid_rotation_equivariance(setup):
         assert float(y.abs().max()) > 1e-3 * float(r.abs().max())        # (not vacuous: the rotated residual is not small)
 
 
+def test_tangent_is_the_derivative_of_the_residual(setup):
+    """K(u) w against a central difference of the RESIDUAL-ONLY assembly (other kernels: one wave per element column,
+    nonlinear_solid.cpp:151-160) along a random direction w, at the full north-star size: (r(u + h w) - r(u - h w)) / 2h with a
+    Richardson step (h and h / 2 combined: truncation h^4).  Ties the analytic tangent of the residual+Jacobian kernels to the
+    residual of the residual-only kernels without oracle or reference data."""
+    torch = setup["torch"]
+    G, u = setup["G"], setup["u"]
+    g = torch.Generator(device="cpu").manual_seed(11)
+    w = torch.randn(u.numel(), dtype=torch.float64, generator=g).to(setup["dev"])
+    Kw = csr_matvec(setup, setup["A"], w)
+
+    def central(h):
+        rp_ = torch.zeros_like(u)
+        rm_ = torch.zeros_like(u)
+        G.AddDomainResidual(u + h * w, rp_)
+        G.AddDomainResidual(u - h * w, rm_)
+        G.Synchronize()
+        return (rp_ - rm_) / (2.0 * h)
+
+    h = 1e-3
+    d = (4.0 * central(0.5 * h) - central(h)) / 3.0
+    err = float((d - Kw).abs().max()) / float(Kw.abs().max())
+    assert err < 1e-8, err
+
+
 def test_tangent_major_symmetry(setup):
     torch = setup["torch"]
     g = torch.Generator(device="cpu").manual_seed(5)
