@@ -161,8 +161,8 @@ int mimi_hip_domain_add_residual_and_grad(mimi_hip_domain_t h, const double* u, 
                                           double* r, double* A_values);
 /* The same assembly with the old values of the matrix taken from a second array:
  *   r += R(u); A_out = A_base + grad_factor * K(u)
- * on every CSR row of a node the handle's elements touch (all rows for a whole-patch handle; other rows of A_out are
- * left as they are).  This is operators::NonlinearSolid::ResidualAndGrad's "jacobian_ values <- mass values, then
+ * for WHOLE-PATCH handles only (refused on an element box / slab handle: "=" does not compose over boxes the way "+="
+ * does -- a slab assembles with mimi_hip_domain_add_residual_and_grad into its copy of the base).  This is operators::NonlinearSolid::ResidualAndGrad's "jacobian_ values <- mass values, then
  * AddMultGrad" (operators/nonlinear_solid.cpp:257-258) without the copy pass: with both arrays on the device the row
  * gathers read A_base where "+=" would read A_out -- no extra traffic.  A_base == A_out is the plain "+=".  Routes
  * without a row gather (colour kernel, atomics fallback) and host-resident arrays copy A_base into A_out first. */

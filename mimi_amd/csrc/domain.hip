@@ -912,6 +912,15 @@ int mimi_hip_domain_add_residual_and_grad_from(mimi_hip_domain_t h, const double
   return guarded([&] {
     if (!h) fail("null handle");
     if (!A_base) fail("null vector argument");
+    // "A_out = A_base + gf K" does not compose over element boxes the way "+=" does (a second box would overwrite the rows it
+    // shares with the first, or -- on the routes that copy the base first -- the whole array): whole-patch handles only
+    // (tables-created handles, el_total 1, are whole by construction)
+    if (A_base != A_out)
+      for (int d = 0; d < h->dim; ++d)
+        if (h->el_begin[d] != 0 || h->el_end[d] != h->el_total[d])
+          fail("mimi_hip_domain_add_residual_and_grad_from needs a whole-patch handle (this one holds elements [%d,%d) of %d in "
+               "direction %d): assemble element boxes with mimi_hip_domain_add_residual_and_grad into a copy of the base",
+               h->el_begin[d], h->el_end[d], h->el_total[d], d);
     try {
       run_domain(h, u, r, A_out, grad_factor, true, A_base);
     } catch (...) {

@@ -246,7 +246,11 @@ MH_DEV double rc_mul(double table, double w) {               // table[lane N of 
   return c * w;
 }
 // A DPP operand must not be read within two wait states of the vector instruction that wrote it, and nothing pads inline
-// asm: the table registers pass through this statement after they are written (tests/test_isa_lint_cpu.py checks it)
+// asm: the table registers pass through this statement after they are written.  tests/test_isa_lint_cpu.py lints THIS kernel
+// (tensor_residual_col_kernel: its 188 asm DPP instructions, no finding, no spill).  Round 5: with this compiler the fences
+// are a second line -- compiled away (or replaced by a vector write of the register) the nearest write -> DPP read of the
+// kernel is still more than 8 wait states, so the lint's negative test on this kernel mutates the compiled instruction
+// stream instead (a vector write of the table register placed directly in front of a DPP read of it must be flagged).
 #define RC_DPP_FENCE1(a) asm volatile("s_nop 1" : "+v"(a))
 #define RC_DPP_FENCE3(a, b, c) asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c))
 #define RC_DPP_FENCE4(a, b, c, d) asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))

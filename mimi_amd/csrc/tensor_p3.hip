@@ -329,7 +329,7 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
 #pragma unroll
           for (int m = 0; m < 3; ++m)
 #pragma unroll
-            for (int n = 0; n < 3; ++n) rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS] = wd * acc[(i * 3 + m) * 3 + n];
+            for (int n = 0; n < 3; ++n) T3_REC_STORE(&rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS], wd * acc[(i * 3 + m) * 3 + n]);
       }
     } else if constexpr (FAMILY != 0) {
       status = evaluate_other<3, FK>(p.mat, p.dt, p.state, e * NPT + tid, F, Pk, nullptr, 1.0);
@@ -1033,7 +1033,6 @@ static auto t3_point_kernel_of(int kind) -> void (*)(TensorArgs) {
 
 void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {
   const int kind = h->mat.m.kind;
-  const bool closed = kind == MIMI_HIP_MAT_NEOHOOKEAN || kind == MIMI_HIP_MAT_J2;
   h->scratch_r.resize((size_t)h->n_el * 3 * T3_ND);
   a.scratch_r = h->scratch_r.ptr;
   const int64_t n_cols = (int64_t)a.box_n[0] * a.box_n[1];
@@ -1070,7 +1069,6 @@ void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {
 
 void launch_tensor_p3_post(mimi_hip_domain_s* h, TensorArgs a) {
   const int kind = h->mat.m.kind;
-  const bool closed = kind == MIMI_HIP_MAT_NEOHOOKEAN || kind == MIMI_HIP_MAT_J2;
   hipLaunchKernelGGL(t3_point_kernel_of<2>(kind), dim3((unsigned)h->n_el), dim3(128), 0, h->stream, a);
   MH_HIP(hipGetLastError());
 }

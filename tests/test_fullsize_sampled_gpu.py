@@ -33,6 +33,12 @@ def test_sampled_rows_match_the_oracle(workload, n_random):
     A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
     G.AddDomainResidualAndGrad(u, 1.0, r, A)
     G.Synchronize()
+    # the residual-only assembly is a different set of kernels (tensor_residual_col_kernel at degree 2, tp3_point_kernel<0, 0>
+    # at degree 3: integrators/nonlinear_solid.cpp:151-160, two of the three assemblies of a Newton iteration): its entries at
+    # the sampled nodes are compared with the same oracle values
+    r_only = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
+    G.AddDomainResidual(u, r_only)
+    G.Synchronize()
 
     P = iga.Patch.block(n_el, p)
     nodes = sample_nodes(P.n, n_random, seed=5)
@@ -40,7 +46,7 @@ def test_sampled_rows_match_the_oracle(workload, n_random):
     rowptr = pattern.rowptr if isinstance(pattern.rowptr, torch.Tensor) else torch.from_numpy(np.asarray(pattern.rowptr))
     col = pattern.col if isinstance(pattern.col, torch.Tensor) else torch.from_numpy(np.asarray(pattern.col))
     scale_r = float(r.abs().max())
-    worst_r = worst_A = scale_A = 0.0
+    worst_r = worst_r_only = worst_A = scale_A = 0.0
     beyond_int32 = rows_checked = 0
     for k, node in enumerate(S.node_ids):
         for i in range(3):
@@ -52,8 +58,10 @@ def test_sampled_rows_match_the_oracle(workload, n_random):
             scale_A = max(scale_A, float(np.abs(exp).max()))
             worst_A = max(worst_A, float(np.abs(got - exp).max()))
             worst_r = max(worst_r, abs(float(r[row]) - r_exp))
+            worst_r_only = max(worst_r_only, abs(float(r_only[row]) - r_exp))
             rows_checked += 1
     assert rows_checked >= 3 * 30
+    assert worst_r_only / scale_r < 1e-12
     if pattern.nnz > 2 ** 31:
         assert beyond_int32 >= 12       # rows whose values start beyond what an int32 offset reaches
     assert worst_r / scale_r < 1e-12
