@@ -1,0 +1,604 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled column loop of tp3_contract_asm_kernel (csrc/tensor_p3.hip) -> tp3_contract_loop.inc.
+
+What the loop computes is documented at tp3_contract_kernel (the C++ form of the same arithmetic: S1 / S2 / S3, the carry
+along the column); this file only decides WHERE every instruction goes.  The facts it is built on (scratch/issue_bench.hip,
+DESIGN 4.2): on gfx950, with the one 512-register wave per SIMD this kernel runs at, no vector instruction overlaps a
+`v_mfma_f64_16x16x4` (64 cycles) -- but LDS, global-memory and scalar instructions placed directly behind a matrix
+instruction issue in its shadow for free, and cost ~4 issue cycles each anywhere else.  The compiler's schedule of the C++
+form leaves ~540 such instructions, 54 register-file moves and ~140 address computations per block in the vector stretches
+and ends every element with `s_waitcnt vmcnt(0)` right behind its last stores.  Here:
+
+  * every LDS / memory / scalar instruction of the loop sits behind a matrix instruction (1 - 3 per shadow);
+  * the four accumulator tiles are double-buffered (tile set = b1 & 1): the stores and the carry writes of pair column b1
+    go out in the shadows of pair column b1 + 1, the carry reads of b1 + 1 in the shadows of b1's plane instructions;
+  * addresses are scalar bases + one per-lane offset register + immediates: no vector address arithmetic in the loop;
+  * ONE `s_waitcnt vmcnt(0)` per element, placed where the youngest memory instruction is ~2 000 cycles old (loads and
+    stores return out of order with respect to each other, so a counted wait would not be safe);
+  * per value, the floating-point operations and their order are those of tp3_contract_kernel: the sums are bitwise equal
+    (tests/test_tensor_p3_gpu.py compares the two kernels).
+
+Register map (fixed; the asm statement clobbers exactly these, the compiler keeps v0..v[V0-1], the low SGPRs):
+  VGPR  D (S1 results) 144 | E (S2 accumulators; bS2 operands during S1) 32 | W, cb, ca 24 | TA..TD 8 | t2 16 | 19 ints
+  AGPR  aop 54 | two tile sets 64 | bS0, bS0x 12 | two sets of final entries 16
+The parameter block arrives in LDS (the carry area, which the loop zeroes afterwards): slot k = 512 bytes, lane-indexed.
+
+usage: python gen_tp3_contract.py [out.inc]     (tests/test_isa_lint_cpu.py checks that the committed file is current)
+"""
+import os
+import sys
+
+NB, NQ = 4, 5
+
+# ---------------------------------------------------------------- register map
+V0 = 11                      # first VGPR of the asm block
+VD = 12                      # D: DU[mn] = VD + 8 mn, DV[mn] = VD + 72 + 8 mn (8-aligned + 4: fine, tuples need even starts)
+VE = VD + 144                # E[g][a1] = VE + 2 (4 g + a1); during S1: bS2[4], bS2U[4], bS2V[4]
+VW = VE + 32                 # W3, W1, W2a, W2b, W0a, W0b
+VCB = VW + 12                # cb[2] (double-buffered over the slots)
+VCA = VCB + 4                # ca[4]
+VT = VCA + 8                 # TA, TB, TC, TD
+VT2 = VT + 8                 # t2[s][k]: VT2 + 2 (4 s + k)
+VI = VT2 + 16                # 32-bit per-lane values
+(I_OFFU, I_OFFX, I_OFFV, I_OA, I_OB, I_OAX, I_OBX, I_CIN0, I_CIN1, I_CIN2, I_CIN3, I_FIN, I_OUT0, I_OUT1, I_MU, I_MV,
+ I_TMP0, I_TMP1, I_CL) = range(VI, VI + 19)
+assert I_TMP0 % 2 == 0           # (a 64-bit operand needs an even register)
+I_ZERO0, I_ZERO1 = I_TMP0, I_TMP1      # (prologue only, after the scalar parameters are read)
+VEND = VI + 19
+assert VEND <= 256, VEND
+
+AA = 0                       # aop[mn][t] = AA + 2 (3 mn + t)
+AT = 56                      # tile set s, tile a1: AT + 32 s + 8 a1
+AB0 = 120                    # bS0[g] = AB0 + 2 g, bS0x[h] = AB0 + 8 + 2 h
+AF = 132                     # fin set s: AF + 8 s + 2 a1
+AEND = 148
+
+S0 = 36                      # first SGPR of the asm block
+(S_REC0, S_REC1, S_REC2, S_RSTRIDE, S_CURA, S_CURB, S_CUR1, S_PRVA, S_PRVB, S_PRV1, S_PSTRIDE, S_B2, S_D2, S_TMP, S_EFF) = \
+    [S0 + 2 * k for k in range(15)]
+S_ES, S_NSEQ, S_TSTRIDE = S0 + 30, S0 + 31, S0 + 32
+SEND = S0 + 34
+
+# parameter slots in LDS (slot k: bytes [512 k, 512 k + 512), 8 bytes per lane)
+P_TA, P_BS0, P_BS0X = 0, 4, 8
+P_INT = 10                   # 16 ints in the order of I_OFFU .. I_MV
+P_REC, P_RSTRIDE, P_PIECE, P_PSTRIDE, P_B2, P_D2, P_NSEQ = 26, 27, 28, 29, 30, 31, 32
+N_PARAM = 33
+
+REC_FIELD = 1024             # bytes per record field (128 points)
+PIECE_OUT1 = 3072 * 8        # byte offset of the rows a2 >= 1 inside a piece
+
+
+def v2(r):
+    return f"v[{r}:{r + 1}]"
+
+
+def a2(r):
+    return f"a[{r}:{r + 1}]"
+
+
+def s2r(r):
+    return f"s[{r}:{r + 1}]"
+
+
+def DU(mn, r=None):
+    base = VD + 8 * mn
+    return base if r is None else base + 2 * r
+
+
+def DV(mn, r=None):
+    base = VD + 72 + 8 * mn
+    return base if r is None else base + 2 * r
+
+
+def E(g, a1):
+    return VE + 2 * (4 * g + a1)
+
+
+W3, W1, W2a, W2b, W0a, W0b = [VW + 2 * k for k in range(6)]
+T_REG = [VT, VT + 2, VT + 4, VT + 6]
+BS2 = [VE + 2 * v for v in range(4)]
+BS2U = [VE + 8 + 2 * v for v in range(4)]
+BS2V = [VE + 16 + 2 * v for v in range(4)]
+
+
+def T2(s, k):
+    return VT2 + 2 * (4 * s + k)
+
+
+def AOP(mn, t):
+    return AA + 2 * (3 * mn + t)
+
+
+def TILE(s, a1, r=None):
+    base = AT + 32 * s + 8 * a1
+    return base if r is None else base + 2 * r
+
+
+def FIN(s, a1):
+    return AF + 8 * s + 2 * a1
+
+
+class Out:
+    def __init__(self):
+        self.lines = []
+        self.counts = {}
+
+    def emit(self, text, kind=None):
+        self.lines.append(text)
+        op = text.split()[0]
+        k = kind or ("mfma" if op.startswith("v_mfma") else "valu" if op.startswith("v_") else
+                     "lds" if op.startswith("ds_") else "vmem" if op.startswith("global_") else "salu")
+        self.counts[k] = self.counts.get(k, 0) + 1
+
+    def comment(self, text):
+        self.lines.append("; " + text)
+
+
+def mfma(d, a, b, c, d_agpr=False):
+    dd = f"a[{d}:{d + 7}]" if d_agpr else f"v[{d}:{d + 7}]"
+    cc = "0" if c is None else (f"a[{c}:{c + 7}]" if d_agpr else f"v[{c}:{c + 7}]")
+    return f"v_mfma_f64_16x16x4_f64 {dd}, {a}, {b}, {cc}"
+
+
+def fmac_bc(acc, table, w, n):
+    return f"v_fmac_f64_dpp {v2(acc)}, {v2(table)}, {v2(w)} row_newbcast:{n} row_mask:0xf bank_mask:0xf"
+
+
+def mov_bc(dst, table, n):
+    return f"v_mov_b64_dpp {v2(dst)}, {v2(table)} row_newbcast:{n} row_mask:0xf bank_mask:0xf"
+
+
+def mul(dst, x, y):
+    return f"v_mul_f64 {v2(dst)}, {v2(x)}, {v2(y)}"
+
+
+def with_shadows(o, mfmas, shadow, per_shadow):
+    """the matrix instructions with the shadow instructions dealt out behind them, `per_shadow` at a time; a shadow
+    instruction may be a list (kept together).  Everything left goes behind the last one."""
+    shadow = list(shadow)
+    for k, m in enumerate(mfmas):
+        o.emit(m)
+        quota = per_shadow if k + 1 < len(mfmas) else len(shadow)
+        n = 0
+        while shadow and n < quota:
+            item = shadow.pop(0)
+            for x in (item if isinstance(item, list) else [item]):
+                o.emit(x)
+            n += 1
+    assert not shadow
+
+
+# ---------------------------------------------------------------- pieces of the schedule
+def s2_pass(o, b1, plane):
+    """S2 of pair column b1: the points q0 < 4 (five slots) or the plane q0 = 4 (three slots).  Per value the operations
+    of tp3_contract_kernel's s2 lambda; ordered so that no instruction reads a register written by one of the two
+    instructions before it (fp64 results take 8.5 cycles, an instruction issues every 4.9)."""
+    n_slot = 3 if plane else NQ
+    cb = [VCB, VCB + 2]
+    ca = [VCA + 2 * k for k in range(4)]
+
+    def slot_tab(s):
+        slot = NQ + s if plane else s
+        T = T_REG[0] if slot < 2 else T_REG[1] if slot < 4 else T_REG[2] if slot < 6 else T_REG[3]
+        cB = (slot & 1) * 8
+        return T, cB, cB + 4
+
+    def X(s, mn):
+        if plane:
+            return DV(mn, s + 1)
+        return DU(mn, s) if s < 4 else DV(mn, 0)
+
+    T, cB, cD = slot_tab(0)
+    o.emit(mov_bc(cb[0], T, cB + b1))
+    for a1 in range(NB):
+        if a1 != b1:
+            o.emit(mov_bc(ca[a1], T, cB + a1))
+    for s in range(n_slot):
+        T, cB, cD = slot_tab(s)
+        c = cb[s & 1]
+        o.emit(mul(W3, c, X(s, 0)))
+        o.emit(mul(W1, c, X(s, 2)))
+        o.emit(mul(W0a, c, X(s, 5)))
+        o.emit(mul(W0b, c, X(s, 8)))
+        o.emit(mul(W2a, c, X(s, 3)))
+        o.emit(mul(W2b, c, X(s, 6)))
+        o.emit(fmac_bc(W1, T, X(s, 1), cD + b1))
+        o.emit(fmac_bc(W0a, T, X(s, 4), cD + b1))
+        o.emit(fmac_bc(W0b, T, X(s, 7), cD + b1))
+        if s + 1 < n_slot:
+            Tn, cBn, _ = slot_tab(s + 1)
+            o.emit(mov_bc(cb[(s + 1) & 1], Tn, cBn + b1))
+        if s == 0:
+            cax = lambda a1: c if a1 == b1 else ca[a1]
+            for a1 in range(NB):
+                o.emit(mul(E(3, a1), cax(a1), W3))
+            for a1 in range(NB):
+                o.emit(mul(E(2, a1), cax(a1), W2b))
+            for a1 in range(NB):
+                o.emit(mul(E(1, a1), cax(a1), W1))
+            for a1 in range(NB):
+                o.emit(mul(E(0, a1), cax(a1), W0b))
+        else:
+            for a1 in range(NB):
+                o.emit(fmac_bc(E(3, a1), T, W3, cB + a1))
+            for a1 in range(NB):
+                o.emit(fmac_bc(E(2, a1), T, W2b, cB + a1))
+            for a1 in range(NB):
+                o.emit(fmac_bc(E(1, a1), T, W1, cB + a1))
+            for a1 in range(NB):
+                o.emit(fmac_bc(E(0, a1), T, W0b, cB + a1))
+        for a1 in range(NB):
+            o.emit(fmac_bc(E(2, a1), T, W2a, cD + a1))
+        for a1 in range(NB):
+            o.emit(fmac_bc(E(0, a1), T, W0a, cD + a1))
+
+
+def carry_in(b1, tset):
+    out = []
+    for a1 in range(NB):
+        for s in range(4):
+            out.append(f"ds_read_b64 {a2(TILE(tset, a1, s))}, v{I_CIN0 + s} offset:{(a1 * 16 + b1 * 4 + s) * 512}")
+    return out
+
+
+def carry_out(b1, tset):
+    out = []
+    for r in range(1, 4):
+        for a1 in range(NB):
+            out.append(f"ds_write_b64 v{I_CL}, {a2(TILE(tset, a1, r))} offset:{(a1 * 16 + b1 * 4 + r - 1) * 512}")
+    return out
+
+
+def finals_in(b1, fset):
+    return [f"ds_read_b64 {a2(FIN(fset, a1))}, v{I_FIN} offset:{(a1 * 16 + b1 * 4) * 512}" for a1 in range(NB)]
+
+
+def finals_store(b1, fset):
+    # out1_prev[a1 4 48 + b1 4]; the base register is piece + 2304 bytes so that the immediates fit 13 signed bits
+    return [f"global_store_dwordx2 v{I_OUT1}, {a2(FIN(fset, a1))}, {s2r(S_PRV1)} offset:{a1 * 1536 + b1 * 32 - 2304}"
+            for a1 in range(NB)]
+
+
+def out_store(b1, tset, prev):
+    # out0[a1 4 192 + b1 16] = register 0 of tile a1; bases A (a1 = 0, 1) and B (a1 = 2, 3) sit 3072 bytes inside their range
+    out = []
+    for a1 in range(NB):
+        base = (S_PRVA if prev else S_CURA) if a1 < 2 else (S_PRVB if prev else S_CURB)
+        out.append(f"global_store_dwordx2 v{I_OUT0}, {a2(TILE(tset, a1, 0))}, {s2r(base)} offset:{(a1 & 1) * 6144 - 3072 + b1 * 128}")
+    return out
+
+
+def operand_loads():
+    """the 27 record values and the 8 table values of the next element (bases already point at it)"""
+    out = []
+    for mn in range(9):
+        m, n = divmod(mn, 3)
+        base = (S_REC0, S_REC1, S_REC2)[m]
+        out.append(f"global_load_dwordx2 {a2(AOP(mn, 0))}, v{I_OFFU}, {s2r(base)} offset:{n * REC_FIELD}")
+        out.append(f"global_load_dwordx2 {a2(AOP(mn, 1))}, v{I_OFFX}, {s2r(base)} offset:{n * REC_FIELD}")
+        out.append(f"global_load_dwordx2 {a2(AOP(mn, 2))}, v{I_OFFV}, {s2r(base)} offset:{n * REC_FIELD}")
+    return out
+
+
+def table_loads():
+    out = []
+    for s, (oa, ob) in enumerate(((I_OA, I_OB), (I_OAX, I_OBX))):
+        out.append(f"global_load_dwordx2 {v2(T2(s, 0))}, v{oa}, {s2r(S_B2)}")
+        out.append(f"global_load_dwordx2 {v2(T2(s, 1))}, v{oa}, {s2r(S_D2)}")
+        out.append(f"global_load_dwordx2 {v2(T2(s, 2))}, v{ob}, {s2r(S_B2)}")
+        out.append(f"global_load_dwordx2 {v2(T2(s, 3))}, v{ob}, {s2r(S_D2)}")
+    return out
+
+
+def advance_operand_bases():
+    """rec / table bases -> the element after the one just requested, clamped at the last one (it is requested once
+    more by the last iteration: no branch, nothing out of range).  es still counts the element being contracted."""
+    return [
+        [f"s_add_u32 s{S_TMP}, s{S_ES}, 2", f"s_cmp_lt_u32 s{S_TMP}, s{S_NSEQ}",
+         f"s_cselect_b32 s{S_EFF}, s{S_RSTRIDE}, 0", f"s_cselect_b32 s{S_EFF + 1}, s{S_RSTRIDE + 1}, 0",
+         f"s_cselect_b32 s{S_TMP}, s{S_TSTRIDE}, 0"],
+        [f"s_add_u32 s{S_REC0}, s{S_REC0}, s{S_EFF}", f"s_addc_u32 s{S_REC0 + 1}, s{S_REC0 + 1}, s{S_EFF + 1}"],
+        [f"s_add_u32 s{S_REC1}, s{S_REC1}, s{S_EFF}", f"s_addc_u32 s{S_REC1 + 1}, s{S_REC1 + 1}, s{S_EFF + 1}"],
+        [f"s_add_u32 s{S_REC2}, s{S_REC2}, s{S_EFF}", f"s_addc_u32 s{S_REC2 + 1}, s{S_REC2 + 1}, s{S_EFF + 1}"],
+        [f"s_add_u32 s{S_B2}, s{S_B2}, s{S_TMP}", f"s_addc_u32 s{S_B2 + 1}, s{S_B2 + 1}, 0"],
+        [f"s_add_u32 s{S_D2}, s{S_D2}, s{S_TMP}", f"s_addc_u32 s{S_D2 + 1}, s{S_D2 + 1}, 0"],
+    ]
+
+
+def rotate_piece_bases():
+    out = []
+    for prv, cur in ((S_PRVA, S_CURA), (S_PRVB, S_CURB), (S_PRV1, S_CUR1)):
+        out.append([f"s_mov_b64 {s2r(prv)}, {s2r(cur)}",
+                    f"s_add_u32 s{cur}, s{cur}, s{S_PSTRIDE}", f"s_addc_u32 s{cur + 1}, s{cur + 1}, s{S_PSTRIDE + 1}"])
+    return out
+
+
+def s1_mfmas():
+    out = []
+    v2_of = lambda mn: (1 if mn // 3 == 2 else 0) + (2 if mn % 3 == 2 else 0)
+    for mn in range(9):
+        out.append(mfma(DU(mn), a2(AOP(mn, 0)), v2(BS2[v2_of(mn)]), None))
+    for mn in range(9):
+        out.append(mfma(DU(mn), a2(AOP(mn, 1)), v2(BS2U[v2_of(mn)]), DU(mn)))
+    for mn in range(9):
+        out.append(mfma(DV(mn), a2(AOP(mn, 2)), v2(BS2[v2_of(mn)]), None))
+    for mn in range(9):
+        out.append(mfma(DV(mn), a2(AOP(mn, 1)), v2(BS2V[v2_of(mn)]), DV(mn)))
+    return out
+
+
+def s3_main(tset):
+    out = []
+    for a1 in range(NB):
+        for g in range(4):
+            out.append(mfma(TILE(tset, a1), v2(E(g, a1)), a2(AB0 + 2 * g), TILE(tset, a1), d_agpr=True))
+    return out
+
+
+def s3_plane(tset):
+    out = []
+    for a1 in range(NB):
+        out.append(mfma(TILE(tset, a1), v2(E(0, a1)), a2(AB0 + 8), TILE(tset, a1), d_agpr=True))
+        out.append(mfma(TILE(tset, a1), v2(E(2, a1)), a2(AB0 + 10), TILE(tset, a1), d_agpr=True))
+    return out
+
+
+def plane_swaps(o):
+    """Ey[0][a1] = lanes 0..31 of Ex[0][a1] | lanes 0..31 of Ex[1][a1] (in place in E[0][a1]), Ey[1][a1] likewise from
+    Ex[2], Ex[3] (in E[2][a1]).  The pairs (2, 3) first: E[0][*] were written by the last instructions of S2."""
+    for g in (2, 0):
+        for a1 in range(NB):
+            o.emit(f"v_permlane32_swap_b32 v{E(g, a1)}, v{E(g + 1, a1)}")
+            o.emit(f"v_permlane32_swap_b32 v{E(g, a1) + 1}, v{E(g + 1, a1) + 1}")
+
+
+def bs2_operands(o):
+    """B operands of S1 from the raw direction-2 tables: bS2[v] (first k-step), and the second k-step's product masked to
+    lane group 0 (tile U) / 1 (tile V) -- `kk == 0 ? x : 0.0` as a bitwise AND with an all-ones / zero lane mask."""
+    for v in range(4):
+        o.emit(mul(BS2[v], T2(0, 1 if v & 1 else 0), T2(0, 3 if v & 2 else 2)))
+    for v in range(4):
+        o.emit(mul(BS2U[v], T2(1, 1 if v & 1 else 0), T2(1, 3 if v & 2 else 2)))
+    for v in range(4):
+        o.emit(f"v_and_b32 v{BS2V[v]}, v{I_MV}, v{BS2U[v]}")
+        o.emit(f"v_and_b32 v{BS2V[v] + 1}, v{I_MV}, v{BS2U[v] + 1}")
+    for v in range(4):
+        o.emit(f"v_and_b32 v{BS2U[v]}, v{I_MU}, v{BS2U[v]}")
+        o.emit(f"v_and_b32 v{BS2U[v] + 1}, v{I_MU}, v{BS2U[v] + 1}")
+
+
+def generate(opts=None):
+    opts = opts or {}
+    per_s1 = opts.get("per_s1", 2)
+    per_s3 = opts.get("per_s3", 2)
+    o = Out()
+    # ------------------------------------------------------------ prologue: parameters, zero carry, first requests
+    o.comment("parameters (LDS slot k at 512 k + 8 lane; %0 = this lane's address of slot 0)")
+    o.emit(f"v_mov_b32 v{I_CL}, %0")
+    o.emit("s_waitcnt lgkmcnt(0)")
+    for k in range(4):
+        o.emit(f"ds_read_b64 {v2(T_REG[k])}, v{I_CL} offset:{(P_TA + k) * 512}")
+    for k in range(6):
+        o.emit(f"ds_read_b64 {a2(AB0 + 2 * k)}, v{I_CL} offset:{(P_BS0 + k) * 512}")
+    for k in range(16):
+        o.emit(f"ds_read_b32 v{VI + k}, v{I_CL} offset:{(P_INT + k) * 512}")
+    o.emit("s_waitcnt lgkmcnt(0)")
+    scal = [(P_REC, S_REC0, 2), (P_RSTRIDE, S_RSTRIDE, 2), (P_PIECE, S_CURA, 2), (P_PSTRIDE, S_PSTRIDE, 2), (P_B2, S_B2, 2),
+            (P_D2, S_D2, 2), (P_NSEQ, S_NSEQ, 1)]
+    for slot, sreg, n in scal:
+        o.emit(f"ds_read_b64 {v2(I_TMP0)}, v{I_CL} offset:{slot * 512}")
+        o.emit("s_waitcnt lgkmcnt(0)")
+        o.emit(f"v_readfirstlane_b32 s{sreg}, v{I_TMP0}")
+        if n == 2:
+            o.emit(f"v_readfirstlane_b32 s{sreg + 1}, v{I_TMP1}")
+    o.emit("s_nop 4")                      # (vector write of a scalar register -> its use as a memory base)
+    o.comment("derived bases")
+    o.emit(f"s_add_u32 s{S_REC1}, s{S_REC0}, {9 * REC_FIELD}")
+    o.emit(f"s_addc_u32 s{S_REC1 + 1}, s{S_REC0 + 1}, 0")
+    o.emit(f"s_add_u32 s{S_REC2}, s{S_REC0}, {18 * REC_FIELD}")
+    o.emit(f"s_addc_u32 s{S_REC2 + 1}, s{S_REC0 + 1}, 0")
+    o.emit(f"s_add_u32 s{S_CUR1}, s{S_CURA}, {PIECE_OUT1 + 2304}")
+    o.emit(f"s_addc_u32 s{S_CUR1 + 1}, s{S_CURA + 1}, 0")
+    o.emit(f"s_add_u32 s{S_CURB}, s{S_CURA}, {3072 + 12288}")
+    o.emit(f"s_addc_u32 s{S_CURB + 1}, s{S_CURA + 1}, 0")
+    o.emit(f"s_add_u32 s{S_CURA}, s{S_CURA}, 3072")
+    o.emit(f"s_addc_u32 s{S_CURA + 1}, s{S_CURA + 1}, 0")
+    for prv, cur in ((S_PRVA, S_CURA), (S_PRVB, S_CURB), (S_PRV1, S_CUR1)):
+        o.emit(f"s_mov_b64 {s2r(prv)}, {s2r(cur)}")     # (element 0 has no predecessor: its stand-in stores go to its own piece)
+    o.emit(f"s_mov_b32 s{S_TSTRIDE}, {NB * NQ * 8}")
+    o.emit(f"s_mov_b32 s{S_ES}, 0")
+    o.comment("element 0's operands, then the bases move on to element 1 (to element 0 again if the column has one element)")
+    for x in operand_loads() + table_loads():
+        o.emit(x)
+    o.emit(f"s_cmp_lt_u32 1, s{S_NSEQ}")
+    o.emit(f"s_cselect_b32 s{S_EFF}, s{S_RSTRIDE}, 0")
+    o.emit(f"s_cselect_b32 s{S_EFF + 1}, s{S_RSTRIDE + 1}, 0")
+    o.emit(f"s_cselect_b32 s{S_TMP}, s{S_TSTRIDE}, 0")
+    for grp in advance_operand_bases()[1:]:
+        for x in grp:
+            o.emit(x)
+    o.comment("zero carry (the parameters are read), zero tile set 1 and final set 1 (flushed, as stand-ins, during element 0)")
+    o.emit(f"v_mov_b32 v{I_ZERO0}, 0")
+    o.emit(f"v_mov_b32 v{I_ZERO1}, 0")
+    for k in range(64):
+        o.emit(f"ds_write_b64 v{I_CL}, {v2(I_ZERO0)} offset:{k * 512}")
+    for r in range(32):
+        o.emit(f"v_accvgpr_write_b32 a{AT + 32 + r}, 0")
+    for r in range(8):
+        o.emit(f"v_accvgpr_write_b32 a{AF + 8 + r}, 0")
+    for x in carry_in(0, 0):
+        o.emit(x)
+    o.emit("s_waitcnt vmcnt(0)")
+    o.emit(".Ltp3_loop_%=:")
+    # ------------------------------------------------------------ one element
+    o.comment("B operands of S1")
+    bs2_operands(o)
+    o.comment("S1; in the shadows: outputs of the previous element's pair column 3, this element's first finals, next element's operands")
+    shadow = ["s_waitcnt lgkmcnt(0)"] + out_store(3, 1, prev=True) + carry_out(3, 1) + finals_in(0, 0)
+    loads = table_loads() + operand_loads()
+    # a record load overwrites the operand register of a matrix instruction: it may only follow it.  S1 order: DU first
+    # k-step (reads aop[mn][0]) 0..8, DU second (aop[mn][1]) 9..17, DV first (aop[mn][2]) 18..26, DV second (aop[mn][1]) 27..35
+    mf = s1_mfmas()
+    by_pos = {k: [] for k in range(36)}
+    for k, x in enumerate(shadow):
+        by_pos[min(k // per_s1, 8)].append(x)
+    for x in table_loads():
+        by_pos[8].append(x)
+    ol = operand_loads()
+    for mn in range(9):
+        by_pos[9 + mn].append(ol[3 * mn + 0])         # aop[mn][0]: read by matrix instruction mn
+        by_pos[27 + mn].append(ol[3 * mn + 2])        # aop[mn][2]: read by 18 + mn
+        by_pos[27 + mn].append(ol[3 * mn + 1])        # aop[mn][1]: read by 9 + mn and 27 + mn
+    adv = advance_operand_bases()
+    for k, m in enumerate(mf):
+        o.emit(m)
+        for x in by_pos[k]:
+            o.emit(x)
+    for grp in adv:
+        for x in grp:
+            o.emit(x)
+    for b1 in range(4):
+        tset = b1 & 1
+        o.comment(f"pair column b1 = {b1}: S2 (points q0 < 4)")
+        s2_pass(o, b1, plane=False)
+        if b1 == 3:
+            o.emit("s_waitcnt vmcnt(0)")       # next element's operands (requested >= 3 pair columns ago); youngest store: b1 = 2's shadows
+        o.emit("s_waitcnt lgkmcnt(0)")
+        shadow = finals_in(b1, tset) if b1 > 0 else []
+        if b1 > 0:
+            shadow = shadow + finals_store(b1 - 1, 1 - tset) + out_store(b1 - 1, 1 - tset, prev=False) + carry_out(b1 - 1, 1 - tset)
+        o.comment(f"S3 main, tile set {tset}")
+        with_shadows(o, s3_main(tset), shadow, per_s3)
+        o.comment("S2 (plane q0 = 4)")
+        s2_pass(o, b1, plane=True)
+        plane_swaps(o)
+        shadow = []
+        if b1 == 3:
+            shadow += ["s_waitcnt lgkmcnt(0)"] + finals_store(3, 1)
+        shadow += carry_in((b1 + 1) % 4, 1 - tset)
+        if b1 == 3:
+            shadow += rotate_piece_bases()
+            shadow += [[f"s_add_u32 s{S_ES}, s{S_ES}, 1", f"s_cmp_lt_u32 s{S_ES}, s{S_NSEQ}"]]
+        o.comment("S3 plane")
+        with_shadows(o, s3_plane(tset), shadow, 3)
+    o.emit(f"s_cbranch_scc1 .Ltp3_loop_%=")
+    # ------------------------------------------------------------ after the last element: its pair column 3
+    o.comment("flush: the last element's pair column 3 (the piece bases were rotated: it is `prev`)")
+    o.emit("s_nop 15")
+    o.emit("s_nop 3")
+    for x in out_store(3, 1, prev=True) + carry_out(3, 1):
+        o.emit(x)
+    o.emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    return o
+
+
+def clobbers():
+    regs = [f"v{k}" for k in range(V0, 256)] + [f"a{k}" for k in range(0, AEND)] + [f"s{k}" for k in range(S0, SEND)]
+    return regs + ["vcc", "scc", "memory"]
+
+
+def render(o):
+    body = [f'    "{ln}\\n\\t"' for ln in o.lines if not ln.startswith(";")]
+    cl = ", ".join(f'"{r}"' for r in clobbers())
+    head = ("// GENERATED by gen_tp3_contract.py -- do not edit (tests/test_isa_lint_cpu.py checks that it is current).\n"
+            "// The column loop of tp3_contract_asm_kernel as ONE asm statement; register map and schedule: see the generator.\n"
+            f"// instructions (prologue + one element + flush): {o.counts}\n")
+    return (head + "#define T3_ASM_LOOP(cl_addr) asm volatile( \\\n" + " \\\n".join(body) +
+            " \\\n    :: \"v\"(cl_addr) \\\n    : " + cl + ")\n")
+
+
+def constants_header():
+    names = ["P_TA", "P_BS0", "P_BS0X", "P_INT", "P_REC", "P_RSTRIDE", "P_PIECE", "P_PSTRIDE", "P_B2", "P_D2", "P_NSEQ", "N_PARAM"]
+    g = globals()
+    return "".join(f"constexpr int T3A_{n} = {g[n]};\n" for n in names)
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "tp3_contract_loop.inc")
+    o = generate()
+    text = render(o) + constants_header()
+    with open(out, "w") as f:
+        f.write(text)
+    print(out, o.counts, "lines", len(o.lines))
+
+
+if __name__ == "__main__":
+    main()
+
+
+# ---------------------------------------------------------------- self-check of the schedule (no GPU, no compiler)
+def check_schedule(o, n_iter=3):
+    """Walks prologue + n_iter unrolled elements + flush in program order and checks what the disassembly lint does not:
+    every register a memory instruction fills is waited for (s_waitcnt) before its first use or overwrite -- LDS
+    instructions of a wave return in order, so lgkmcnt(N) covers all but the youngest N; global loads are only ever
+    trusted behind vmcnt(0) (loads and stores return out of order with respect to each other) -- and a register pair a
+    vector instruction wrote is not read by a v_permlane32_swap / a DPP operand within two wait states.
+    Returns the list of findings (empty = fine)."""
+    import re
+    reg_re = re.compile(r"\b([vas])(?:(\d+)|\[(\d+):(\d+)\])(?![\w.])")
+
+    def regs(text):
+        out = set()
+        for m in reg_re.finditer(text):
+            lo, hi = (int(m.group(2)),) * 2 if m.group(2) is not None else (int(m.group(3)), int(m.group(4)))
+            out.update((m.group(1), k) for k in range(lo, hi + 1))
+        return out
+
+    lines = [ln for ln in o.lines if not ln.startswith(";")]
+    start = next(k for k, ln in enumerate(lines) if ln.startswith(".Ltp3_loop"))
+    end = next(k for k, ln in enumerate(lines) if ln.startswith("s_cbranch_scc1"))
+    seq = lines[:start] + lines[start + 1:end] * n_iter + lines[end + 1:]
+    pending = {}              # register -> ("lds", number) | ("vm", number)
+    n_lds = n_vm = 0
+    done_lds = 0              # LDS instructions 1..done_lds are known to be complete
+    last_valu_write = {}      # register -> instruction index
+    bad = []
+    for idx, ln in enumerate(seq):
+        op = ln.split()[0]
+        rest = ln[len(op):]
+        operands = [x.strip() for x in rest.split(",")] if rest.strip() else []
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", ln)
+            if m:
+                done_lds = max(done_lds, n_lds - int(m.group(1)))
+            m = re.search(r"vmcnt\((\d+)\)", ln)
+            if m and int(m.group(1)) == 0:
+                for r in [r for r, (kind, _) in pending.items() if kind == "vm"]:
+                    del pending[r]
+            for r in [r for r, (kind, num) in pending.items() if kind == "lds" and num <= done_lds]:
+                del pending[r]
+            continue
+        touched = regs(rest)
+        for r in touched:
+            if r in pending:
+                bad.append((idx, ln, f"{r[0]}{r[1]} is still being filled by a {pending[r][0]} instruction"))
+        if op.startswith("v_permlane32_swap") or "_dpp" in op:
+            watch = regs(operands[1]) if "_dpp" in op else touched
+            for r in watch:
+                if idx - last_valu_write.get(r, -10) <= 2:
+                    bad.append((idx, ln, f"{r[0]}{r[1]} written {idx - last_valu_write[r]} instruction(s) before"))
+        if op.startswith("ds_read"):
+            n_lds += 1
+            for r in regs(operands[0]):
+                pending[r] = ("lds", n_lds)
+        elif op.startswith("ds_write"):
+            n_lds += 1
+        elif op.startswith("global_load"):
+            n_vm += 1
+            for r in regs(operands[0]):
+                pending[r] = ("vm", n_vm)
+        elif op.startswith("v_") and operands:
+            for r in regs(operands[0]):
+                last_valu_write[r] = idx
+            if op.startswith("v_permlane32_swap"):
+                for r in regs(operands[1]):
+                    last_valu_write[r] = idx
+    return bad
+
+
+if __name__ == "__main__" and "--check" in sys.argv:
+    findings = check_schedule(generate())
+    for f in findings[:20]:
+        print(f)
+    print(len(findings), "findings")

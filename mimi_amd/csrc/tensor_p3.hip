@@ -25,6 +25,8 @@
 // Nothing is atomic: results are bitwise reproducible.
 #include "tensor_p3.hpp"
 
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <utility>
 
@@ -859,6 +861,121 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// phase 1, hand-scheduled (round 5): the same arithmetic as tp3_contract_kernel above -- per value the same operations in the
+// same order, the sums are bitwise equal -- with the whole column loop as ONE asm statement generated by
+// gen_tp3_contract.py (fixed register map; every LDS / memory / scalar instruction in the shadow of a matrix instruction,
+// double-buffered accumulator tiles, scalar-base addressing, one `s_waitcnt vmcnt(0)` per element: see the generator).
+// This function computes what the loop needs per lane and per column, hands it over through LDS (the carry area, which
+// the loop zeroes once it has read it: 33 slots of [64 lanes] x 8 bytes) and finishes the column as the C++ form does.
+// ------------------------------------------------------------------------------------------------
+#include "tp3_contract_loop.inc"
+
+__global__ __launch_bounds__(64) void tp3_contract_asm_kernel(TensorArgs p) {
+  constexpr int NB = T3_NB, NQ = T3_NQ, PS = T3_PS;
+  extern __shared__ __align__(16) double carry[];   // [16 (a1, b1)][4 slots, the last one zero][64 lanes], then the direction-1 table [6][2][4]
+  const int lane = threadIdx.x;
+  const int J = (int)(blockIdx.x % 3), I = (int)((blockIdx.x / 3) % 3);
+  const int64_t col = blockIdx.x / 9;
+  const int eu = (int)(col % p.box_n[0]), ev = (int)(col / p.box_n[0]);
+  const int n_seq = p.box_n[2];
+  const int64_t e_step = (int64_t)p.box_n[0] * p.box_n[1];
+  const int c16 = lane & 15, kk = lane >> 4, pa = c16 >> 2, pb = c16 & 3;
+  const int pa2 = c16 >> 2, pb2 = (pa2 + (c16 & 3)) & 3;   // direction 2: diagonal pair index
+  double* par = carry + lane;                              // slot k of this lane: par[k * 64]
+  auto put_int = [&](int slot, unsigned v) { *reinterpret_cast<unsigned*>(par + slot * 64) = v; };
+  auto put_ptr = [&](int slot, const void* q) { *reinterpret_cast<uint64_t*>(par + slot * 64) = (uint64_t)(uintptr_t)q; };
+  auto put_i64 = [&](int slot, int64_t v) { *reinterpret_cast<int64_t*>(par + slot * 64) = v; };
+
+  // direction 0 (S3 B operands), as in tp3_contract_kernel
+  {
+    const double* B0 = p.tabB[0] + (int64_t)(p.box_begin[0] + eu) * NB * NQ;
+    const double* D0 = p.tabD[0] + (int64_t)(p.box_begin[0] + eu) * NB * NQ;
+    const double Ba = B0[pa * NQ + kk], Da = D0[pa * NQ + kk], Bb = B0[pb * NQ + kk], Db = D0[pb * NQ + kk];
+    const double Bax = B0[pa * NQ + 4], Dax = D0[pa * NQ + 4], Bbx = B0[pb * NQ + 4], Dbx = D0[pb * NQ + 4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) par[(T3A_P_BS0 + v) * 64] = ((v & 1) ? Da : Ba) * ((v & 2) ? Db : Bb);
+    par[(T3A_P_BS0X + 0) * 64] = kk < 2 ? Bax * Bbx : Dax * Bbx;
+    par[(T3A_P_BS0X + 1) * 64] = kk < 2 ? Bax * Dbx : Dax * Dbx;
+  }
+  // direction 1 (S2 coefficients) through the LDS table behind the carry, as in tp3_contract_kernel
+  double* tl = carry + 16 * 4 * 64;
+  if (lane < 2 * NB * NQ) {
+    const int v = lane / (NB * NQ), a = (lane % (NB * NQ)) / NQ, q = lane % NQ;
+    tl[q * 8 + v * 4 + a] = ((v ? p.tabD[1] : p.tabB[1]) + (int64_t)(p.box_begin[1] + ev) * NB * NQ)[a * NQ + q];
+  } else if (lane < 2 * NB * NQ + 8) {
+    tl[lane] = 0.0;
+  }
+  __syncthreads();
+  {
+    const int ti = lane & 15, th = ti >> 3, tk = ti & 7;
+    auto plane_row = [&](int r) -> int { return kk == 0 ? r : ((kk == 1 && r < 2) ? r + 3 : NQ); };
+    par[(T3A_P_TA + 0) * 64] = tl[8 * th + tk];
+    par[(T3A_P_TA + 1) * 64] = tl[8 * (2 + th) + tk];
+    par[(T3A_P_TA + 2) * 64] = tl[8 * (th == 0 ? 4 : plane_row(0)) + tk];
+    par[(T3A_P_TA + 3) * 64] = tl[8 * plane_row(1 + th) + tk];
+  }
+  // S1 A operands: the points of this lane (byte offsets inside a record field)
+  const int ptU = (c16 & 3) + NQ * (c16 >> 2);
+  const bool vrow = c16 < 4 || c16 == 4 || c16 == 8 || c16 == 12 || c16 == 5 || c16 == 9;
+  const int vq0 = c16 < 4 ? c16 : 4;
+  const int vq1 = c16 < 4 ? 4 : (c16 == 5 ? 3 : (c16 == 9 ? 4 : c16 / 4 - 1));
+  const int ptV = vrow ? vq0 + NQ * vq1 : 0;
+  const unsigned cl_addr = (unsigned)(uintptr_t)par;   // (the low half of a shared-aperture address is the LDS offset)
+  put_int(T3A_P_INT + 0, 8u * (unsigned)(ptU + NQ * NQ * kk));
+  put_int(T3A_P_INT + 1, 8u * (unsigned)((kk == 1 ? ptV : ptU) + NQ * NQ * (NQ - 1)));
+  put_int(T3A_P_INT + 2, 8u * (unsigned)(ptV + NQ * NQ * kk));
+  put_int(T3A_P_INT + 3, 8u * (unsigned)(pa2 * NQ + kk));
+  put_int(T3A_P_INT + 4, 8u * (unsigned)(pb2 * NQ + kk));
+  put_int(T3A_P_INT + 5, 8u * (unsigned)(pa2 * NQ + NQ - 1));
+  put_int(T3A_P_INT + 6, 8u * (unsigned)(pb2 * NQ + NQ - 1));
+  // where this lane reads slot s of a pair's carry: the lane group that stored register s + 1 as final reads the zero slot
+  put_int(T3A_P_INT + 7, cl_addr + (kk == 3 ? 3u * 512u : 0u));
+  put_int(T3A_P_INT + 8, cl_addr + (kk == 2 ? 2u * 512u : 0u));
+  put_int(T3A_P_INT + 9, cl_addr + (kk == 1 ? 1u * 512u : 0u));
+  put_int(T3A_P_INT + 10, cl_addr);
+  // the final entry with b2 = 0 of lane groups 1..3 (register 4 - kk -> slot 3 - kk); lane group 0 has none and doubles
+  // lane group 1's (same slot of lane + 16, same destination: the same value stored twice, no execution mask)
+  put_int(T3A_P_INT + 11, kk == 0 ? cl_addr + 16u * 8u + 2u * 512u : cl_addr + (unsigned)(3 - kk) * 512u);
+  put_int(T3A_P_INT + 12, 8u * (unsigned)(pa * 192 + J * 64 + kk * 4 + pb));                            // rows a2 = 0: + 4 a1 192 + b1 16
+  put_int(T3A_P_INT + 13, 8u * (unsigned)((pa + 16 * (3 - (kk ? kk : 1))) * 48 + J * 16 + pb));        // rows a2 >= 1, b2 = 0: + 4 a1 48 + b1 4
+  put_int(T3A_P_INT + 14, kk == 0 ? 0xffffffffu : 0u);
+  put_int(T3A_P_INT + 15, kk == 1 ? 0xffffffffu : 0u);
+  const int64_t e0 = eu + (int64_t)p.box_n[0] * ev;
+  put_ptr(T3A_P_REC, p.scratch_pt + e0 * (int64_t)(T3_REC * PS) + (int64_t)(I * 27 + J * 3) * PS);
+  put_i64(T3A_P_RSTRIDE, e_step * (int64_t)(T3_REC * PS) * 8);
+  put_ptr(T3A_P_PIECE, p.scratch_k + (e0 * 3 + I) * (int64_t)T3_PIECE);
+  put_i64(T3A_P_PSTRIDE, e_step * 3 * (int64_t)T3_PIECE * 8);
+  put_ptr(T3A_P_B2, p.tabB[2] + (int64_t)p.box_begin[2] * NB * NQ);
+  put_ptr(T3A_P_D2, p.tabD[2] + (int64_t)p.box_begin[2] * NB * NQ);
+  put_i64(T3A_P_NSEQ, n_seq);
+  __syncthreads();
+  T3_ASM_LOOP(cl_addr);
+  // (the loop ends on s_waitcnt vmcnt(0) lgkmcnt(0): the carry of the last element lies in LDS)
+  const double* cl = par;
+  double* out1_prev = p.scratch_k + ((e0 + e_step * (n_seq - 1)) * 3 + I) * (int64_t)T3_PIECE + 3072 +
+                      (pa + 16 * (3 - (kk ? kk : 1))) * 48 + J * 16 + pb;
+  // the b2 = 0 entries of the last element
+  {
+    const double* fl = cl + (kk == 0 ? 3 : 3 - kk) * 64;
+#pragma unroll
+    for (int ab = 0; ab < 16; ++ab) {
+      const double v = fl[ab * 4 * 64];
+      if (kk > 0) out1_prev[(ab / NB) * 4 * 48 + (ab % NB) * 4] = v;
+    }
+  }
+  // what the last element of the column would have passed on: rows a2 >= 1, b2 >= 1 -> the tail of (column, i)
+  double* tail = p.scratch_tail + ((e0 * 3 + I) * (int64_t)T3_TAIL) + pa * 144 + J * 48 + pb;
+#pragma unroll
+  for (int ab = 0; ab < 16; ++ab)
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      const int b2 = (r + kk) & 3;
+      const double v = cl[(ab * 4 + r - 1) * 64];
+      if (b2) tail[(4 * (ab / NB) + 16 * (r - 1)) * 144 + (ab % NB) * 12 + (b2 - 1) * 4] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // phase 2
 // ------------------------------------------------------------------------------------------------
 // One wave per (node A of the shard's node box, component i).  WITH_K 0: residual rows only.
@@ -1052,7 +1169,12 @@ void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {
   h->phase_has_prepass = true;
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[3], h->stream));
   if (grad && h->phase_select != 2) {
-    hipLaunchKernelGGL(tp3_contract_kernel, dim3((unsigned)(n_cols * 9)), dim3(64), (16 * 4 * 64 + 48) * sizeof(double), h->stream, a);
+    // MIMI_HIP_P3_CONTRACT=cxx: the compiler-scheduled form of the same arithmetic (the A/B reference of the bitwise test)
+    // (read per launch, so that one process can run both: tests/test_tensor_p3_gpu.py)
+    const char* variant = getenv("MIMI_HIP_P3_CONTRACT");
+    const bool cxx = variant && !strcmp(variant, "cxx");
+    hipLaunchKernelGGL(cxx ? tp3_contract_kernel : tp3_contract_asm_kernel, dim3((unsigned)(n_cols * 9)), dim3(64),
+                       (16 * 4 * 64 + 48) * sizeof(double), h->stream, a);
     MH_HIP(hipGetLastError());
   }
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[1], h->stream));

@@ -52,6 +52,33 @@ def test_p3_residual_and_tangent_parity(case, matname):
     assert np.array_equal(r_2, r_g) and np.array_equal(A_2, A_g)
 
 
+@pytest.mark.parametrize("matname", ["neohook", "j2"])
+@pytest.mark.parametrize("n_el", [(1, 1, 1), (2, 2, 1), (3, 2, 2), (2, 3, 5), (5, 4, 7)], ids=lambda c: "x".join(map(str, c)))
+def test_p3_hand_scheduled_contraction_equals_the_compiler_scheduled_one_bitwise(n_el, matname, monkeypatch):
+    """Round 5: the column loop of the contraction is one generated asm statement (tp3_contract_asm_kernel,
+    csrc/gen_tp3_contract.py: fixed register map, memory / LDS / scalar instructions in the shadows of the matrix
+    instructions, double-buffered accumulator tiles, stand-in stores for the first element).  Per value it performs the
+    operations of the compiler-scheduled C++ form (tp3_contract_kernel, MIMI_HIP_P3_CONTRACT=cxx) in the same order, so
+    every assembled value must be the same BITS -- on columns of 1, 2, 5 and 7 elements (the stand-in stores of element 0,
+    the clamped prefetch of the last element, both tile-set parities at the column end).  Same reference lines as the
+    kernels: integrators/nonlinear_solid.cpp:48-76 at n_dof 64."""
+    P, D, G = make_pair(n_el, 3, None, matname, "bspline")
+    assert G.path_ == 1
+    G.dt_ = 0.5
+    u = synthetic_u(P, scale=0.05 if matname == "neohook" else 0.02)
+    out = {}
+    for variant in ("cxx", "asm", "cxx", "asm"):
+        monkeypatch.setenv("MIMI_HIP_P3_CONTRACT", variant)
+        r, A = np.zeros(P.n_vdofs), np.full(D.nnz, 0.25)
+        G.AddDomainResidualAndGrad(u, 0.37, r, A)
+        assert np.abs(A - 0.25).max() > 0
+        if variant in out:
+            assert np.array_equal(out[variant][0], r) and np.array_equal(out[variant][1], A)
+        out[variant] = (r, A)
+    assert np.array_equal(out["asm"][0], out["cxx"][0])
+    assert np.array_equal(out["asm"][1], out["cxx"][1])
+
+
 @pytest.mark.parametrize("matname", ["stvk", "j2simo"])
 def test_p3_other_materials(matname):
     """the materials without a closed-form tangent run through the same record (materials_other.hpp)"""
