@@ -41,6 +41,7 @@ struct mimi_hip_domain_s {
   mimi_hip::DeviceBuffer<uint16_t> nbr_pos16;     // [n_nodes][343] the same for degree 3
   bool first_is_identity = false;            // span e's first basis function is e (no repeated interior knots)
   mimi_hip::DeviceBuffer<double> scratch_k, scratch_r, scratch_pt, scratch_tail;  // two-phase tangent path
+  mimi_hip::DeviceBuffer<double> t3_t2pack;  // degree-3 contraction: direction-2 table values per (span, lane), [n_spans][64][8] (tensor_p3.hip)
 
   // J2 state, SoA over points
   mimi_hip::DeviceBuffer<double> eqps, temperature, plastic_strain, state2;

@@ -13,8 +13,11 @@ and ends every element with `s_waitcnt vmcnt(0)` right behind its last stores.  
   * the four accumulator tiles are double-buffered (tile set = b1 & 1): the stores and the carry writes of pair column b1
     go out in the shadows of pair column b1 + 1, the carry reads of b1 + 1 in the shadows of b1's plane instructions;
   * addresses are scalar bases + one per-lane offset register + immediates: no vector address arithmetic in the loop;
-  * ONE `s_waitcnt vmcnt(0)` per element, placed where the youngest memory instruction is ~2 000 cycles old (loads and
-    stores return out of order with respect to each other, so a counted wait would not be safe);
+  * ONE counted `s_waitcnt vmcnt(N)` per element at the loop top, N = the stores issued behind the last operand load
+    (gfx9 has one in-order counter for global loads and stores -- no vscnt --, which is what the compiler's own counted
+    waits rely on; the C++ form ends every element with vmcnt(0) right behind its last stores);
+  * at most one global-memory instruction per shadow: the CU's address unit takes 16 - 21 cycles per wave instruction and
+    serves four waves (two stores in one shadow outlast it: profiles/r05_cfg3_contract_ablations_v1.txt);
   * per value, the floating-point operations and their order are those of tp3_contract_kernel: the sums are bitwise equal
     (tests/test_tensor_p3_gpu.py compares the two kernels).
 
@@ -40,21 +43,21 @@ VCA = VCB + 4                # ca[4]
 VT = VCA + 8                 # TA, TB, TC, TD
 VT2 = VT + 8                 # t2[s][k]: VT2 + 2 (4 s + k)
 VI = VT2 + 16                # 32-bit per-lane values
-(I_OFFU, I_OFFX, I_OFFV, I_OA, I_OB, I_OAX, I_OBX, I_CIN0, I_CIN1, I_CIN2, I_CIN3, I_FIN, I_OUT0, I_OUT1, I_MU, I_MV,
+(I_OFFU, I_OFFX, I_OFFV, I_OFFU8, I_OFFX8, I_OFFV8, I_OT2, I_CIN0, I_CIN1, I_CIN2, I_CIN3, I_FIN, I_OUT0, I_OUT1, I_MU, I_MV,
  I_TMP0, I_TMP1, I_CL) = range(VI, VI + 19)
 assert I_TMP0 % 2 == 0           # (a 64-bit operand needs an even register)
 I_ZERO0, I_ZERO1 = I_TMP0, I_TMP1      # (prologue only, after the scalar parameters are read)
 VEND = VI + 19
 assert VEND <= 256, VEND
 
-AA = 0                       # aop[mn][t] = AA + 2 (3 mn + t)
+AA = 0                       # aop[mn][t] = AA + 18 t + 2 mn (a 16-byte load fills mn = 2 q, 2 q + 1 of one t)
 AT = 56                      # tile set s, tile a1: AT + 32 s + 8 a1
 AB0 = 120                    # bS0[g] = AB0 + 2 g, bS0x[h] = AB0 + 8 + 2 h
 AF = 132                     # fin set s: AF + 8 s + 2 a1
 AEND = 148
 
 S0 = 36                      # first SGPR of the asm block
-(S_REC0, S_REC1, S_REC2, S_RSTRIDE, S_CURA, S_CURB, S_CUR1, S_PRVA, S_PRVB, S_PRV1, S_PSTRIDE, S_B2, S_D2, S_TMP, S_EFF) = \
+(S_REC0, S_REC1, S_REC2, S_RSTRIDE, S_CURA, S_CURB, S_CUR1, S_PRVA, S_PRVB, S_PRV1, S_PSTRIDE, S_B2, S_SPARE, S_TMP, S_EFF) = \
     [S0 + 2 * k for k in range(15)]
 S_ES, S_NSEQ, S_TSTRIDE = S0 + 30, S0 + 31, S0 + 32
 SEND = S0 + 34
@@ -62,7 +65,7 @@ SEND = S0 + 34
 # parameter slots in LDS (slot k: bytes [512 k, 512 k + 512), 8 bytes per lane)
 P_TA, P_BS0, P_BS0X = 0, 4, 8
 P_INT = 10                   # 16 ints in the order of I_OFFU .. I_MV
-P_REC, P_RSTRIDE, P_PIECE, P_PSTRIDE, P_B2, P_D2, P_NSEQ = 26, 27, 28, 29, 30, 31, 32
+P_REC, P_RSTRIDE, P_PIECE, P_PSTRIDE, P_B2, P_D2, P_NSEQ = 26, 27, 28, 29, 30, 31, 32     # (P_B2: the packed table values; P_D2 unused)
 N_PARAM = 33
 
 REC_FIELD = 1024             # bytes per record field (128 points)
@@ -107,7 +110,7 @@ def T2(s, k):
 
 
 def AOP(mn, t):
-    return AA + 2 * (3 * mn + t)
+    return AA + 18 * t + 2 * mn
 
 
 def TILE(s, a1, r=None):
@@ -120,13 +123,33 @@ def FIN(s, a1):
 
 
 class Out:
-    def __init__(self):
+    def __init__(self, drop=()):
         self.lines = []
         self.counts = {}
+        self.drop = set(drop)      # timing experiments only (scratch/p3_asm_variants.sh): classes of loop instructions left out
+        self.in_loop = False
 
     def emit(self, text, kind=None):
-        self.lines.append(text)
         op = text.split()[0]
+        if op.startswith(".Ltp3_loop"):
+            self.in_loop = True
+        if self.in_loop and self.drop:
+            cls = ("store" if op.startswith("global_store") else "load" if op.startswith("global_load") else
+                   "lds" if op.startswith("ds_") else "mfma" if op.startswith("v_mfma") else
+                   "swap" if op.startswith("v_permlane") else "valu" if op.startswith("v_") else "other")
+            if cls in self.drop:
+                return
+        if self.in_loop and "x4probe" in self.drop and op.startswith("global_store"):
+            # timing probe: half as many store instructions, twice as wide (same bytes; the values are not the results)
+            self.n_store = getattr(self, "n_store", 0) + 1
+            if self.n_store % 2:
+                return
+            text = text.replace("global_store_dwordx2", "global_store_dwordx4")
+            import re as _re
+            m = _re.search(r"a\[(\d+):(\d+)\]", text)
+            lo = int(m.group(1)) & ~3
+            text = text.replace(m.group(0), f"a[{lo}:{lo + 3}]")
+        self.lines.append(text)
         k = kind or ("mfma" if op.startswith("v_mfma") else "valu" if op.startswith("v_") else
                      "lds" if op.startswith("ds_") else "vmem" if op.startswith("global_") else "salu")
         self.counts[k] = self.counts.get(k, 0) + 1
@@ -270,25 +293,24 @@ def out_store(b1, tset, prev):
 
 
 def operand_loads():
-    """the 27 record values and the 8 table values of the next element (bases already point at it)"""
+    """the 27 record values of the next element (bases already point at it) as (first S1 slot it may follow, instruction):
+    per operand kind t (0: tile U first k-step, 1: second k-step of both tiles, 2: tile V first k-step) four 16-byte loads
+    of the pair fields q (mn = 2 q, 2 q + 1) and one 8-byte load of the single field mn = 8.  A load overwrites operand
+    registers of matrix instructions and may only follow the last of them: S1 order DU first k-step (reads aop[mn][0]) at
+    slot mn, DU second (aop[mn][1]) 9 + mn, DV first (aop[mn][2]) 18 + mn, DV second (aop[mn][1]) 27 + mn."""
     out = []
-    for mn in range(9):
-        m, n = divmod(mn, 3)
-        base = (S_REC0, S_REC1, S_REC2)[m]
-        out.append(f"global_load_dwordx2 {a2(AOP(mn, 0))}, v{I_OFFU}, {s2r(base)} offset:{n * REC_FIELD}")
-        out.append(f"global_load_dwordx2 {a2(AOP(mn, 1))}, v{I_OFFX}, {s2r(base)} offset:{n * REC_FIELD}")
-        out.append(f"global_load_dwordx2 {a2(AOP(mn, 2))}, v{I_OFFV}, {s2r(base)} offset:{n * REC_FIELD}")
+    first = {0: 0, 2: 18, 1: 27}
+    for t, off16, off8 in ((0, I_OFFU, I_OFFU8), (2, I_OFFV, I_OFFV8), (1, I_OFFX, I_OFFX8)):
+        for q in range(4):
+            base = S_REC0 if q < 2 else S_REC1
+            out.append((first[t] + 2 * q + 1,
+                        f"global_load_dwordx4 a[{AOP(2 * q, t)}:{AOP(2 * q, t) + 3}], v{off16}, {s2r(base)} offset:{(q & 1) * 2 * REC_FIELD}"))
+        out.append((first[t] + 8, f"global_load_dwordx2 {a2(AOP(8, t))}, v{off8}, {s2r(S_REC2)}"))
     return out
 
 
 def table_loads():
-    out = []
-    for s, (oa, ob) in enumerate(((I_OA, I_OB), (I_OAX, I_OBX))):
-        out.append(f"global_load_dwordx2 {v2(T2(s, 0))}, v{oa}, {s2r(S_B2)}")
-        out.append(f"global_load_dwordx2 {v2(T2(s, 1))}, v{oa}, {s2r(S_D2)}")
-        out.append(f"global_load_dwordx2 {v2(T2(s, 2))}, v{ob}, {s2r(S_B2)}")
-        out.append(f"global_load_dwordx2 {v2(T2(s, 3))}, v{ob}, {s2r(S_D2)}")
-    return out
+    return [f"global_load_dwordx4 v[{T2(0, 0) + 4 * q}:{T2(0, 0) + 4 * q + 3}], v{I_OT2}, {s2r(S_B2)} offset:{16 * q}" for q in range(4)]
 
 
 def advance_operand_bases():
@@ -302,7 +324,6 @@ def advance_operand_bases():
         [f"s_add_u32 s{S_REC1}, s{S_REC1}, s{S_EFF}", f"s_addc_u32 s{S_REC1 + 1}, s{S_REC1 + 1}, s{S_EFF + 1}"],
         [f"s_add_u32 s{S_REC2}, s{S_REC2}, s{S_EFF}", f"s_addc_u32 s{S_REC2 + 1}, s{S_REC2 + 1}, s{S_EFF + 1}"],
         [f"s_add_u32 s{S_B2}, s{S_B2}, s{S_TMP}", f"s_addc_u32 s{S_B2 + 1}, s{S_B2 + 1}, 0"],
-        [f"s_add_u32 s{S_D2}, s{S_D2}, s{S_TMP}", f"s_addc_u32 s{S_D2 + 1}, s{S_D2 + 1}, 0"],
     ]
 
 
@@ -372,7 +393,7 @@ def generate(opts=None):
     opts = opts or {}
     per_s1 = opts.get("per_s1", 2)
     per_s3 = opts.get("per_s3", 2)
-    o = Out()
+    o = Out(opts.get("drop", ()))
     # ------------------------------------------------------------ prologue: parameters, zero carry, first requests
     o.comment("parameters (LDS slot k at 512 k + 8 lane; %0 = this lane's address of slot 0)")
     o.emit(f"v_mov_b32 v{I_CL}, %0")
@@ -385,7 +406,7 @@ def generate(opts=None):
         o.emit(f"ds_read_b32 v{VI + k}, v{I_CL} offset:{(P_INT + k) * 512}")
     o.emit("s_waitcnt lgkmcnt(0)")
     scal = [(P_REC, S_REC0, 2), (P_RSTRIDE, S_RSTRIDE, 2), (P_PIECE, S_CURA, 2), (P_PSTRIDE, S_PSTRIDE, 2), (P_B2, S_B2, 2),
-            (P_D2, S_D2, 2), (P_NSEQ, S_NSEQ, 1)]
+            (P_NSEQ, S_NSEQ, 1)]
     for slot, sreg, n in scal:
         o.emit(f"ds_read_b64 {v2(I_TMP0)}, v{I_CL} offset:{slot * 512}")
         o.emit("s_waitcnt lgkmcnt(0)")
@@ -394,9 +415,9 @@ def generate(opts=None):
             o.emit(f"v_readfirstlane_b32 s{sreg + 1}, v{I_TMP1}")
     o.emit("s_nop 4")                      # (vector write of a scalar register -> its use as a memory base)
     o.comment("derived bases")
-    o.emit(f"s_add_u32 s{S_REC1}, s{S_REC0}, {9 * REC_FIELD}")
+    o.emit(f"s_add_u32 s{S_REC1}, s{S_REC0}, {4 * REC_FIELD}")          # pair fields q = 2, 3
     o.emit(f"s_addc_u32 s{S_REC1 + 1}, s{S_REC0 + 1}, 0")
-    o.emit(f"s_add_u32 s{S_REC2}, s{S_REC0}, {18 * REC_FIELD}")
+    o.emit(f"s_add_u32 s{S_REC2}, s{S_REC0}, {8 * REC_FIELD}")          # the single field mn = 8
     o.emit(f"s_addc_u32 s{S_REC2 + 1}, s{S_REC0 + 1}, 0")
     o.emit(f"s_add_u32 s{S_CUR1}, s{S_CURA}, {PIECE_OUT1 + 2304}")
     o.emit(f"s_addc_u32 s{S_CUR1 + 1}, s{S_CURA + 1}, 0")
@@ -406,10 +427,10 @@ def generate(opts=None):
     o.emit(f"s_addc_u32 s{S_CURA + 1}, s{S_CURA + 1}, 0")
     for prv, cur in ((S_PRVA, S_CURA), (S_PRVB, S_CURB), (S_PRV1, S_CUR1)):
         o.emit(f"s_mov_b64 {s2r(prv)}, {s2r(cur)}")     # (element 0 has no predecessor: its stand-in stores go to its own piece)
-    o.emit(f"s_mov_b32 s{S_TSTRIDE}, {NB * NQ * 8}")
+    o.emit(f"s_mov_b32 s{S_TSTRIDE}, {64 * 8 * 8}")                    # table values per span: [64 lanes][8]
     o.emit(f"s_mov_b32 s{S_ES}, 0")
     o.comment("element 0's operands, then the bases move on to element 1 (to element 0 again if the column has one element)")
-    for x in operand_loads() + table_loads():
+    for x in [x for _, x in operand_loads()] + table_loads():
         o.emit(x)
     o.emit(f"s_cmp_lt_u32 1, s{S_NSEQ}")
     o.emit(f"s_cselect_b32 s{S_EFF}, s{S_RSTRIDE}, 0")
@@ -425,63 +446,95 @@ def generate(opts=None):
         o.emit(f"ds_write_b64 v{I_CL}, {v2(I_ZERO0)} offset:{k * 512}")
     for r in range(32):
         o.emit(f"v_accvgpr_write_b32 a{AT + 32 + r}, 0")
-    for r in range(8):
-        o.emit(f"v_accvgpr_write_b32 a{AF + 8 + r}, 0")
+    for r in range(16):
+        o.emit(f"v_accvgpr_write_b32 a{AF + r}, 0")
     for x in carry_in(0, 0):
         o.emit(x)
     o.emit("s_waitcnt vmcnt(0)")
     o.emit(".Ltp3_loop_%=:")
     # ------------------------------------------------------------ one element
-    o.comment("B operands of S1")
-    bs2_operands(o)
-    o.comment("S1; in the shadows: outputs of the previous element's pair column 3, this element's first finals, next element's operands")
-    shadow = ["s_waitcnt lgkmcnt(0)"] + out_store(3, 1, prev=True) + carry_out(3, 1) + finals_in(0, 0)
-    loads = table_loads() + operand_loads()
-    # a record load overwrites the operand register of a matrix instruction: it may only follow it.  S1 order: DU first
-    # k-step (reads aop[mn][0]) 0..8, DU second (aop[mn][1]) 9..17, DV first (aop[mn][2]) 18..26, DV second (aop[mn][1]) 27..35
+    # Matrix instruction slots of an element: S1 0..35, then per pair column b1 S3 main 36 + 24 b1 .. + 15 and S3 plane .. + 23.
+    # Everything that is not a vector instruction is dealt out into the shadows behind them: at most `vm_cap` global-memory
+    # instructions per shadow (the CU's address unit takes 16 - 21 cycles per wave instruction and is shared by four waves:
+    # two stores in one shadow already outlast it -- measured, profiles/r05_cfg3_contract_ablations_v1.txt), `lds_cap` LDS
+    # instructions, one group of scalar instructions.
+    vm_cap, lds_cap = opts.get("vm_cap", 1), opts.get("lds_cap", 2)
+    n_slot = 36 + 4 * 24
+    m_of = lambda b1: 36 + 24 * b1          # first S3 main slot of pair column b1
+    p_of = lambda b1: 36 + 24 * b1 + 16     # first S3 plane slot
     mf = s1_mfmas()
-    by_pos = {k: [] for k in range(36)}
-    for k, x in enumerate(shadow):
-        by_pos[min(k // per_s1, 8)].append(x)
-    for x in table_loads():
-        by_pos[8].append(x)
-    ol = operand_loads()
-    for mn in range(9):
-        by_pos[9 + mn].append(ol[3 * mn + 0])         # aop[mn][0]: read by matrix instruction mn
-        by_pos[27 + mn].append(ol[3 * mn + 2])        # aop[mn][2]: read by 18 + mn
-        by_pos[27 + mn].append(ol[3 * mn + 1])        # aop[mn][1]: read by 9 + mn and 27 + mn
-    adv = advance_operand_bases()
-    for k, m in enumerate(mf):
-        o.emit(m)
-        for x in by_pos[k]:
-            o.emit(x)
-    for grp in adv:
-        for x in grp:
-            o.emit(x)
+    for b1 in range(4):
+        mf += s3_main(b1 & 1) + s3_plane(b1 & 1)
+    assert len(mf) == n_slot
+    # (kind, earliest slot, latest slot, instruction or group).  Order inside a kind = issue order.
+    ops = []
+
+    def add(kind, lo, hi, items):
+        for x in items:
+            ops.append([kind, lo, hi, x])
+
+    # outputs of the previous element's pair column 3 (tile set 1, `prev` bases) -- before tile set 1 is read into again
+    for i, x in enumerate(out_store(3, 1, prev=True)):
+        add("vm", i, p_of(0) - 1, [x])
+    add("lds", 0, p_of(0) - 1, carry_out(3, 1))
+    # next element's operands (operand_loads); the tables' registers are free once the B operands are formed
+    last_load = opts.get("last_load", m_of(2) - 1)
+    load_spread, store_spread = opts.get("load_spread", 1), opts.get("store_spread", 2)
+    loads = [(0, x) for x in table_loads()] + sorted(operand_loads(), key=lambda t: t[0])
+    first_load = opts.get("first_load", 4)
+    for i, (lo, x) in enumerate(loads):
+        add("vm", max(lo, first_load + i * load_spread), last_load, [x])
+    add("sc", last_load + 1, n_slot - 1, advance_operand_bases())
     for b1 in range(4):
         tset = b1 & 1
-        o.comment(f"pair column b1 = {b1}: S2 (points q0 < 4)")
-        s2_pass(o, b1, plane=False)
-        if b1 == 3:
-            o.emit("s_waitcnt vmcnt(0)")       # next element's operands (requested >= 3 pair columns ago); youngest store: b1 = 2's shadows
-        o.emit("s_waitcnt lgkmcnt(0)")
-        shadow = finals_in(b1, tset) if b1 > 0 else []
+        # finals found by the previous plane shadows (waited for at the head of S3 main), this element's (b1 - 1) outputs
+        for i, x in enumerate(finals_store(b1, tset)):
+            add("vm", m_of(b1) + 2 * store_spread * i, m_of(b1) + 15, [x])
         if b1 > 0:
-            shadow = shadow + finals_store(b1 - 1, 1 - tset) + out_store(b1 - 1, 1 - tset, prev=False) + carry_out(b1 - 1, 1 - tset)
-        o.comment(f"S3 main, tile set {tset}")
-        with_shadows(o, s3_main(tset), shadow, per_s3)
-        o.comment("S2 (plane q0 = 4)")
-        s2_pass(o, b1, plane=True)
-        plane_swaps(o)
-        shadow = []
-        if b1 == 3:
-            shadow += ["s_waitcnt lgkmcnt(0)"] + finals_store(3, 1)
-        shadow += carry_in((b1 + 1) % 4, 1 - tset)
-        if b1 == 3:
-            shadow += rotate_piece_bases()
-            shadow += [[f"s_add_u32 s{S_ES}, s{S_ES}, 1", f"s_cmp_lt_u32 s{S_ES}, s{S_NSEQ}"]]
-        o.comment("S3 plane")
-        with_shadows(o, s3_plane(tset), shadow, 3)
+            for i, x in enumerate(out_store(b1 - 1, 1 - tset, prev=False)):
+                add("vm", m_of(b1) + 2 * store_spread * i + store_spread, p_of(b1) - 1, [x])
+            add("lds", m_of(b1), p_of(b1) - 1, carry_out(b1 - 1, 1 - tset))
+        # the finals the next pair column's S3 main shadows will store (any time before its head, where they are waited for;
+        # their register set was stored from by pair column b1 - 1) and the start values of its tiles
+        add("lds", m_of(b1), p_of(b1) + 7, finals_in((b1 + 1) % 4, 1 - tset))
+        add("lds", p_of(b1), p_of(b1) + 7, carry_in((b1 + 1) % 4, 1 - tset))
+    add("sc", p_of(3), n_slot - 1, rotate_piece_bases())
+    # assignment: slot by slot, per kind the eligible instructions with the earliest deadline first
+    cap = {"vm": vm_cap, "lds": lds_cap, "sc": 1}
+    shadow = [[] for _ in range(n_slot)]
+    for k in range(n_slot):
+        for kind in ("vm", "lds", "sc"):
+            ready = sorted((q for q in ops if q[3] is not None and q[0] == kind and q[1] <= k), key=lambda q: q[2])
+            for q in ready[:cap[kind]]:
+                assert k <= q[2], (k, q)
+                shadow[k].append(q[3])
+                q[3] = None
+    late = [q for q in ops if q[3] is not None]
+    assert not late, late[:3]
+    flat = [y for k in range(n_slot) for x in shadow[k] for y in (x if isinstance(x, list) else [x])]
+    last = max(k for k, y in enumerate(flat) if y.startswith("global_load"))
+    n_vm_after_last_load = sum(1 for y in flat[last + 1:] if y.startswith("global_"))
+    o.comment("B operands of S1")
+    assert n_vm_after_last_load < 60
+    o.emit(f"s_waitcnt vmcnt({n_vm_after_last_load})")     # this element's operands (vector memory instructions of a wave complete in order on gfx9)
+    bs2_operands(o)
+    for k, m in enumerate(mf):
+        if k >= 36 and (k - 36) % 24 == 0:
+            b1 = (k - 36) // 24
+            o.comment(f"pair column b1 = {b1}: S2 (points q0 < 4), S3 main")
+            s2_pass(o, b1, plane=False)
+            o.emit("s_waitcnt lgkmcnt(0)")
+        if k >= 36 and (k - 36) % 24 == 16:
+            b1 = (k - 36) // 24
+            o.comment("S2 (plane q0 = 4), S3 plane")
+            s2_pass(o, b1, plane=True)
+            plane_swaps(o)
+        o.emit(m)
+        for x in shadow[k]:
+            for y in (x if isinstance(x, list) else [x]):
+                o.emit(y)
+    o.emit(f"s_add_u32 s{S_ES}, s{S_ES}, 1")
+    o.emit(f"s_cmp_lt_u32 s{S_ES}, s{S_NSEQ}")
     o.emit(f"s_cbranch_scc1 .Ltp3_loop_%=")
     # ------------------------------------------------------------ after the last element: its pair column 3
     o.comment("flush: the last element's pair column 3 (the piece bases were rotated: it is `prev`)")
@@ -515,15 +568,22 @@ def constants_header():
 
 
 def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "tp3_contract_loop.inc")
-    o = generate()
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    opts = {}
+    for a in sys.argv[1:]:
+        if a.startswith("--drop="):
+            opts["drop"] = a[7:].split(",")
+        elif a.startswith("--") and "=" in a:
+            opts[a[2:a.index("=")]] = int(a[a.index("=") + 1:])
+    out = args[0] if args else os.path.join(os.path.dirname(os.path.abspath(__file__)), "tp3_contract_loop.inc")
+    o = generate(opts)
     text = render(o) + constants_header()
     with open(out, "w") as f:
         f.write(text)
     print(out, o.counts, "lines", len(o.lines))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--check" not in sys.argv:
     main()
 
 
@@ -531,8 +591,8 @@ if __name__ == "__main__":
 def check_schedule(o, n_iter=3):
     """Walks prologue + n_iter unrolled elements + flush in program order and checks what the disassembly lint does not:
     every register a memory instruction fills is waited for (s_waitcnt) before its first use or overwrite -- LDS
-    instructions of a wave return in order, so lgkmcnt(N) covers all but the youngest N; global loads are only ever
-    trusted behind vmcnt(0) (loads and stores return out of order with respect to each other) -- and a register pair a
+    instructions of a wave return in order, so lgkmcnt(N) covers all but the youngest N; global loads and stores share one
+    in-order counter on gfx9 (no vscnt: what the compiler's own waits rely on), so vmcnt(N) covers all but the youngest N -- and a register pair a
     vector instruction wrote is not read by a v_permlane32_swap / a DPP operand within two wait states.
     Returns the list of findings (empty = fine)."""
     import re
@@ -563,8 +623,9 @@ def check_schedule(o, n_iter=3):
             if m:
                 done_lds = max(done_lds, n_lds - int(m.group(1)))
             m = re.search(r"vmcnt\((\d+)\)", ln)
-            if m and int(m.group(1)) == 0:
-                for r in [r for r, (kind, _) in pending.items() if kind == "vm"]:
+            if m:
+                done_vm = n_vm - int(m.group(1))       # (global loads and stores of a wave complete in order on gfx9: one counter)
+                for r in [r for r, (kind, num) in pending.items() if kind == "vm" and num <= done_vm]:
                     del pending[r]
             for r in [r for r, (kind, num) in pending.items() if kind == "lds" and num <= done_lds]:
                 del pending[r]
@@ -588,6 +649,8 @@ def check_schedule(o, n_iter=3):
             n_vm += 1
             for r in regs(operands[0]):
                 pending[r] = ("vm", n_vm)
+        elif op.startswith("global_store"):
+            n_vm += 1
         elif op.startswith("v_") and operands:
             for r in regs(operands[0]):
                 last_valu_write[r] = idx

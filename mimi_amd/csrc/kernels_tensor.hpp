@@ -67,6 +67,7 @@ struct TensorArgs {
   const unsigned char* nbr_pos;  // two-phase path, permuted numbering: [n_nodes][125] positions inside a CSR row
   const uint16_t* nbr_pos16; // p = 3 two-phase path, permuted numbering: [n_nodes][343] positions inside a CSR row
   double* scratch_tail;      // p = 3 two-phase path: [column][3][48*144] carried rows of the last element of a column
+  const double* t2pack;      // p = 3 two-phase path: [span of direction 2][64 lanes][8] table values of the contraction's S1 B operands
   int win_begin[3], win_n[3];  // two-phase paths, phase 2: the nodes this launch gathers (global node indices per direction;
                                // default: every node the handle's elements touch; mimi_hip_domain_gather: a part of them)
 };

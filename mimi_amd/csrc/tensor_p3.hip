@@ -35,6 +35,7 @@ namespace mimi_hip {
 namespace {
 
 typedef double t3_d4 __attribute__((ext_vector_type(4)));
+typedef double t3_d2 __attribute__((ext_vector_type(2)));
 
 // the record is written once by the pre-pass and read once by the contraction, 21.6 GB at BASELINE configuration 3: stored
 // with the non-temporal hint (pre-pass 7.48 -> 7.14 ms, 7.6 -> 7.3 ms on a second box; the same hint on the contraction's
@@ -44,7 +45,13 @@ typedef double t3_d4 __attribute__((ext_vector_type(4)));
 // loads nothing: profiles/r04_cfg3_nt_variants.txt)
 
 constexpr int T3_NB = 4, T3_NQ = 5, T3_ND = 64, T3_NPT = 125, T3_PS = 128, T3_NROW = 192;
-constexpr int T3_REC = 90;                        // 81 Ahat + 9 Phat (the record layout of kernels_tensor_wgs.hpp)
+constexpr int T3_REC = 90;                        // fields of 128 points per element: 81 used (Ahat), 9 spare
+// Record layout (round 5): per (i, j) nine fields mn = 3 m + n, stored as four PAIR fields [point][mn = 2 q, 2 q + 1] and one
+// single field [point] (mn = 8) -- a lane's two values of a pair are 16 adjacent bytes: the pre-pass writes a pair with
+// one 16-byte store per lane (45 fully coalesced store instructions per element instead of 81), a contraction wave reads
+// it with one 16-byte load (15 operand loads per block instead of 27; a global-memory instruction costs a wave of
+// this kernel 50 - 80 cycles whatever its width: profiles/r05_cfg3_contract_ablations_v2.txt).
+MH_DEV constexpr int t3_rec_block(int i, int j) { return (i * 3 + j) * 9 * T3_PS; }        // doubles, + pair q 2 PS + 2 point (+ 1) | 8 PS + point
 constexpr int T3_PIECE = 16 * 192 + 48 * 48;       // doubles per (element, i): rows a2 = 0, then rows a2 >= 1 at b2 = 0
 constexpr int T3_TAIL = 48 * 144;                  // per (column, i): rows a2 >= 1 at b2 >= 1 of the column's last element
 
@@ -53,13 +60,22 @@ constexpr int T3_TAIL = 48 * 144;                  // per (column, i): rows a2 >
 // ------------------------------------------------------------------------------------------------
 // Closed forms of the pulled-back, weighted tangent Ahat_i[m][j][n] = wd sum_JL Jinv[m][J] dP_iJ/dF_jL Jinv[n][L] for the
 // two materials with a closed-form dP/dF (materials.hpp tangent_of; the same expressions as the p = 2 point wave,
-// kernels_tensor_wgs.hpp), written straight into the record: rec[field * T3_PS], field = i 27 + (m 3 + j) 3 + n.
+// kernels_tensor_wgs.hpp), written straight into the record (layout: t3_rec_block).
 //   with G = Jinv F^-1 (G[m][i] = sum_J Jinv[m][J] Finv[J][i]):
 //   neo-Hookean   wd (mu d_ij M[m][n] - c1 G[n][i] G[m][j] + c2 G[n][j] G[m][i]),  M = Jinv Jinv^T
 //   J2            wd J (G[n][j] S_i[m] - G[m][j] S_i[n] + (K - beta 2G/3) G[m][i] Jinv[n][j]
 //                       + beta G (d_ij N[m][n] + G[m][j] Jinv[n][i]) - 2G gamma Ts_i[m] Q[n][j]),
 //                 N = G Jinv^T, Q[n][j] = sum_L s_jL Jinv[n][L], S_i[m] = sum_k sigma_ik G[m][k], Ts_i[m] = sum_k s_ik G[m][k]
-MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult<3>& w, const double* Ji, double wd, double* rec) {
+// the nine values mn of one (i, j) at point `pt`; `blk` = the (i, j) block of the element's record
+MH_DEV void t3_store_block_at(double* blk, int pt, const double (&v)[9]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    t3_d2 two = {v[2 * q], v[2 * q + 1]};
+    T3_REC_STORE(reinterpret_cast<t3_d2*>(blk + q * 2 * T3_PS + 2 * pt), two);
+  }
+  T3_REC_STORE(blk + 8 * T3_PS + pt, v[8]);
+}
+MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult<3>& w, const double* Ji, double wd, double* rec, int pt) {
   constexpr int PS = T3_PS;
   double G[9];
 #pragma unroll
@@ -87,15 +103,18 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int m = 0; m < 3; ++m)
+      for (int j = 0; j < 3; ++j) {
+        double blk[9];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int m = 0; m < 3; ++m)
 #pragma unroll
           for (int n = 0; n < 3; ++n) {
             double v = c2_w * G[m * 3 + i] * G[n * 3 + j] - c1_w * G[m * 3 + j] * G[n * 3 + i];
             if (i == j) v += mu_w * M[m * 3 + n];
-            T3_REC_STORE(&rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS], v);
+            blk[m * 3 + n] = v;
           }
+        t3_store_block_at(rec + t3_rec_block(i, j), pt, blk);
+      }
     return;
   }
   double beta = 1.0, gamma = 0.0;
@@ -145,9 +164,10 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
       KG[m] = Kw * G[m * 3 + i];
     }
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
+    for (int j = 0; j < 3; ++j) {
+      double blk[9];
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
+      for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
           double v = G[n * 3 + j] * S[m];
@@ -156,8 +176,10 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
           v = __builtin_fma(hG[m * 3 + j], Ji[n * 3 + i], v);
           if (i == j) v += hN[m * 3 + n];
           v = __builtin_fma(-Ts[m], Q[n * 3 + j], v);
-          T3_REC_STORE(&rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS], v);
+          blk[m * 3 + n] = v;
         }
+      t3_store_block_at(rec + t3_rec_block(i, j), pt, blk);
+    }
   }
 }
 
@@ -302,7 +324,7 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
       // entries of dP/dF (which, with the material's own working set, spilled 360 registers)
       OtherTangent<3> ot;
       status = other_tangent_begin<3, FK>(p.mat, p.dt, p.state, e * NPT + tid, F, Pk, ot);
-      double* rec = p.scratch_pt + e * (int64_t)(T3_REC * PS) + tid;
+      double* rec = p.scratch_pt + e * (int64_t)(T3_REC * PS);
 #pragma unroll 1
       for (int j = 0; j < 3; ++j) {
         double acc[27];
@@ -327,11 +349,12 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i) {
+          double blk[9];
 #pragma unroll
-          for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int n = 0; n < 3; ++n) T3_REC_STORE(&rec[(int64_t)(i * 27 + (m * 3 + j) * 3 + n) * PS], wd * acc[(i * 3 + m) * 3 + n]);
+          for (int mn = 0; mn < 9; ++mn) blk[mn] = wd * acc[i * 9 + mn];
+          t3_store_block_at(rec + (i * 3 + j) * 9 * T3_PS, tid, blk);     // (j is a loop variable here: t3_rec_block written out)
+        }
       }
     } else if constexpr (FAMILY != 0) {
       status = evaluate_other<3, FK>(p.mat, p.dt, p.state, e * NPT + tid, F, Pk, nullptr, 1.0);
@@ -340,7 +363,7 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
       status = evaluate_pk1<3>(p.mat, p.dt, p.state, e * NPT + tid, F, w);
 #pragma unroll
       for (int k = 0; k < 9; ++k) Pk[k] = w.P[k];
-      if constexpr (GRAD == 1) t3_closed_form_record(p.mat.m, w, Ji, wd, p.scratch_pt + e * (int64_t)(T3_REC * PS) + tid);
+      if constexpr (GRAD == 1) t3_closed_form_record(p.mat.m, w, Ji, wd, p.scratch_pt + e * (int64_t)(T3_REC * PS), tid);
     }
     if (status) atomicOr(p.status, status);
 #pragma unroll
@@ -404,8 +427,6 @@ MH_DEV double t3_low_halves(double a, double b) {
   const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
   return __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]);
 }
-
-typedef double t3_d2 __attribute__((ext_vector_type(2)));
 
 // compile-time loop: the index arrives as a type, so that it can be an immediate of an asm statement
 template<int... Is, class F>
@@ -659,16 +680,16 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
   double aop[9][3], t2[2][4];
   auto request = [&](int es) {
     const int64_t e = e0 + e_step * es;
-    const double* rec = p.scratch_pt + e * (int64_t)(T3_REC * PS) + (int64_t)I * 27 * PS;
+    const double* rec = p.scratch_pt + e * (int64_t)(T3_REC * PS) + (I * 3 + J) * 9 * PS;      // (t3_rec_block)
 #pragma unroll
     for (int mn = 0; mn < 9; ++mn) {
-      const int m = mn / 3, n = mn % 3;
-      const double* f = rec + (int64_t)((m * 3 + J) * 3 + n) * PS;
       // every lane loads a real (finite) value: the lanes that carry no point meet a zero B operand (second k-step)
       // or feed rows of the result that nothing reads
-      aop[mn][0] = f[offU0];
-      aop[mn][1] = f[offX1];
-      aop[mn][2] = f[offV0];
+      const double* f = rec + (mn < 8 ? (mn >> 1) * 2 * PS + (mn & 1) : 8 * PS);
+      const int st = mn < 8 ? 2 : 1;
+      aop[mn][0] = f[st * offU0];
+      aop[mn][1] = f[st * offX1];
+      aop[mn][2] = f[st * offV0];
     }
     const double* B2 = p.tabB[2] + (int64_t)(p.box_begin[2] + es) * NB * NQ;
     const double* D2 = p.tabD[2] + (int64_t)(p.box_begin[2] + es) * NB * NQ;
@@ -868,7 +889,30 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
 // This function computes what the loop needs per lane and per column, hands it over through LDS (the carry area, which
 // the loop zeroes once it has read it: 33 slots of [64 lanes] x 8 bytes) and finishes the column as the C++ form does.
 // ------------------------------------------------------------------------------------------------
-#include "tp3_contract_loop.inc"
+// The eight direction-2 table values a lane of the contraction needs per element -- t2[s][k]: k = 0 B[a2], 1 D[a2], 2 B[b2], 3 D[b2]
+// of the lane's DIAGONAL pair (a2, b2) at q2 = lane >> 4 (s = 0) and q2 = 4 (s = 1) -- depend on (span, lane) only: built
+// once per handle as [span][lane][8], so that the loop fetches them with four 16-byte loads (were eight 8-byte ones).
+__global__ __launch_bounds__(64) void tp3_t2pack_kernel(const double* __restrict__ B2, const double* __restrict__ D2, double* __restrict__ pack) {
+  constexpr int NB = T3_NB, NQ = T3_NQ;
+  const int lane = threadIdx.x, c16 = lane & 15, kk = lane >> 4;
+  const int pa2 = c16 >> 2, pb2 = (pa2 + (c16 & 3)) & 3;
+  const double* B = B2 + (int64_t)blockIdx.x * NB * NQ;
+  const double* D = D2 + (int64_t)blockIdx.x * NB * NQ;
+  double* out = pack + ((int64_t)blockIdx.x * 64 + lane) * 8;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int q = s == 0 ? kk : NQ - 1;
+    out[4 * s + 0] = B[pa2 * NQ + q];
+    out[4 * s + 1] = D[pa2 * NQ + q];
+    out[4 * s + 2] = B[pb2 * NQ + q];
+    out[4 * s + 3] = D[pb2 * NQ + q];
+  }
+}
+
+#ifndef T3_LOOP_INC            // (scratch/p3_asm_variants.sh: a loop generated with other options, for timing experiments)
+#define T3_LOOP_INC "tp3_contract_loop.inc"
+#endif
+#include T3_LOOP_INC
 
 __global__ __launch_bounds__(64) void tp3_contract_asm_kernel(TensorArgs p) {
   constexpr int NB = T3_NB, NQ = T3_NQ, PS = T3_PS;
@@ -880,7 +924,6 @@ __global__ __launch_bounds__(64) void tp3_contract_asm_kernel(TensorArgs p) {
   const int n_seq = p.box_n[2];
   const int64_t e_step = (int64_t)p.box_n[0] * p.box_n[1];
   const int c16 = lane & 15, kk = lane >> 4, pa = c16 >> 2, pb = c16 & 3;
-  const int pa2 = c16 >> 2, pb2 = (pa2 + (c16 & 3)) & 3;   // direction 2: diagonal pair index
   double* par = carry + lane;                              // slot k of this lane: par[k * 64]
   auto put_int = [&](int slot, unsigned v) { *reinterpret_cast<unsigned*>(par + slot * 64) = v; };
   auto put_ptr = [&](int slot, const void* q) { *reinterpret_cast<uint64_t*>(par + slot * 64) = (uint64_t)(uintptr_t)q; };
@@ -921,13 +964,13 @@ __global__ __launch_bounds__(64) void tp3_contract_asm_kernel(TensorArgs p) {
   const int vq1 = c16 < 4 ? 4 : (c16 == 5 ? 3 : (c16 == 9 ? 4 : c16 / 4 - 1));
   const int ptV = vrow ? vq0 + NQ * vq1 : 0;
   const unsigned cl_addr = (unsigned)(uintptr_t)par;   // (the low half of a shared-aperture address is the LDS offset)
-  put_int(T3A_P_INT + 0, 8u * (unsigned)(ptU + NQ * NQ * kk));
-  put_int(T3A_P_INT + 1, 8u * (unsigned)((kk == 1 ? ptV : ptU) + NQ * NQ * (NQ - 1)));
-  put_int(T3A_P_INT + 2, 8u * (unsigned)(ptV + NQ * NQ * kk));
-  put_int(T3A_P_INT + 3, 8u * (unsigned)(pa2 * NQ + kk));
-  put_int(T3A_P_INT + 4, 8u * (unsigned)(pb2 * NQ + kk));
-  put_int(T3A_P_INT + 5, 8u * (unsigned)(pa2 * NQ + NQ - 1));
-  put_int(T3A_P_INT + 6, 8u * (unsigned)(pb2 * NQ + NQ - 1));
+  put_int(T3A_P_INT + 0, 16u * (unsigned)(ptU + NQ * NQ * kk));            // (a pair field holds 16 bytes per point)
+  put_int(T3A_P_INT + 1, 16u * (unsigned)((kk == 1 ? ptV : ptU) + NQ * NQ * (NQ - 1)));
+  put_int(T3A_P_INT + 2, 16u * (unsigned)(ptV + NQ * NQ * kk));
+  put_int(T3A_P_INT + 3, 8u * (unsigned)(ptU + NQ * NQ * kk));             // (the single field mn = 8: 8 bytes per point)
+  put_int(T3A_P_INT + 4, 8u * (unsigned)((kk == 1 ? ptV : ptU) + NQ * NQ * (NQ - 1)));
+  put_int(T3A_P_INT + 5, 8u * (unsigned)(ptV + NQ * NQ * kk));
+  put_int(T3A_P_INT + 6, 64u * (unsigned)lane);                            // this lane's eight table values in tp3_t2pack_kernel's array
   // where this lane reads slot s of a pair's carry: the lane group that stored register s + 1 as final reads the zero slot
   put_int(T3A_P_INT + 7, cl_addr + (kk == 3 ? 3u * 512u : 0u));
   put_int(T3A_P_INT + 8, cl_addr + (kk == 2 ? 2u * 512u : 0u));
@@ -941,12 +984,11 @@ __global__ __launch_bounds__(64) void tp3_contract_asm_kernel(TensorArgs p) {
   put_int(T3A_P_INT + 14, kk == 0 ? 0xffffffffu : 0u);
   put_int(T3A_P_INT + 15, kk == 1 ? 0xffffffffu : 0u);
   const int64_t e0 = eu + (int64_t)p.box_n[0] * ev;
-  put_ptr(T3A_P_REC, p.scratch_pt + e0 * (int64_t)(T3_REC * PS) + (int64_t)(I * 27 + J * 3) * PS);
+  put_ptr(T3A_P_REC, p.scratch_pt + e0 * (int64_t)(T3_REC * PS) + (int64_t)(I * 3 + J) * 9 * PS);      // (t3_rec_block)
   put_i64(T3A_P_RSTRIDE, e_step * (int64_t)(T3_REC * PS) * 8);
   put_ptr(T3A_P_PIECE, p.scratch_k + (e0 * 3 + I) * (int64_t)T3_PIECE);
   put_i64(T3A_P_PSTRIDE, e_step * 3 * (int64_t)T3_PIECE * 8);
-  put_ptr(T3A_P_B2, p.tabB[2] + (int64_t)p.box_begin[2] * NB * NQ);
-  put_ptr(T3A_P_D2, p.tabD[2] + (int64_t)p.box_begin[2] * NB * NQ);
+  put_ptr(T3A_P_B2, p.t2pack + (int64_t)p.box_begin[2] * 64 * 8);
   put_i64(T3A_P_NSEQ, n_seq);
   __syncthreads();
   T3_ASM_LOOP(cl_addr);
@@ -1160,6 +1202,12 @@ void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {
     a.scratch_pt = h->scratch_pt.ptr;
     a.scratch_k = h->scratch_k.ptr;
     a.scratch_tail = h->scratch_tail.ptr;
+    if (!h->t3_t2pack.ptr) {
+      h->t3_t2pack.resize((size_t)h->el_total[2] * 64 * 8);
+      hipLaunchKernelGGL(tp3_t2pack_kernel, dim3((unsigned)h->el_total[2]), dim3(64), 0, h->stream, a.tabB[2], a.tabD[2], h->t3_t2pack.ptr);
+      MH_HIP(hipGetLastError());
+    }
+    a.t2pack = h->t3_t2pack.ptr;
   }
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[0], h->stream));
   if (h->phase_select != 2) {
