@@ -358,20 +358,29 @@ def s3_main(tset):
 
 
 def s3_plane(tset):
-    out = []
-    for a1 in range(NB):
-        out.append(mfma(TILE(tset, a1), v2(E(0, a1)), a2(AB0 + 8), TILE(tset, a1), d_agpr=True))
-        out.append(mfma(TILE(tset, a1), v2(E(2, a1)), a2(AB0 + 10), TILE(tset, a1), d_agpr=True))
-    return out
+    # one instruction per tile: k = lane group = table variant g of direction 0, the A operand holds the plane's sum over q1
+    # of variant g in lane group g (plane_totals); two instructions per tile with the partial sums of two variants each
+    # until round 5
+    return [mfma(TILE(tset, a1), v2(E(0, a1)), a2(AB0 + 8), TILE(tset, a1), d_agpr=True) for a1 in range(NB)]
 
 
-def plane_swaps(o):
-    """Ey[0][a1] = lanes 0..31 of Ex[0][a1] | lanes 0..31 of Ex[1][a1] (in place in E[0][a1]), Ey[1][a1] likewise from
-    Ex[2], Ex[3] (in E[2][a1]).  The pairs (2, 3) first: E[0][*] were written by the last instructions of S2."""
+def plane_totals(o):
+    """The plane q0 = 4 leaves S2 as two partial sums per variant g: lane group 0 holds q1 = 0..2, lane group 1 q1 = 3, 4
+    (lane groups 2, 3 hold zeros).  v_permlane16_swap (rows of 16 lanes: rows 1, 3 of the first operand <-> rows 0, 2 of the
+    second) turns the pair (Ex[g], Ex[g + 1]) into [p0_g, p0_g+1, 0, 0], [p1_g, p1_g+1, 0, 0]; their sum is [t_g, t_g+1, 0, 0];
+    v_permlane32_swap of the two sums gives [t_0, t_1, t_2, t_3]: the A operand of ONE matrix instruction whose k index
+    is the variant -- 4 instead of 8 plane instructions per pair column for 16 more vector instructions (64 cycles each
+    against 5).  In place: the result is in E[0][a1]."""
+    for g in (2, 0):                    # (E[0][*] were written by the last instructions of S2: the pairs (2, 3) first)
+        for a1 in range(NB):
+            o.emit(f"v_permlane16_swap_b32 v{E(g, a1)}, v{E(g + 1, a1)}")
+            o.emit(f"v_permlane16_swap_b32 v{E(g, a1) + 1}, v{E(g + 1, a1) + 1}")
     for g in (2, 0):
         for a1 in range(NB):
-            o.emit(f"v_permlane32_swap_b32 v{E(g, a1)}, v{E(g + 1, a1)}")
-            o.emit(f"v_permlane32_swap_b32 v{E(g, a1) + 1}, v{E(g + 1, a1) + 1}")
+            o.emit(f"v_add_f64 {v2(E(g, a1))}, {v2(E(g, a1))}, {v2(E(g + 1, a1))}")
+    for a1 in range(NB):
+        o.emit(f"v_permlane32_swap_b32 v{E(0, a1)}, v{E(2, a1)}")
+        o.emit(f"v_permlane32_swap_b32 v{E(0, a1) + 1}, v{E(2, a1) + 1}")
 
 
 def bs2_operands(o):
@@ -453,15 +462,16 @@ def generate(opts=None):
     o.emit("s_waitcnt vmcnt(0)")
     o.emit(".Ltp3_loop_%=:")
     # ------------------------------------------------------------ one element
-    # Matrix instruction slots of an element: S1 0..35, then per pair column b1 S3 main 36 + 24 b1 .. + 15 and S3 plane .. + 23.
+    # Matrix instruction slots of an element: S1 0..35, then per pair column b1 S3 main 36 + 20 b1 .. + 15 and S3 plane .. + 19.
     # Everything that is not a vector instruction is dealt out into the shadows behind them: at most `vm_cap` global-memory
     # instructions per shadow (the CU's address unit takes 16 - 21 cycles per wave instruction and is shared by four waves:
     # two stores in one shadow already outlast it -- measured, profiles/r05_cfg3_contract_ablations_v1.txt), `lds_cap` LDS
     # instructions, one group of scalar instructions.
     vm_cap, lds_cap = opts.get("vm_cap", 1), opts.get("lds_cap", 2)
-    n_slot = 36 + 4 * 24
-    m_of = lambda b1: 36 + 24 * b1          # first S3 main slot of pair column b1
-    p_of = lambda b1: 36 + 24 * b1 + 16     # first S3 plane slot
+    NM, NP = 16, 4                          # S3 main / S3 plane matrix instructions per pair column
+    n_slot = 36 + 4 * (NM + NP)
+    m_of = lambda b1: 36 + (NM + NP) * b1          # first S3 main slot of pair column b1
+    p_of = lambda b1: 36 + (NM + NP) * b1 + NM     # first S3 plane slot
     mf = s1_mfmas()
     for b1 in range(4):
         mf += s3_main(b1 & 1) + s3_plane(b1 & 1)
@@ -475,8 +485,8 @@ def generate(opts=None):
 
     # outputs of the previous element's pair column 3 (tile set 1, `prev` bases) -- before tile set 1 is read into again
     for i, x in enumerate(out_store(3, 1, prev=True)):
-        add("vm", i, p_of(0) - 1, [x])
-    add("lds", 0, p_of(0) - 1, carry_out(3, 1))
+        add("vm", i, 35, [x])
+    add("lds", 0, 35, carry_out(3, 1))
     # next element's operands (operand_loads); the tables' registers are free once the B operands are formed
     last_load = opts.get("last_load", m_of(2) - 1)
     load_spread, store_spread = opts.get("load_spread", 1), opts.get("store_spread", 2)
@@ -487,17 +497,18 @@ def generate(opts=None):
     add("sc", last_load + 1, n_slot - 1, advance_operand_bases())
     for b1 in range(4):
         tset = b1 & 1
-        # finals found by the previous plane shadows (waited for at the head of S3 main), this element's (b1 - 1) outputs
-        for i, x in enumerate(finals_store(b1, tset)):
-            add("vm", m_of(b1) + 2 * store_spread * i, m_of(b1) + 15, [x])
+        m, pl = m_of(b1), p_of(b1)
+        # first half of the S3 main shadows: the outputs of pair column b1 - 1 (the other tile set) and the finals the next pair
+        # column will store; second half: this pair column's finals (found by the previous one, waited for at the head of S3
+        # main) and -- once nothing reads the other tile set any more -- the start values of the next pair column's tiles
         if b1 > 0:
             for i, x in enumerate(out_store(b1 - 1, 1 - tset, prev=False)):
-                add("vm", m_of(b1) + 2 * store_spread * i + store_spread, p_of(b1) - 1, [x])
-            add("lds", m_of(b1), p_of(b1) - 1, carry_out(b1 - 1, 1 - tset))
-        # the finals the next pair column's S3 main shadows will store (any time before its head, where they are waited for;
-        # their register set was stored from by pair column b1 - 1) and the start values of its tiles
-        add("lds", m_of(b1), p_of(b1) + 7, finals_in((b1 + 1) % 4, 1 - tset))
-        add("lds", p_of(b1), p_of(b1) + 7, carry_in((b1 + 1) % 4, 1 - tset))
+                add("vm", m + store_spread * i, m + 7, [x])
+            add("lds", m, m + 7, carry_out(b1 - 1, 1 - tset))
+        add("lds", m, m + 7, finals_in((b1 + 1) % 4, 1 - tset))
+        for i, x in enumerate(finals_store(b1, tset)):
+            add("vm", m + 8 + store_spread * i, pl - 1, [x])
+        add("lds", m + 8 if b1 > 0 else m, pl + NP - 1, carry_in((b1 + 1) % 4, 1 - tset))
     add("sc", p_of(3), n_slot - 1, rotate_piece_bases())
     # assignment: slot by slot, per kind the eligible instructions with the earliest deadline first
     cap = {"vm": vm_cap, "lds": lds_cap, "sc": 1}
@@ -519,16 +530,16 @@ def generate(opts=None):
     o.emit(f"s_waitcnt vmcnt({n_vm_after_last_load})")     # this element's operands (vector memory instructions of a wave complete in order on gfx9)
     bs2_operands(o)
     for k, m in enumerate(mf):
-        if k >= 36 and (k - 36) % 24 == 0:
-            b1 = (k - 36) // 24
+        if k >= 36 and (k - 36) % (NM + NP) == 0:
+            b1 = (k - 36) // (NM + NP)
             o.comment(f"pair column b1 = {b1}: S2 (points q0 < 4), S3 main")
             s2_pass(o, b1, plane=False)
             o.emit("s_waitcnt lgkmcnt(0)")
-        if k >= 36 and (k - 36) % 24 == 16:
-            b1 = (k - 36) // 24
+        if k >= 36 and (k - 36) % (NM + NP) == NM:
+            b1 = (k - 36) // (NM + NP)
             o.comment("S2 (plane q0 = 4), S3 plane")
             s2_pass(o, b1, plane=True)
-            plane_swaps(o)
+            plane_totals(o)
         o.emit(m)
         for x in shadow[k]:
             for y in (x if isinstance(x, list) else [x]):

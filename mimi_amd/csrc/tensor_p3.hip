@@ -428,6 +428,18 @@ MH_DEV double t3_low_halves(double a, double b) {
   return __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]);
 }
 
+// rows of 16 lanes r0..r3: a = [a0, a1, a2, a3], b = [b0, b1, b2, b3]  ->  [a0 + a1, b0 + b1, a2 + a3, b2 + b3]
+// (v_permlane16_swap: rows 1, 3 of the first operand <-> rows 0, 2 of the second -- tests/test_tensor_p3_gpu.py pins it
+// through the oracle parity of the whole assembly)
+MH_DEV double t3_row_pair_sums(double a, double b) {
+  const unsigned long long ua = __double_as_longlong(a), ub = __double_as_longlong(b);
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  const double x = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]);
+  const double y = __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+  return x + y;
+}
+
 // compile-time loop: the index arrives as a type, so that it can be an immediate of an asm statement
 template<int... Is, class F>
 MH_DEV void t3_for(std::integer_sequence<int, Is...>, F&& f) {
@@ -460,10 +472,10 @@ MH_DEV void t3_s3_main_0(double (&K)[4], double e0, double e1, double e2, double
                : "+{a[0:1]}"(K[0]), "+{a[2:3]}"(K[1]), "+{a[4:5]}"(K[2]), "+{a[6:7]}"(K[3])
                : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
 }
-MH_DEV void t3_s3_plane_0(double (&K)[4], double e0, double e1, const double (&b)[2]) {
-  asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 a[0:7], %4, %6, a[0:7]\n\tv_mfma_f64_16x16x4_f64 a[0:7], %5, %7, a[0:7]"
+MH_DEV void t3_s3_plane_0(double (&K)[4], double e, double b) {
+  asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 a[0:7], %4, %5, a[0:7]"
                : "+{a[0:1]}"(K[0]), "+{a[2:3]}"(K[1]), "+{a[4:5]}"(K[2]), "+{a[6:7]}"(K[3])
-               : "v"(e0), "v"(e1), "v"(b[0]), "v"(b[1]));
+               : "v"(e), "v"(b));
 }
 template<int B1>
 MH_DEV void t3_carry_in_1(const unsigned (&addr)[4], double (&K)[4]) {   // requests the carry of (1, B1) as the tile's start value (no wait)
@@ -480,10 +492,10 @@ MH_DEV void t3_s3_main_1(double (&K)[4], double e0, double e1, double e2, double
                : "+{a[8:9]}"(K[0]), "+{a[10:11]}"(K[1]), "+{a[12:13]}"(K[2]), "+{a[14:15]}"(K[3])
                : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
 }
-MH_DEV void t3_s3_plane_1(double (&K)[4], double e0, double e1, const double (&b)[2]) {
-  asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 a[8:15], %4, %6, a[8:15]\n\tv_mfma_f64_16x16x4_f64 a[8:15], %5, %7, a[8:15]"
+MH_DEV void t3_s3_plane_1(double (&K)[4], double e, double b) {
+  asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 a[8:15], %4, %5, a[8:15]"
                : "+{a[8:9]}"(K[0]), "+{a[10:11]}"(K[1]), "+{a[12:13]}"(K[2]), "+{a[14:15]}"(K[3])
-               : "v"(e0), "v"(e1), "v"(b[0]), "v"(b[1]));
+               : "v"(e), "v"(b));
 }
 template<int B1>
 MH_DEV void t3_carry_in_2(const unsigned (&addr)[4], double (&K)[4]) {   // requests the carry of (2, B1) as the tile's start value (no wait)
@@ -500,10 +512,10 @@ MH_DEV void t3_s3_main_2(double (&K)[4], double e0, double e1, double e2, double
                : "+{a[16:17]}"(K[0]), "+{a[18:19]}"(K[1]), "+{a[20:21]}"(K[2]), "+{a[22:23]}"(K[3])
                : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
 }
-MH_DEV void t3_s3_plane_2(double (&K)[4], double e0, double e1, const double (&b)[2]) {
-  asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 a[16:23], %4, %6, a[16:23]\n\tv_mfma_f64_16x16x4_f64 a[16:23], %5, %7, a[16:23]"
+MH_DEV void t3_s3_plane_2(double (&K)[4], double e, double b) {
+  asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 a[16:23], %4, %5, a[16:23]"
                : "+{a[16:17]}"(K[0]), "+{a[18:19]}"(K[1]), "+{a[20:21]}"(K[2]), "+{a[22:23]}"(K[3])
-               : "v"(e0), "v"(e1), "v"(b[0]), "v"(b[1]));
+               : "v"(e), "v"(b));
 }
 template<int B1>
 MH_DEV void t3_carry_in_3(const unsigned (&addr)[4], double (&K)[4]) {   // requests the carry of (3, B1) as the tile's start value (no wait)
@@ -520,10 +532,10 @@ MH_DEV void t3_s3_main_3(double (&K)[4], double e0, double e1, double e2, double
                : "+{a[24:25]}"(K[0]), "+{a[26:27]}"(K[1]), "+{a[28:29]}"(K[2]), "+{a[30:31]}"(K[3])
                : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
 }
-MH_DEV void t3_s3_plane_3(double (&K)[4], double e0, double e1, const double (&b)[2]) {
-  asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 a[24:31], %4, %6, a[24:31]\n\tv_mfma_f64_16x16x4_f64 a[24:31], %5, %7, a[24:31]"
+MH_DEV void t3_s3_plane_3(double (&K)[4], double e, double b) {
+  asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 a[24:31], %4, %5, a[24:31]"
                : "+{a[24:25]}"(K[0]), "+{a[26:27]}"(K[1]), "+{a[28:29]}"(K[2]), "+{a[30:31]}"(K[3])
-               : "v"(e0), "v"(e1), "v"(b[0]), "v"(b[1]));
+               : "v"(e), "v"(b));
 }
 // register R (1..3) of the four tiles -> slot R - 1 of their carry (every lane)
 template<int B1, int R>
@@ -602,8 +614,10 @@ MH_DEV void t3_results_guard() { asm volatile("s_nop 15" ::: "memory"); }
 //   two k-steps each: q2 = kk, then q2 = 4 (operand lane group 0 only).
 // S2 runs lane-local on the result registers: the points q0 < 4 with wave-uniform coefficients, the plane q0 = 4
 // with per-lane ones (two partial sums, lane groups 0 and 1).
-// S3, per (a1, b1): one k-step q0 = kk per table variant g, and for the plane q0 = 4 two k-steps that each take the
-// partial sums of two variants (k = 0, 1: variant g, k = 2, 3: variant g + 1, moved there by one v_permlane32_swap pair).
+// S3, per (a1, b1): one k-step q0 = kk per table variant g, and for the plane q0 = 4 ONE k-step whose k index is the variant
+// (round 5: the two partial sums of a variant are added and variant g's total moved to lane group g with a v_permlane16_swap
+// and a v_permlane32_swap pair -- 116 matrix instructions per block; rounds 2-4: two k-steps with the partial sums of two
+// variants each, 132).
 //
 // Piece of (element, i), 5376 doubles -- what phase 2 reads contiguously:
 //   [0, 3072)     rows a2 = 0:  (a0 + 4 a1) 192 + j 64 + b1 16 + b2 4 + b0
@@ -623,7 +637,7 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
   const int pa2 = c16 >> 2, pb2 = (pa2 + (c16 & 3)) & 3;   // direction 2: diagonal pair index
 
   // direction 0 (S3 B operands): variants (a: B / D) + 2 (b: B / D); k-step 0: q0 = kk; the plane q0 = 4: variants 0 | 1 and 2 | 3
-  double bS0[4], bS0x[2];
+  double bS0[4], bS0y;
   {
     const double* B0 = p.tabB[0] + (int64_t)(p.box_begin[0] + eu) * NB * NQ;
     const double* D0 = p.tabD[0] + (int64_t)(p.box_begin[0] + eu) * NB * NQ;
@@ -631,8 +645,7 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
     const double Bax = B0[pa * NQ + 4], Dax = D0[pa * NQ + 4], Bbx = B0[pb * NQ + 4], Dbx = D0[pb * NQ + 4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) bS0[v] = ((v & 1) ? Da : Ba) * ((v & 2) ? Db : Bb);
-    bS0x[0] = kk < 2 ? Bax * Bbx : Dax * Bbx;
-    bS0x[1] = kk < 2 ? Bax * Dbx : Dax * Dbx;
+    bS0y = ((kk & 1) ? Dax : Bax) * ((kk & 2) ? Dbx : Bbx);     // the plane q0 = 4: k = lane group = variant
   }
   // direction 1 (S2 coefficients): table rows [q1][B, D][a] in LDS, q1 = 0..4 and a row of zeros.  The points q0 < 4 read
   // row q1 = slot (the same for every lane); for the plane q0 = 4 register r = 1..3 of tile V holds q1 = r - 1 in lane
@@ -829,17 +842,17 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       {
         double Ex[4][NB];
         s2(std::true_type{}, Ex);
-        double Ey[2][NB];
+        // the plane's two partial sums per variant (lane groups 0 and 1) added, variant g's total moved to lane group g:
+        // ONE matrix instruction per tile (k = variant) instead of two (round 5; see gen_tp3_contract.py plane_totals)
+        double Ey[NB];
 #pragma unroll
-        for (int a1 = 0; a1 < NB; ++a1) {
-          Ey[0][a1] = t3_low_halves(Ex[0][a1], Ex[1][a1]);
-          Ey[1][a1] = t3_low_halves(Ex[2][a1], Ex[3][a1]);
-        }
+        for (int a1 = 0; a1 < NB; ++a1)
+          Ey[a1] = t3_low_halves(t3_row_pair_sums(Ex[0][a1], Ex[1][a1]), t3_row_pair_sums(Ex[2][a1], Ex[3][a1]));
         __builtin_amdgcn_sched_barrier(0);
-        t3_s3_plane_0(K0, Ey[0][0], Ey[1][0], bS0x);
-        t3_s3_plane_1(K1, Ey[0][1], Ey[1][1], bS0x);
-        t3_s3_plane_2(K2, Ey[0][2], Ey[1][2], bS0x);
-        t3_s3_plane_3(K3, Ey[0][3], Ey[1][3], bS0x);
+        t3_s3_plane_0(K0, Ey[0], bS0y);
+        t3_s3_plane_1(K1, Ey[1], bS0y);
+        t3_s3_plane_2(K2, Ey[2], bS0y);
+        t3_s3_plane_3(K3, Ey[3], bS0y);
         t3_results_guard();
       }
       // register r of this lane: (a2 = r, b2 = (r + kk) & 3), column (a0 = pa, b0 = pb).  Final: a2 = 0 (register 0, every
@@ -937,8 +950,8 @@ __global__ __launch_bounds__(64) void tp3_contract_asm_kernel(TensorArgs p) {
     const double Bax = B0[pa * NQ + 4], Dax = D0[pa * NQ + 4], Bbx = B0[pb * NQ + 4], Dbx = D0[pb * NQ + 4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) par[(T3A_P_BS0 + v) * 64] = ((v & 1) ? Da : Ba) * ((v & 2) ? Db : Bb);
-    par[(T3A_P_BS0X + 0) * 64] = kk < 2 ? Bax * Bbx : Dax * Bbx;
-    par[(T3A_P_BS0X + 1) * 64] = kk < 2 ? Bax * Dbx : Dax * Dbx;
+    par[(T3A_P_BS0X + 0) * 64] = ((kk & 1) ? Dax : Bax) * ((kk & 2) ? Dbx : Bbx);     // the plane q0 = 4: k = lane group = variant
+    par[(T3A_P_BS0X + 1) * 64] = 0.0;
   }
   // direction 1 (S2 coefficients) through the LDS table behind the carry, as in tp3_contract_kernel
   double* tl = carry + 16 * 4 * 64;

@@ -32,7 +32,7 @@ def test_requirements_read_back_from_the_compiler(need):
 
 def test_degree3_contraction_kernel_is_hazard_free_and_spill_free(need):
     (bad, stats), = L.report("tensor_p3.hip", ["tp3_contract_kernel"], need, asm_only=True).values()
-    assert stats["mfma"] == 132 and stats["mfma_from_asm"] == 132          # (all of them hand-placed)
+    assert stats["mfma"] == 116 and stats["mfma_from_asm"] == 116          # (all of them hand-placed)
     assert not bad, "\n".join(f"{w}: {d} < {r}\n  {a}\n  {b}" for a, b, d, r, w in bad[:10])
     assert stats["vgpr_spill_count"] == 0
     # the margins of the shipped schedule (informative: a change here is a change of the schedule, not yet a hazard)
