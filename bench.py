@@ -85,7 +85,7 @@ def kernel_sources_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mimi_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f in ("krylov.hip", "contact.hip", "exchange.hip"):
+        if f in ("krylov.hip", "contact.hip", "exchange.hip") or not os.path.isfile(os.path.join(d, f)):
             continue
         with open(os.path.join(d, f), "rb") as fh:
             h.update(f.encode())
@@ -463,12 +463,25 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
 
     dev = torch.device("cuda", local_rank)
     n_el, p, material = WORKLOADS[workload]
-    patch = mimi_amd.BSplinePatch.block(n_el, p)
-    shard = parallel.SlabShard(patch, None, rank, world)
-    # N > 1: each rank holds the row slice of the nodes its slab touches, not the whole patch's value array
-    pattern = CSRPattern.of_bspline_patch(patch, device=local_rank, on_device=True,
-                                          node_box=shard.node_box() if world > 1 else None)
-    shard.pattern = pattern
+    t_setup = time.perf_counter()
+    free0, _total = torch.cuda.mem_get_info(dev)
+    if world > 1:
+        # N > 1 (round 5): every rank holds its slab and p ghost layers either side as a patch of its OWN -- u, r, the matrix (the
+        # local patch's whole structured pattern), the material state and the handle's set-up are of local size; nothing
+        # of whole-patch size is built on the host or the device (parallel.SlabShard.localized)
+        from mimi_amd.splines import PatchShape
+        whole_shape = PatchShape.block(n_el, p)
+        shard_g = parallel.SlabShard(whole_shape, None, rank, world)
+        below, above = shard_g.ghost_layers()
+        gb, ge = shard_g.element_box
+        patch = mimi_amd.BSplinePatch.block_slab(n_el, p, shard_g.axis, gb[shard_g.axis] - below, ge[shard_g.axis] + above)
+        pattern = CSRPattern.of_bspline_patch(patch, device=local_rank, on_device=True)
+        shard = shard_g.localized(patch, pattern, ghost=(below, above))
+    else:
+        whole_shape = patch = mimi_amd.BSplinePatch.block(n_el, p)
+        shard = parallel.SlabShard(patch, None, rank, world)
+        pattern = CSRPattern.of_bspline_patch(patch, device=local_rank, on_device=True)
+        shard.pattern = pattern
     # a non-default stream: the library launches on it and the events below are recorded on it
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
@@ -492,7 +505,12 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
     scheme = "none"
     if world > 1 and not args.residual_only:
         scheme = args.scheme
-    u = torch.from_numpy(synthetic_u(patch, scale=0.01 if workload == "cfg4" else 0.05)).to(dev)
+    u_whole = synthetic_u(whole_shape, scale=0.01 if workload == "cfg4" else 0.05)     # (the workload's u: same numbers at every N)
+    if world > 1:
+        gnodes = shard.global_nodes()
+        u_whole = np.ascontiguousarray(u_whole.reshape(-1, patch.dim)[gnodes].reshape(-1))
+    u = torch.from_numpy(u_whole).to(dev)
+    del u_whole
     integ = None
     if scheme == "gather":
         integ = make_integrator(shard.element_box)
@@ -522,13 +540,13 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
     contact = None
     if workload == "cfg4":
         from mimi_amd.integrators import RigidSphere
-        L = patch.control_points.max(axis=0)
+        L = np.asarray(n_el, dtype=np.float64)             # (unit cells: the block's extent)
         R = 0.25 * L[0]
         c = 0.5 * L
         c[2] = L[2] + 0.9 * R
         body = RigidSphere(list(c), R, 1e4)
         if world > 1:
-            contact = parallel.ShardedContact(shard, body, pattern, 2, 1, device=local_rank)
+            contact = parallel.ShardedContact(shard, body, pattern, 2, 1, device=local_rank, loopback=loopback)
         else:
             from mimi_amd.integrators import MortarContact
             contact = MortarContact(body, "contact", pattern, patch, 2, 1, device=local_rank).Prepare()
@@ -579,6 +597,8 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
                     exchange.sum_residual_and_grad()
 
     steps, warmup = args.steps, args.warmup
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -614,37 +634,43 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
         torch.cuda.synchronize()
 
         def compare():
-            full = CSRPattern.of_bspline_patch(patch, device=local_rank, on_device=True)
-            whole = NonlinearSolid("domain", make_material(material), full, patch=patch, device=local_rank).Prepare()
+            gpatch = mimi_amd.BSplinePatch.block(n_el, p)
+            full = CSRPattern.of_bspline_patch(gpatch, device=local_rank, on_device=True)
+            whole = NonlinearSolid("domain", make_material(material), full, patch=gpatch, device=local_rank).Prepare()
             whole.dt_ = 0.5
             whole.SetStream(stream.cuda_stream)
-            r_w = torch.zeros_like(r)
+            u_w = torch.from_numpy(synthetic_u(gpatch, scale=0.01 if workload == "cfg4" else 0.05)).to(dev)
+            r_w = torch.zeros(gpatch.n_vdofs, dtype=torch.float64, device=dev)
             A_w = torch.zeros(full.nnz, dtype=torch.float64, device=dev)
-            whole.AddDomainResidualAndGrad(u, 1.0, r_w, A_w)
+            whole.AddDomainResidualAndGrad(u_w, 1.0, r_w, A_w)
             if contact:
                 from mimi_amd.integrators import MortarContact
-                whole_c = MortarContact(contact.body_, "contact", full, patch, 2, 1, device=local_rank).Prepare()
+                whole_c = MortarContact(contact.body_, "contact", full, gpatch, 2, 1, device=local_rank).Prepare()
                 whole_c.SetStream(stream.cuda_stream)
-                whole_c.AddBoundaryResidualAndGrad(u, 1.0, r_w, A_w)
+                whole_c.AddBoundaryResidualAndGrad(u_w, 1.0, r_w, A_w)
                 whole_c.Synchronize()
             whole.Synchronize()
             torch.cuda.synchronize()
+            # the rows this rank owns: local rows and the whole patch's rows of the same nodes (an owned row is complete in
+            # its columns on this rank -- the ghost layers -- so the two runs have the same length and order)
             planes = torch.tensor(exchange.owned_node_planes(), device=dev)
             mi_axis = torch.from_numpy(patch.node_multi_index()[shard.axis]).to(dev)
             nodes = torch.nonzero(torch.isin(mi_axis, planes)).reshape(-1)
+            gn = torch.from_numpy(shard.global_nodes()).to(dev)
             rows = (nodes[:, None] * 3 + torch.arange(3, device=dev)[None, :]).reshape(-1)
-            er = float((r[rows] - r_w[rows]).abs().max() / r_w.abs().max())
+            grows = (gn[nodes][:, None] * 3 + torch.arange(3, device=dev)[None, :]).reshape(-1)
+            er = float((r[rows] - r_w[grows]).abs().max() / r_w.abs().max())
 
-            def positions(rowptr):
-                # positions in a value array of all entries of `rows`, row after row
-                start = rowptr[rows]
-                length = rowptr[rows + 1] - start
+            def positions(rowptr, which):
+                # positions in a value array of all entries of the rows `which`, row after row
+                start = rowptr[which]
+                length = rowptr[which + 1] - start
                 offs = torch.cumsum(length, 0) - length
                 return torch.repeat_interleave(start - offs, length) + torch.arange(int(length.sum()), device=dev)
 
-            mine, ref = positions(pattern.rowptr), positions(full.rowptr)
+            mine, ref = positions(pattern.rowptr, rows), positions(full.rowptr, grows)
             if mine.numel() != ref.numel() or mine.numel() == 0:
-                raise RuntimeError("owned rows of the sliced and the whole pattern differ")
+                raise RuntimeError("owned rows of the local and the whole pattern differ")
             return er, float((A[mine] - A_w[ref]).abs().max() / A_w.abs().max())
 
         failed = ""
@@ -705,7 +731,7 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
 
     result = None
     if rank == 0 or loopback:
-        n_elements = patch.n_elements
+        n_elements = whole_shape.n_elements
         grad = not args.residual_only
         stateful = material not in ("neohookean", "stvk")
         balg = b_alg(patch.dim, p, grad=grad, stateful=stateful)
@@ -717,8 +743,9 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
             config={"workload": f"{'x'.join(map(str, n_el))} p={p} {material} B-spline block, "
                                 f"{n_elements} elements, n_q={(p + 2) ** patch.dim}, nnz={pattern.nnz}",
                     "name": workload,
-                    "parallelism": f"element slabs x{world}" + (", interface rows summed on their owner rank; every rank holds "
-                                   "its row slice of the matrix values, a full-length residual vector and a replica of u"
+                    "parallelism": f"element slabs x{world}" + (", interface rows summed on their owner rank; every rank holds its "
+                                   "slab and p ghost element layers either side as a patch of its own: u, r, matrix, state "
+                                   f"and set-up of local size ({patch.n_vdofs} of {whole_shape.n_vdofs} dofs, {pattern.nnz} stored entries)"
                                    if world > 1 else "")
                                    + (", exchange overlapped with the interior elements" if boundary else "")
                                    + (", rows that leave the rank gathered first and sent while the others are gathered"
@@ -741,6 +768,13 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
                        "how": "HIP events recorded by the library on the launch stream around the kernels of each phase, "
                               "mean of 5 assemblies after the timed region"}},
             check=check)
+        import resource
+        free1, _total = torch.cuda.mem_get_info(dev)
+        result["rank_footprint"] = {"setup_s": setup_s, "host_peak_rss_gib": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20,
+                                    "device_gib_in_use_after_the_run": (free0 - free1) / 2 ** 30,
+                                    "torch_peak_allocated_gib": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+                                    "what": "this rank: seconds from the first patch object to the first step; peak resident host "
+                                            "memory of the process; device memory in use (library + torch) after the timed run"}
         if pmc and pmc.get("pipe"):
             result["fp64_pipe"] = {"per_kernel": pmc["pipe"], "source": pmc["traffic_source"],
                                    "note": "rocprofv3 PMC per kernel (recorded, not live): mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES over "
@@ -827,8 +861,8 @@ def run_rank(args):
 
     if args.rehearse_rccl:
         # one slab of an N-rank job on this one GPU, exchange over a one-rank RCCL communicator (sends to itself)
-        if world != 1 or args.workload == "cfg4":
-            raise SystemExit("--rehearse-rccl: one process, domain workloads only")
+        if world != 1:
+            raise SystemExit("--rehearse-rccl: one process")
         n_fake = args.rehearse_rccl
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(_free_port()))
@@ -840,7 +874,7 @@ def run_rank(args):
                             "rate IF every rank took this long -- not a measurement of an N-GPU run",
                "value": res["value"], "unit": "element-integrations/s", "n_gpus": 1, "ranks_rehearsed": n_fake,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "config": res["config"],
-               "elements_on_this_rank": res["roofline"]["elements_per_launch"]}
+               "elements_on_this_rank": res["roofline"]["elements_per_launch"], "rank_footprint": res.get("rank_footprint")}
         _emit(json_fd, out)
         dist.destroy_process_group()
         return

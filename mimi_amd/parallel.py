@@ -43,6 +43,28 @@ class SlabShard:
         self.element_box = (begin, end)
         self.n_local_elements = int(np.prod([end[d] - begin[d] for d in range(patch.dim)]))
 
+    def ghost_layers(self):
+        """(below, above): element layers of the neighbours a localized slab carries along -- p on either side (none at an end
+        of the patch).  The rows of node plane n hold columns of the planes n - p .. n + p; the rows that travel are those
+        of the shared planes [e, e + p) between the slabs [b, e) and [e, ...): with p ghost layers the local patches of
+        BOTH sides contain every column of every shared row, in the same (lexicographic) order -- so a row is the same run
+        of values on either side and the exchange packs / unpacks whole rows (csrc/exchange.hip) exactly as with global
+        row slices -- and the rows a rank owns after the exchange are complete in their columns."""
+        p = self.patch.degrees[self.axis]
+        b, e = self.element_box[0][self.axis], self.element_box[1][self.axis]
+        total = int(self.patch.n_spans[self.axis])
+        return (min(p, b) if self.rank > 0 else 0), (min(p, total - e) if self.rank < self.world_size - 1 else 0)
+
+    def localized(self, local_patch, pattern=None, ghost=(0, 0)):
+        """This rank's slab as a patch of its OWN (round 5): `local_patch` holds the slab's element layers and `ghost`
+        = ghost_layers() more on either side (BSplinePatch.block_slab(n_el, p, axis, b - below, e + above), or any patch cut
+        the same way); the handle integrates the slab's own layers (element_box of the returned shard).  Vectors, CSR rows
+        and columns, material state and the handle's set-up are then of LOCAL size -- u and r over the node planes of the
+        slab and its halo, the matrix = the structured pattern of the local patch -- instead of whole-patch vectors and a row
+        slice of the whole pattern.  Returns the shard in local coordinates: InterfaceExchange, gather_windows and
+        overlap_boxes work on it unchanged; global_nodes() maps back."""
+        return LocalSlabShard(self, local_patch, pattern, ghost)
+
     def node_box(self):
         """(begin, end) of the nodes this slab's elements touch: the rows a rank has to hold
         (CSRPattern.of_bspline_patch(..., node_box=...) builds exactly that row slice of the pattern)."""
@@ -112,6 +134,46 @@ class SlabShard:
         planes = self.interface_node_planes(neighbour)
         mi = self.patch.node_multi_index()
         return np.nonzero(np.isin(mi[self.axis], planes))[0]
+
+
+class LocalSlabShard(SlabShard):
+    """SlabShard.localized: the same slab, seen from a patch that consists of it and its ghost layers alone."""
+
+    def __init__(self, parent, local_patch, pattern=None, ghost=(0, 0)):
+        ax = parent.axis
+        b, e = parent.element_box
+        n_own = e[ax] - b[ax]
+        below, above = int(ghost[0]), int(ghost[1])
+        if local_patch.n_spans[ax] != below + n_own + above or any(local_patch.n_spans[d] != parent.patch.n_spans[d]
+                                                                    for d in range(parent.patch.dim) if d != ax):
+            raise RuntimeError(f"local patch has {local_patch.n_spans} spans; the slab has {n_own} layers along axis {ax} and "
+                               f"{below} + {above} ghost layers")
+        self.parent = parent
+        self.patch, self.pattern = local_patch, pattern
+        self.rank, self.world_size, self.axis = parent.rank, parent.world_size, ax
+        self.ghost = (below, above)
+        self.origin = int(b[ax]) - below               # first element layer = first node plane of the local patch, global
+        self.starts = parent.starts - self.origin      # (entries rank, rank + 1 are what the methods read: below, below + n_own)
+        begin, end = [0, 0, 0], [1, 1, 1]
+        for d in range(local_patch.dim):
+            end[d] = int(local_patch.n_spans[d])
+        begin[ax], end[ax] = below, below + n_own
+        self.element_box = (begin, end)
+        self.n_local_elements = parent.n_local_elements
+
+    def global_nodes(self):
+        """global (whole-patch, lexicographic) id of every local node, in local order"""
+        g = self.parent.patch
+        mi = self.patch.node_multi_index()
+        out = np.zeros(self.patch.n_nodes, dtype=np.int64)
+        stride = 1
+        for d in range(g.dim):
+            out += (mi[d] + (self.origin if d == self.axis else 0)) * stride
+            stride *= g.n_ctrl[d]
+        return out
+
+    def global_planes(self, local_planes):
+        return [int(k) + self.origin for k in local_planes]
 
 
 class _RowRuns:
@@ -372,7 +434,7 @@ class ShardedContact:
     formed -- a small all-reduce over the nodes of the contact face (two doubles per node); the residual / Jacobian rows
     then travel with the domain integrator's InterfaceExchange like any other contribution."""
 
-    def __init__(self, shard, body, pattern, axis, side, device=0, quadrature_order=-1, name="contact"):
+    def __init__(self, shard, body, pattern, axis, side, device=0, quadrature_order=-1, name="contact", loopback=False):
         import torch
         import torch.distributed as dist
         from .integrators import MortarContact
@@ -381,13 +443,18 @@ class ShardedContact:
         self.body_ = body
         patch = shard.patch
         self.contact = None
+        local = isinstance(shard, LocalSlabShard)
+        # (a localized slab is a patch of its own: its end along the sharding axis is the patch face only on the first / last rank)
+        has_face = not local or axis != shard.axis or (shard.rank == (0 if side == 0 else shard.world_size - 1))
         try:
-            self.contact = MortarContact(body, name, pattern, patch, axis, side, device=device,
-                                         quadrature_order=quadrature_order, element_box=shard.element_box).Prepare()
+            if has_face:
+                self.contact = MortarContact(body, name, pattern, patch, axis, side, device=device,
+                                             quadrature_order=quadrature_order, element_box=shard.element_box).Prepare()
         except RuntimeError as e:                      # this slab does not touch the contact face
             if "no marked boundary faces" not in str(e):
                 raise
-        face_nodes = patch.boundary_nodes(axis, side)                 # sorted global node ids of the whole face
+        # sorted global node ids of the whole face (the slots of the nodal sum over the ranks)
+        face_nodes = (shard.parent.patch if local else patch).boundary_nodes(axis, side)
         self.n_face = len(face_nodes)
         backend = dist.get_backend() if dist.is_initialized() else None
         self.comm_device = torch.device("cuda", device) if backend == "nccl" else torch.device("cpu")
@@ -403,9 +470,14 @@ class ShardedContact:
             self.group_size = len(ranks)
             if 1 < len(ranks) < dist.get_world_size():
                 self.group = dist.new_group(ranks)              # (collective: every rank calls it with the same list)
+        if loopback and self.group_size == 1:
+            self.group_size = 2          # (one-rank rehearsal: the nodal sum runs over the one-rank communicator, to itself)
         if self.contact is not None:
             n = len(self.contact.MarkedNodes())
-            self.slot = torch.from_numpy(np.searchsorted(face_nodes, self.contact.MarkedNodes()).astype(np.int64)).to(self.comm_device)
+            marked = np.asarray(self.contact.MarkedNodes())
+            if local:
+                marked = shard.global_nodes()[marked]
+            self.slot = torch.from_numpy(np.searchsorted(face_nodes, marked).astype(np.int64)).to(self.comm_device)
             # persistent buffers: the step allocates nothing and -- with RCCL -- never waits on the host
             self.buf = torch.zeros(2, self.n_face, dtype=torch.float64, device=self.comm_device)
             self.nodal = torch.empty(2, n, dtype=torch.float64, device=self.device)

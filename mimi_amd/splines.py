@@ -47,6 +47,34 @@ class BSplinePatch:
             pts[..., d] = grev[d].reshape(shape)
         return cls(degrees, knots, pts.reshape(-1, dim))
 
+    @classmethod
+    def block_slab(cls, n_el, degree, axis, begin, end, lengths=None):
+        """The element layers [begin, end) along `axis` of block(n_el, degree, lengths) as a patch of its OWN: what one rank
+        of a multi-GPU job holds (parallel.SlabShard.localized).  B-splines depend on their own knots only, so the patch
+        with the knot slice k[begin : end + 2 p + 1] along `axis` (not an open knot vector at a cut) has exactly the
+        basis functions of the whole block that live on those layers -- same knot values, hence the same tables to the
+        bit -- on the node planes [begin, end + p); its control points are those planes' Greville points.  Nothing of
+        whole-block size is built."""
+        dim = len(n_el)
+        degrees = [degree] * dim if np.isscalar(degree) else list(degree)
+        lengths = [float(m) for m in n_el] if lengths is None else [float(x) for x in lengths]
+        knots, grev = [], []
+        for d, (m, p, L) in enumerate(zip(n_el, degrees, lengths)):
+            k = np.concatenate([np.zeros(p), np.arange(m + 1) / m, np.ones(p)])
+            n = len(k) - p - 1
+            g = L * np.array([k[i + 1:i + p + 1].sum() / p for i in range(n)])
+            if d == axis:
+                k = k[begin:end + 2 * p + 1]
+                g = g[begin:end + p]
+            knots.append(k)
+            grev.append(g)
+        pts = np.zeros([len(g) for g in grev][::-1] + [dim])
+        for d in range(dim):
+            shape = [1] * dim
+            shape[dim - 1 - d] = -1
+            pts[..., d] = grev[d].reshape(shape)
+        return cls(degrees, knots, pts.reshape(-1, dim))
+
     def node_multi_index(self, nodes=None):
         idx = np.arange(self.n_nodes) if nodes is None else np.asarray(nodes)
         out = []
@@ -73,6 +101,28 @@ class BSplinePatch:
             end[d] = self.n_spans[d]
         begin[axis], end[axis] = b, e
         return begin, end
+
+
+class PatchShape:
+    """The index space of a patch without its control net: what SlabShard needs to cut slabs (dim, degrees, spans and
+    control points per direction).  PatchShape.block(n_el, p) describes BSplinePatch.block(n_el, p)."""
+
+    def __init__(self, degrees, n_spans):
+        self.dim = len(degrees)
+        self.degrees = [int(p) for p in degrees]
+        self.n_spans = [int(m) for m in n_spans]
+        self.n_ctrl = [m + p for m, p in zip(self.n_spans, self.degrees)]
+        self.n_nodes = int(np.prod(self.n_ctrl))
+        self.n_elements = int(np.prod(self.n_spans))
+        self.n_vdofs = self.n_nodes * self.dim
+
+    @classmethod
+    def block(cls, n_el, degree):
+        dim = len(n_el)
+        return cls([degree] * dim if np.isscalar(degree) else list(degree), n_el)
+
+    node_multi_index = BSplinePatch.node_multi_index
+    boundary_nodes = BSplinePatch.boundary_nodes
 
 
 # ---- boundary (face) tables for the contact integrator ---------------------------------

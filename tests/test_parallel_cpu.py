@@ -85,6 +85,80 @@ def _worker(rank, world, port, n_el, p, mode, q, sliced=False):
         dist.destroy_process_group()
 
 
+def _worker_local(rank, world, port, n_el, p, mode, q):
+    """the LOCAL layout (round 5; parallel.SlabShard.localized): every rank holds a patch that consists of its slab alone --
+    u, r of local length, the whole structured matrix of the local patch -- and the interface exchange runs in local
+    coordinates.  The oracle integrates the LOCAL patch (the data source) and, as the checker, the whole one."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mimi_amd
+        from mimi_amd import parallel
+        from mimi_amd.integrators import CSRPattern
+        from mimi_amd.splines import PatchShape
+        from oracle import iga, ref_path as rp
+        from _cases import oracle_material, synthetic_u
+        shard_g = parallel.SlabShard(PatchShape.block(n_el, p), None, rank, world)
+        b, e = shard_g.element_box
+        ax = shard_g.axis
+        below, above = shard_g.ghost_layers()
+        lp = mimi_amd.BSplinePatch.block_slab(n_el, p, ax, b[ax] - below, e[ax] + above)
+        P_loc = iga.Patch(lp.degrees, lp.knots, lp.control_points)         # the oracle on the local patch
+        assert P_loc.n_nodes == lp.n_nodes
+        rowptr, col = P_loc.sparsity()
+        shard = shard_g.localized(lp, CSRPattern(rowptr, col, rowptr[-1]), ghost=(below, above))
+        em = P_loc.element_multi_index()
+        own = np.nonzero((em[ax] >= shard.element_box[0][ax]) & (em[ax] < shard.element_box[1][ax]))[0]
+        assert len(own) == shard_g.n_local_elements
+        gn = shard.global_nodes()
+        P = iga.Patch.block(n_el, p)                                        # (the checker's whole patch)
+        assert np.allclose(P.ctrl[gn], lp.control_points, atol=1e-14, rtol=0)
+        u = synthetic_u(P)
+        dim = P.dim
+        gdofs = (gn[:, None] * dim + np.arange(dim)[None, :]).ravel()
+        u_loc = np.ascontiguousarray(u[gdofs])
+        D = rp.DomainOracle(P_loc, oracle_material("neohook"), elements=own)        # (the ghost layers are the neighbours')
+        r = np.zeros(P_loc.n_vdofs)
+        A = np.zeros(D.nnz)
+        D.add_domain_residual_and_grad(u_loc, 1.0, r, A, rp.TANGENT_EXACT)
+        tr, tA = torch.from_numpy(r), torch.from_numpy(A)
+        ex = parallel.InterfaceExchange(shard, tr, tA, mode=mode)
+        ex.sum_residual_and_grad()
+        Dfull = rp.DomainOracle(P, oracle_material("neohook"))
+        rf = np.zeros(P.n_vdofs)
+        Af = np.zeros(Dfull.nnz)
+        Dfull.add_domain_residual_and_grad(u, 1.0, rf, Af, rp.TANGENT_EXACT)
+        frowptr, fcol = P.sparsity()
+        # rows this rank owns after the exchange, local -> global
+        mi_axis = lp.node_multi_index()[ax]
+        owned = np.nonzero(np.isin(mi_axis, ex.owned_node_planes()))[0]
+        ok = True
+        local_of = -np.ones(P.n_nodes, dtype=np.int64)
+        local_of[gn] = np.arange(len(gn))
+        for node in owned:
+            for i in range(dim):
+                lrow, grow = node * dim + i, gn[node] * dim + i
+                ok = ok and np.isclose(r[lrow], rf[grow], rtol=1e-12, atol=1e-12)
+                ls, lt = rowptr[lrow], rowptr[lrow + 1]
+                s, t = frowptr[grow], frowptr[grow + 1]
+                # an owned row is COMPLETE on this rank, columns included: the ghost layers make room for them
+                gc = fcol[s:t]
+                lc = local_of[gc // dim] * dim + gc % dim
+                ok = ok and np.all(local_of[gc // dim] >= 0)
+                ok = ok and np.array_equal(lc, col[ls:lt]) and np.allclose(A[ls:lt], Af[s:t], rtol=1e-12, atol=1e-10)
+        q.put((rank, bool(ok), len(own), len(owned)))
+    except Exception as exc:  # pragma: no cover
+        import traceback
+        q.put((rank, False, repr(exc) + traceback.format_exc(), 0))
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -92,12 +166,15 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def _run(world, n_el, p, mode, sliced):
+def _run(world, n_el, p, mode, sliced, local=False):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_el, p, mode, q, sliced)) for r in range(world)]
+    if local:
+        procs = [ctx.Process(target=_worker_local, args=(r, world, port, n_el, p, mode, q)) for r in range(world)]
+    else:
+        procs = [ctx.Process(target=_worker, args=(r, world, port, n_el, p, mode, q, sliced)) for r in range(world)]
     for pr in procs:
         pr.start()
     try:
@@ -126,6 +203,47 @@ def test_interface_exchange_gloo(world, n_el, p, mode):
 def test_interface_exchange_gloo_row_slices(world, n_el, p, mode):
     """each rank holds only its row slice of the matrix (what bench.py does for N > 1)"""
     _run(world, n_el, p, mode, True)
+
+
+@pytest.mark.parametrize("world,n_el,p,mode", [(2, (3, 2, 6), 2, "owner"), (3, (2, 9), 3, "owner"), (3, (3, 7, 2), 2, "replicate"),
+                                               (2, (4, 5, 3), 1, "owner")])
+def test_interface_exchange_gloo_local_layout(world, n_el, p, mode):
+    """every rank holds its slab as a patch of its own: vectors of local length, the local patch's whole matrix
+    (what bench.py does for N > 1 since round 5)"""
+    _run(world, n_el, p, mode, False, local=True)
+
+
+def test_local_slab_patch_has_the_whole_patch_tables_and_points():
+    """BSplinePatch.block_slab: the knot slice of a slab gives the whole block's basis functions on those layers (the oracle's
+    1-D tables of the local patch are the rows of the whole patch's tables, to the bit) and the control points of its
+    node planes; LocalSlabShard maps local nodes to global ones."""
+    import mimi_amd
+    from mimi_amd import parallel
+    from mimi_amd.splines import PatchShape
+    from oracle import iga
+    n_el, p = (3, 7, 2), 3
+    whole = mimi_amd.BSplinePatch.block(n_el, p)
+    Pw = iga.Patch.block(n_el, p)
+    Bw, Dw, Ww, _ = Pw.tables_1d()
+    seen = np.zeros(whole.n_nodes, dtype=int)
+    for rank in range(2):
+        g = parallel.SlabShard(PatchShape.block(n_el, p), None, rank, 2)
+        b, e = g.element_box
+        assert g.ghost_layers() == ((0, 3) if rank == 0 else (3, 0))
+        lp = mimi_amd.BSplinePatch.block_slab(n_el, p, g.axis, b[g.axis], e[g.axis])
+        loc = g.localized(lp)
+        gn = loc.global_nodes()
+        assert np.array_equal(lp.control_points, whole.control_points[gn])
+        seen[gn] += 1
+        Pl = iga.Patch(lp.degrees, lp.knots, lp.control_points)
+        Bl, Dl, Wl, _ = Pl.tables_1d()
+        for d in range(3):
+            sl = slice(b[d], e[d]) if d == g.axis else slice(None)
+            # (the oracle's recursion is not the library's: rounding-level agreement here; the library's own tables are
+            # held to the bit through the assembled values, tests/test_parallel_gpu.py)
+            assert np.allclose(Bl[d], Bw[d][sl], rtol=0, atol=1e-14) and np.allclose(Dl[d], Dw[d][sl], rtol=0, atol=1e-13)
+        assert loc.interface_node_planes(1 - rank) == ([e[g.axis] - b[g.axis] + k for k in range(p)] if rank == 0 else list(range(p)))
+    assert seen.min() == 1 and seen.max() == 2 and (seen == 2).sum() == p * whole.n_ctrl[0] * whole.n_ctrl[2]
 
 
 def test_slab_shard_boxes():

@@ -151,6 +151,130 @@ def test_slabs_on_one_gpu(world, n_el, mode):
         assert sum(n for _, _, n in results) == int(np.prod([n + 2 for n in n_el]))
 
 
+def _local_worker(rank, world, port, n_el, p, scheme, q):
+    """the LOCAL layout (round 5, parallel.SlabShard.localized): every rank holds its slab (+ p ghost layers either side) as a
+    patch of its own -- u, r of local length, the local patch's whole structured matrix, set-up of local size."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        import mimi_amd
+        from mimi_amd import parallel
+        from mimi_amd.integrators import CSRPattern, NonlinearSolid
+        from mimi_amd.splines import PatchShape
+        dev = torch.device("cuda", 0)
+        shape = PatchShape.block(n_el, p)
+        shard_g = parallel.SlabShard(shape, None, rank, world)
+        b, e = shard_g.element_box
+        ax = shard_g.axis
+        below, above = shard_g.ghost_layers()
+        lp = mimi_amd.BSplinePatch.block_slab(n_el, p, ax, b[ax] - below, e[ax] + above)
+        pattern = CSRPattern.of_bspline_patch(lp, on_device=True)
+        shard = shard_g.localized(lp, pattern, ghost=(below, above))
+        gn = shard.global_nodes()
+        stream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(stream)
+        mat = bench.make_material("neohookean")
+        g = NonlinearSolid("domain", mat, pattern, patch=lp, element_box=shard.element_box).Prepare()
+        g.SetStream(stream.cuda_stream)
+        assert g.n_elements_ == shard_g.n_local_elements and g.path_ == 1
+        # the whole patch on the same GPU: the checker, and the source of u
+        patch = mimi_amd.BSplinePatch.block(n_el, p)
+        full = CSRPattern.of_bspline_patch(patch, on_device=True)
+        u_g = bench.synthetic_u(patch)
+        gdofs = (gn[:, None] * 3 + np.arange(3)[None, :]).ravel()
+        u = torch.from_numpy(np.ascontiguousarray(u_g[gdofs])).to(dev)
+        r = torch.zeros(lp.n_vdofs, dtype=torch.float64, device=dev)
+        A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
+        assert lp.n_vdofs < patch.n_vdofs and pattern.nnz < full.nnz
+        # (1) before any exchange: the same bits as a slab handle on the whole patch (same tables: the knot slice has the
+        # whole knot vector's values; same kernels) on every row of the slab's nodes
+        g.AddDomainResidualAndGrad(u, 1.0, r, A)
+        g.Synchronize()
+        Gs = NonlinearSolid("slab", mat, full, patch=patch, element_box=shard_g.element_box).Prepare()
+        r_s = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
+        A_s = torch.zeros(full.nnz, dtype=torch.float64, device=dev)
+        Gs.AddDomainResidualAndGrad(torch.from_numpy(u_g).to(dev), 1.0, r_s, A_s)
+        Gs.Synchronize()
+        rowptr, rowptr_f = pattern.rowptr.cpu().numpy(), full.rowptr.cpu().numpy()
+        r_h, A_h, rs_h, As_h = r.cpu().numpy(), A.cpu().numpy(), r_s.cpu().numpy(), A_s.cpu().numpy()
+        nb, ne = shard.node_box()
+        mi = lp.node_multi_index()
+        touched = np.nonzero((mi[ax] >= nb[ax]) & (mi[ax] < ne[ax]))[0]
+        same_bits = True
+        for node in touched:
+            for i in range(3):
+                lrow, grow = node * 3 + i, gn[node] * 3 + i
+                ls, lt, s, t = rowptr[lrow], rowptr[lrow + 1], rowptr_f[grow], rowptr_f[grow + 1]
+                same_bits = same_bits and lt - ls == t - s and np.array_equal(A_h[ls:lt], As_h[s:t]) and r_h[lrow] == rs_h[grow]
+        # (2) the exchange in local coordinates, twice (zero_interface must reset the shared rows)
+        ex = parallel.InterfaceExchange(shard, r, A, dev, mode="owner")
+        r.zero_()
+        A.zero_()
+        for _ in range(2):
+            ex.zero_interface(True)
+            if scheme == "gather":
+                early, rest = ex.gather_windows()
+                g.Integrate(u)
+                for w in early:
+                    g.Gather(1.0, r, A, *w)
+                ex.start(True)
+                g.Gather(1.0, r, A, *rest)
+                ex.finish()
+            else:
+                g.AddDomainResidualAndGrad(u, 1.0, r, A)
+                ex.sum_residual_and_grad()
+        g.Synchronize()
+        stream.synchronize()
+        Gf = NonlinearSolid("whole", mat, full, patch=patch).Prepare()
+        rf = torch.zeros(patch.n_vdofs, dtype=torch.float64, device=dev)
+        Af = torch.zeros(full.nnz, dtype=torch.float64, device=dev)
+        Gf.AddDomainResidualAndGrad(torch.from_numpy(u_g).to(dev), 1.0, rf, Af)
+        Gf.Synchronize()
+        r_h, A_h, rf_h, Af_h = r.cpu().numpy(), A.cpu().numpy(), rf.cpu().numpy(), Af.cpu().numpy()
+        owned = np.nonzero(np.isin(mi[ax], ex.owned_node_planes()))[0]
+        shared_planes = set()
+        for nbr in (rank - 1, rank + 1):
+            if 0 <= nbr < world:
+                shared_planes.update(shard.interface_node_planes(nbr))
+        worst_r = worst_A = 0.0
+        for node in owned:
+            mult = 1.0 if mi[ax][node] in shared_planes else 2.0
+            for i in range(3):
+                lrow, grow = node * 3 + i, gn[node] * 3 + i
+                ls, lt, s, t = rowptr[lrow], rowptr[lrow + 1], rowptr_f[grow], rowptr_f[grow + 1]
+                assert lt - ls == t - s          # an owned row is complete in its columns
+                worst_r = max(worst_r, abs(r_h[lrow] - mult * rf_h[grow]))
+                worst_A = max(worst_A, np.abs(A_h[ls:lt] - mult * Af_h[s:t]).max())
+        ok = same_bits and worst_r < 1e-12 * np.abs(rf_h).max() and worst_A < 1e-12 * np.abs(Af_h).max()
+        q.put((rank, bool(ok), len(owned) if ok else repr((same_bits, worst_r, worst_A))))
+    except Exception as exc:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_el,p,scheme", [(2, (4, 6, 3), 2, "plain"), (3, (3, 4, 15), 2, "gather"), (2, (3, 8, 2), 3, "gather"),
+                                                 (3, (2, 3, 9), 3, "plain")])
+def test_local_layout_slabs_on_one_gpu(world, n_el, p, scheme):
+    """per-rank vectors and matrix of local size (the slab and its halo as a patch of its own) with
+    the HIP kernels, degree 2 and 3: the same bits as a slab handle on the whole patch before the exchange, and after it
+    every owned row -- complete in its columns -- equals the whole-patch assembly."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_local_worker, args=(r, world, port, n_el, p, scheme, q)) for r in range(world)]
+    results = _run_ranks(ctx, procs, q, world)
+    assert all(ok is True for _, ok, _ in results), results
+    assert sum(n for _, _, n in results) == int(np.prod([n + p for n in n_el]))
+
+
 def _contact_worker(rank, world, port, n_el, sliced, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
