@@ -190,7 +190,7 @@ def _local_worker(rank, world, port, n_el, p, scheme, q):
         u = torch.from_numpy(np.ascontiguousarray(u_g[gdofs])).to(dev)
         r = torch.zeros(lp.n_vdofs, dtype=torch.float64, device=dev)
         A = torch.zeros(pattern.nnz, dtype=torch.float64, device=dev)
-        assert lp.n_vdofs < patch.n_vdofs and pattern.nnz < full.nnz
+        assert lp.n_vdofs <= patch.n_vdofs and pattern.nnz <= full.nnz     # (equal when slab + ghost layers are the whole patch)
         # (1) before any exchange: the same bits as a slab handle on the whole patch (same tables: the knot slice has the
         # whole knot vector's values; same kernels) on every row of the slab's nodes
         g.AddDomainResidualAndGrad(u, 1.0, r, A)
