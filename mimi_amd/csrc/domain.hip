@@ -350,6 +350,17 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a_
   };
   size_t lds = general_lds_bytes(DIM, h->n_dof, h->n_q, grad);
   if (lds > 160 * 1024) fail("element too large for LDS (%zu bytes)", lds);
+  // tangent assemblies of the materials without a closed-form tangent: w det P, w det dP/dF per point from a kernel of their own
+  auto material_prepass = [&]() {
+    constexpr int DD = DIM * DIM;
+    h->mat_rec.resize((size_t)h->n_el * h->n_q * (DD + DD * DD));
+    a.mat_rec = h->mat_rec.ptr;
+    by_other_kind(h->mat.m.kind, [&](auto K) {
+      constexpr int FK = decltype(K)::value;
+      hipLaunchKernelGGL((general_material_kernel<DIM, FK>), dim3(h->n_el), dim3(64), (size_t)h->n_dof * DIM * sizeof(double), h->stream, a);
+      MH_HIP(hipGetLastError());
+    });
+  };
   // small elements (one pass of the node-pair phase fits one wave: 2-D p <= 3, 3-D p = 1): one wave per element, four
   // elements per workgroup (MIMI_HIP_GENERAL_NO_WPE=1: one workgroup per element as for the large ones)
   static const bool no_wpe = getenv("MIMI_HIP_GENERAL_NO_WPE") && getenv("MIMI_HIP_GENERAL_NO_WPE")[0] == '1';
@@ -365,10 +376,13 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a_
     const bool other = !material_closed_form(h->mat.m.kind);
     if (!other) {
       if (grad == 0) gow(domain_general_kernel<DIM, 0, 3, 256, 0, 0, 1>); else gow(domain_general_kernel<DIM, 1, 3, 256, 0, 0, 1>);
+    } else if (grad == 1) {
+      material_prepass();
+      gow(domain_general_kernel<DIM, 1, 3, 256, 1, 0, 1>);
     } else {
       by_other_kind(h->mat.m.kind, [&](auto K) {
         constexpr int FK = decltype(K)::value;
-        if (grad == 0) gow(domain_general_kernel<DIM, 0, 3, 256, FK, 0, 1>); else gow(domain_general_kernel<DIM, 1, 3, 256, FK, 0, 1>);
+        gow(domain_general_kernel<DIM, 0, 3, 256, FK, 0, 1>);
       });
     }
     gather();
@@ -383,15 +397,20 @@ static void launch_general(mimi_hip_domain_s* h, int grad, const GeneralArgs& a_
   // MIMI_HIP_GENERAL_NO_MFMA=1: the vector-pipe node-pair phase also for 64-node elements (A/B comparisons)
   static const bool no_mfma = getenv("MIMI_HIP_GENERAL_NO_MFMA") && getenv("MIMI_HIP_GENERAL_NO_MFMA")[0] == '1';
   if (!material_closed_form(h->mat.m.kind)) {
-    // the other materials: same kernel, stress and tangent from materials_other.hpp
-    by_other_kind(h->mat.m.kind, [&](auto K) {
-      constexpr int FK = decltype(K)::value;
-      if (grad == 0) go(domain_general_kernel<DIM, 0, 3, 256, FK>);
-      else if (grad == 1 && DIM == 3 && h->n_dof == 64 && !no_mfma) go(domain_general_kernel<3, 1, GEN_BIG_PP, GEN_BIG_THREADS, FK, 1>, GEN_BIG_THREADS);
-      else if (grad == 1 && h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, GEN_BIG_PP, GEN_BIG_THREADS, FK>, GEN_BIG_THREADS);
-      else if (grad == 1) go(domain_general_kernel<DIM, 1, 3, 256, FK>);
-      else go(domain_general_kernel<DIM, 2, 3, 256, FK>);
-    });
+    // the other materials (materials_other.hpp): the tangent assembly takes P and dP/dF from the material pre-pass (one lean
+    // kernel per material), the residual-only and reference-FD assemblies evaluate the stress in the element kernel
+    if (grad == 1) {
+      material_prepass();
+      if (DIM == 3 && h->n_dof == 64 && !no_mfma) go(domain_general_kernel<3, 1, GEN_BIG_PP, GEN_BIG_THREADS, 1, 1>, GEN_BIG_THREADS);
+      else if (h->n_dof * h->n_dof > 3 * 256) go(domain_general_kernel<DIM, 1, GEN_BIG_PP, GEN_BIG_THREADS, 1>, GEN_BIG_THREADS);
+      else go(domain_general_kernel<DIM, 1, 3, 256, 1>);
+    } else {
+      by_other_kind(h->mat.m.kind, [&](auto K) {
+        constexpr int FK = decltype(K)::value;
+        if (grad == 0) go(domain_general_kernel<DIM, 0, 3, 256, FK>);
+        else go(domain_general_kernel<DIM, 2, 3, 256, FK>);
+      });
+    }
     gather();
     return;
   }
@@ -495,12 +514,11 @@ static void run_domain(mimi_hip_domain_s* h, const double* u, double* r, double*
     mA = Mirror<double>::inout(A, h->nnz, h->stage_A, h->stream);
   }
   const int grad = !with_grad ? 0 : (h->tangent_mode == MIMI_HIP_TANGENT_REFERENCE_FD ? 2 : 1);
-  // (the colour-partitioned tensor kernel, the fallback when the CSR is not the structured pattern, has closed-form
-  // materials only: the other materials then take the general kernels)
+  // (a 3-D degree-2 / 3 patch whose CSR is not the structured pattern is not tensor_usable: the general kernels take it)
   if (tensor_small(h) && grad != 2 && launch_tensor_small(h, grad, mu.dev, mr.dev, mA.dev, gf)) {
     // (2-D, degree 1: element kernel from the 1-D tables + the general gather)
     h->last_family = 3;
-  } else if (tensor_usable(h) && !tensor_small(h) && grad != 2 && (material_closed_form(h->mat.m.kind) || two_phase_supported(h))) {
+  } else if (tensor_usable(h) && !tensor_small(h) && grad != 2) {
     h->last_family = launch_tensor(h, grad, mu.dev, mr.dev, mA.dev, gf);
   } else {
     h->last_family = 4;
@@ -790,7 +808,7 @@ int mimi_hip_domain_create_bspline(const mimi_hip_bspline_patch* p, const mimi_h
     // degree 3 has the two-phase tensor kernels only: anything else about the handle (numbering, pattern) -> general path
     if (h->path == 1 && !tensor_usable(h.get())) h->path = 0;
     // pair positions now unless this handle will run the two-phase kernels (then on demand, ensure_pair_pos)
-    if (!(tensor_usable(h.get()) && two_phase_supported(h.get())) || tensor_small(h.get())) build_pair_pos(h.get(), p->csr_col);
+    if (!tensor_usable(h.get()) || tensor_small(h.get())) build_pair_pos(h.get(), p->csr_col);
     init_state(h.get());
     MH_HIP(hipStreamSynchronize(h->stream));
     *out = h.release();
@@ -832,11 +850,7 @@ int mimi_hip_domain_set_stream(mimi_hip_domain_t h, void* stream) {
 
 // the two-step form of a tangent assembly: phase 1 of the whole handle, then phase 2 over parts of its nodes
 static void require_two_phase(mimi_hip_domain_s* h) {
-  const char* variant = getenv("MIMI_HIP_TENSOR_VARIANT");
-  const bool colour_forced = variant && variant[0] == 'v' && h->degree[0] == 2 &&
-                             (h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN || h->mat.m.kind == MIMI_HIP_MAT_J2);
-  const bool ok = h->dim == 3 && tensor_usable(h) && !tensor_small(h) && two_phase_supported(h) &&
-                  h->tangent_mode == MIMI_HIP_TANGENT_ANALYTIC && !colour_forced;
+  const bool ok = h->dim == 3 && tensor_usable(h) && !tensor_small(h) && h->tangent_mode == MIMI_HIP_TANGENT_ANALYTIC;
   if (!ok) fail("integrate / gather: only on the two-phase tensor paths (3-D, degree 2 or 3, structured CSR, analytic tangent)");
 }
 

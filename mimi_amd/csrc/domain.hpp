@@ -41,6 +41,7 @@ struct mimi_hip_domain_s {
   mimi_hip::DeviceBuffer<uint16_t> nbr_pos16;     // [n_nodes][343] the same for degree 3
   bool first_is_identity = false;            // span e's first basis function is e (no repeated interior knots)
   mimi_hip::DeviceBuffer<double> scratch_k, scratch_r, scratch_pt, scratch_tail;  // two-phase tangent path
+  mimi_hip::DeviceBuffer<double> mat_rec;    // general path, other materials' tangent assemblies: [n_el][n_q][DIM^2 + DIM^4] (kernels_general.hpp)
   mimi_hip::DeviceBuffer<double> t3_t2pack;  // degree-3 contraction: direction-2 table values per (span, lane), [n_spans][64][8] (tensor_p3.hip)
 
   // J2 state, SoA over points
@@ -65,8 +66,7 @@ struct mimi_hip_domain_s {
   // (consume_base below).
   const double* A_base = nullptr;
   // kernel family of the last assembly / state commit on this handle (mimi_hip_domain_info(h, 7)): 0 none yet,
-  // 1 two-phase tensor degree 2, 2 two-phase tensor degree 3, 3 small-element tensor kernel, 4 general kernels,
-  // 5 colour-partitioned tensor kernel
+  // 1 two-phase tensor degree 2, 2 two-phase tensor degree 3, 3 small-element tensor kernel, 4 general kernels
   int last_family = 0;
 
   // staging for host-resident u / r / A

@@ -45,6 +45,7 @@ struct GeneralArgs {
   int lds_per_element;      // WPE kernels: bytes of LDS per element (general_lds_bytes rounded up to 16)
   double* scratch_k;        // dense element blocks [n_el][(a, i)][(j, b)] instead of atomics (then gathered); nullptr: atomics
   double* scratch_r;        // element residual vectors [n_el][i][a] instead of atomics (then gathered); nullptr: atomics
+  double* mat_rec;          // FAMILY 1 (the other materials' tangent assemblies): [n_el][n_q][DIM^2 + DIM^4] = w det P, w det dP/dF
 };
 
 MH_DEV void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
@@ -113,10 +114,66 @@ typedef double mhg_d4 __attribute__((ext_vector_type(4)));
 #define GEN_MF_QC 8   // quadrature points staged per barrier pair of the matrix-instruction node-pair phase
 #endif
 #define GEN_SYNC() do { if constexpr (WPE) __builtin_amdgcn_wave_barrier(); else __syncthreads(); } while (0)
+// Material pre-pass of the general path's TANGENT assemblies for the materials without a closed-form tangent (StVenant-
+// Kirchhoff, J2Linear, J2Simo, J2Log; round 5): one 64-lane workgroup per element, lane = quadrature point, one instantiation
+// per material, the whole register file to itself -- the dual-number stress routines of J2Simo / J2Log need ~ 470 registers
+// and spilled 480 - 520 of them inside the element kernel, whose occupancy bound leaves 256.
+// Leaves w det P and w det dP/dF per point (mat_rec); the element kernel then runs as FAMILY 1 and only loads them.
+template<int DIM, int FK>
+__global__ __launch_bounds__(64) void general_material_kernel(GeneralArgs p) {
+  constexpr int DD = DIM * DIM, D4 = DD * DD;
+  extern __shared__ __align__(16) unsigned char smem_mat[];
+  double* u_e = reinterpret_cast<double*>(smem_mat);   // [DIM][n_dof]
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const int n_dof = p.n_dof, n_q = p.n_q, n_tdof = n_dof * DIM;
+  for (int t = tid; t < n_tdof; t += 64) {
+    const int a = t % n_dof, i = t / n_dof;
+    u_e[t] = p.u[(int64_t)p.dofs[(int64_t)e * n_dof + a] * DIM + i];
+  }
+  __syncthreads();
+  const double* gE = p.dN_dX + (int64_t)e * n_q * n_tdof;
+  int status = 0;
+  for (int q = tid; q < n_q; q += 64) {
+    double F[DD], P[DD];
+    compute_F_general<DIM>(n_dof, gE + (int64_t)q * n_tdof, u_e, F);
+    const double wd = p.wdet[(int64_t)e * n_q + q];
+    double* rec = p.mat_rec + ((int64_t)e * n_q + q) * (DD + D4);
+    // (the tangent one direction (j, L) at a time, as in the tensor pre-pass kernels: nothing but the direction's DIM^2
+    // derivatives is live beside the material's own working set)
+    OtherTangent<DIM> ot;
+    status |= other_tangent_begin<DIM, FK>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F, P, ot);
+#pragma unroll
+    for (int k = 0; k < DD; ++k) rec[k] = wd * P[k];
+#pragma unroll 1
+    for (int j = 0; j < DIM; ++j)
+#pragma unroll 1
+      for (int L = 0; L < DIM; ++L) {
+        double dP[DD], Fl[DD];
+        // (F passes through an empty asm per direction: otherwise the compiler hoists everything of the dual-number stress
+        // routine that depends on the value parts alone out of the loop and keeps it live across the nine directions --
+        // ~ 200 values parked in the accumulation file, counted as spilled registers, for J2Log)
+#pragma unroll
+        for (int k = 0; k < DD; ++k) {
+          Fl[k] = F[k];
+          asm volatile("" : "+v"(Fl[k]));
+        }
+        other_tangent_dir<DIM, FK>(p.mat, p.dt, Fl, ot, j, L, dP);
+#pragma unroll
+        for (int i = 0; i < DIM; ++i)
+#pragma unroll
+          for (int J = 0; J < DIM; ++J) rec[DD + ((i * DIM + J) * DIM + j) * DIM + L] = wd * MH_M(dP, i, J);
+      }
+  }
+  if (status) atomicOr(p.status, status);
+}
+
 // WPE: 1 = one WAVE per element (small elements: 2-D, p = 1): THREADS / 64 elements per workgroup, every barrier a wave
 //      barrier, the LDS block of the element at wave * general_lds_bytes
 template<int DIM, int GRAD, int PP = 3, int THREADS = 256, int FAMILY = 0, int MF = 0, int WPE = 0>
-__global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domain_general_kernel(GeneralArgs p) {
+// (FAMILY: 0 closed-form materials; 1 tangent assembly of another material: P and dP/dF come from general_material_kernel;
+//  2..5 that one of the other materials evaluated here -- residual-only and reference-FD assemblies.  The 3-D one-wave-per-
+//  element tangent kernel gets the whole register file: at two waves per SIMD it spilled 67 - 76 registers)
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? ((WPE && DIM == 3 && GRAD == 1) ? 1 : GEN_WAVES) : 1) void domain_general_kernel(GeneralArgs p) {
   constexpr int DD = DIM * DIM;
   constexpr int D4 = DD * DD;
   extern __shared__ __align__(16) unsigned char smem_all[];
@@ -146,11 +203,19 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? GEN_WAVES : 1) void domai
 
   // phase 1: constitutive update per quadrature point
   int status = 0;
-  for (int q = tid; q < n_q; q += n_threads) {
+  if constexpr (FAMILY == 1) {
+    static_assert(GRAD == 1, "FAMILY 1 is the tangent assembly behind general_material_kernel");
+    const double* rec = p.mat_rec + (int64_t)e * n_q * (DD + D4);
+    for (int t = tid; t < n_q * (DD + D4); t += n_threads) {
+      const int q = t / (DD + D4), k = t % (DD + D4);
+      if (k < DD) Pw[q * DD + k] = rec[t]; else Aw[q * D4 + (k - DD)] = rec[t];
+    }
+  }
+  for (int q = tid; FAMILY != 1 && q < n_q; q += n_threads) {
     double F[DD];
     compute_F_general<DIM>(n_dof, gE + (int64_t)q * n_tdof, u_e, F);
     const double wd = wE[q];
-    if constexpr (FAMILY != 0) {
+    if constexpr (FAMILY >= 2) {
       double P[DD];
       status |= evaluate_other<DIM, (FAMILY >= 2 ? FAMILY : -1)>(p.mat, p.dt, p.state, (int64_t)e * n_q + q, F, P, GRAD == 1 ? Aw + q * D4 : nullptr, wd);
 #pragma unroll

@@ -12,11 +12,13 @@ inline void launch_tensor_wgs(mimi_hip_domain_s* h, TensorArgs a);              
 inline void launch_tensor_wgsym(mimi_hip_domain_s* h, TensorArgs a);             // kernels_tensor_wgsym.hpp
 inline void launch_tensor_residual(mimi_hip_domain_s* h, TensorArgs a);          // kernels_tensor_residual.hpp
 inline void launch_tensor_p2_post(mimi_hip_domain_s* h, TensorArgs a);           // kernels_tensor_wgs.hpp
-static void ensure_pair_pos(mimi_hip_domain_s* h);                                // domain.hip
 
-// can this handle's assembly run on the tensor kernels?  (p = 3 has the two-phase kernels only)
+// can this handle's assembly run on the tensor kernels?  (3-D degree 2 and 3 have the two-phase kernels only: a patch
+// whose CSR is not the structured pattern, or with repeated interior knots, takes the general kernels)
 inline bool tensor_usable(const mimi_hip_domain_s* h) {
-  return h->path == 1 && (tensor_small_shape(h->dim, h->degree, h->nq1[0]) || h->degree[0] != 3 || tensor_p3_ready(h));
+  if (h->path != 1) return false;
+  if (tensor_small_shape(h->dim, h->degree, h->nq1[0])) return true;
+  return h->degree[0] == 3 ? tensor_p3_ready(h) : two_phase_supported(h);
 }
 
 // returns the kernel family that ran (mimi_hip_domain_s::last_family)
@@ -26,26 +28,14 @@ inline int launch_tensor(mimi_hip_domain_s* h, int grad, const double* u, double
     launch_tensor_p3(h, grad, a);
     return 2;
   }
-  // MIMI_HIP_TENSOR_VARIANT: default when supported = two-phase with role-specialised workgroups, the
-  // symmetric-half kernel for hyperelastic materials; "wgs" forces the full nine-block kernel,
-  // "valu" the colour-partitioned read-modify-write kernel
+  // MIMI_HIP_TENSOR_VARIANT=wgs: the full nine-block kernel also for hyperelastic materials (default: symmetric half)
   static const char* variant = getenv("MIMI_HIP_TENSOR_VARIANT");
-  const bool closed_form = h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN || h->mat.m.kind == MIMI_HIP_MAT_J2;
-  const bool want_valu = variant && variant[0] == 'v' && closed_form;   // the colour kernel has the closed-form materials only
-  if (grad && !want_valu && two_phase_supported(h)) {
+  if (grad) {
     const bool want_full = variant && variant[0] == 'w';
     if (h->mat.m.kind == MIMI_HIP_MAT_NEOHOOKEAN && !want_full) launch_tensor_wgsym(h, a);
     else launch_tensor_wgs(h, a);
-  }
-  else if (!grad && !want_valu && two_phase_supported(h))
+  } else {
     launch_tensor_residual(h, a);
-  else {
-    if (grad) {
-      ensure_pair_pos(h);       // domain.hip: the colour kernel scatters the tangent through the pair-position table
-      a.pair_pos = h->pair_pos.ptr;
-    }
-    launch_tensor_p<2>(h, grad, a);
-    return 5;
   }
   return 1;
 }

@@ -230,8 +230,7 @@ class NonlinearSolid(NonlinearBase):
         raise RuntimeError("Currently not implemented, use AddDomainResidualAndGrad")  # nonlinear_solid.hpp:108-113
 
     # -- material state (MaterialState, materials.hpp:278-286) --------------------------
-    KERNEL_FAMILIES = {0: "none", 1: "tensor_p2_two_phase", 2: "tensor_p3_two_phase", 3: "tensor_small", 4: "general",
-                       5: "tensor_colour"}
+    KERNEL_FAMILIES = {0: "none", 1: "tensor_p2_two_phase", 2: "tensor_p3_two_phase", 3: "tensor_small", 4: "general"}
 
     def LastKernelFamily(self):
         """which kernel family the last assembly on this handle ran on (tests assert it; see mimi_hip_domain_info)"""
