@@ -2,6 +2,8 @@
 seeded inputs.  Bars: residual <= 1e-12 relative (max-norm); analytic tangent
 vs the oracle's exact tangent <= 1e-11 relative; reference-FD mode vs the oracle's
 reference-FD restatement within the FD round-off amplification (5e-4 relative, measured 1e-5)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -76,7 +78,10 @@ def test_residual_and_tangent_parity(case, matname, creator):
     n_el, p, lengths = case
     P, D, G = make_pair(n_el, p, lengths, matname, creator)
     # B-spline patches (2-D and 3-D, degree <= 3) must take the sum-factorised (tensor) kernels, flat tables the general ones
-    assert G.path_ == (1 if creator == "bspline" else 0)
+    # (MIMI_HIP_NO_STRUCTURED=1, test_fallback_kernel_families: a 3-D degree-2 / 3 patch whose CSR is not recognised as the
+    # structured pattern takes the general kernels)
+    unrecognised = os.environ.get("MIMI_HIP_NO_STRUCTURED") == "1" and len(n_el) == 3 and p >= 2
+    assert G.path_ == (1 if creator == "bspline" and not unrecognised else 0)
     dt = 0.5
     D.set_dt(dt)
     G.dt_ = dt
@@ -192,7 +197,7 @@ def test_element_boxes_add_up_to_the_whole(axis, matname):
         begin, end = [0, 0, 0], list(n_el)
         begin[axis], end[axis] = b, e
         G = NonlinearSolid("domain", product_material(matname), pattern, patch=patch, element_box=(begin, end)).Prepare()
-        assert G.path_ == 1
+        assert G.path_ == (0 if os.environ.get("MIMI_HIP_NO_STRUCTURED") == "1" else 1)     # (see test_fallback_kernel_families)
         G.dt_ = 0.5
         G.AddDomainResidualAndGrad(u, 1.0, r_g, A_g)
         # the residual-only assembly of the same box (neo-Hookean: one wave per element column of the BOX, the columns cut
@@ -416,9 +421,10 @@ def test_fallback_kernel_families(env):
     import subprocess
     import sys
     e = dict(os.environ, **env)
-    select = "(5x5x5p2 and bspline) or (boxes and neohook) or tiny"
+    select = "(5x5x5p2 and bspline) or (boxes and neohook)"
     if "MIMI_HIP_NO_STRUCTURED" not in env:
-        select += " or permuted"      # (that test asserts the structured-pattern detection, which this variable disables)
+        # (these assert the structured-pattern detection / the two-phase kernels, which that variable takes away)
+        select += " or tiny or permuted"
     cmd = [sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
            "-k", select]
     res = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
