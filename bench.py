@@ -99,7 +99,7 @@ def recorded_pmc(workload, world, grad, material):
     kernel's 8-byte accesses by scratch/fetch_calib.hip).  bench.py cannot run the profiler on itself, so these are
     RECORDED numbers: returned with their source, and dropped (None) when the kernel sources changed since."""
     key = f"{workload}/{material}/{'grad' if grad else 'residual'}/n{world}"
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f).get(key)
@@ -789,9 +789,23 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
             # the residual-only assembly against ITS roofline (HBM-bound, B_alg without the n_tdof^2 term)
             b_res = b_alg(patch.dim, p, grad=False, stateful=stateful)
             ach = b_res * local_elements / (residual_ms * 1e-3) / 1e9
+            # what binds it, from the RECORDED counters of these kernel sources (None when they changed since): the vector
+            # instructions the assembly issues per element against the chip's issue capacity over the measured time -- the J2
+            # return mapping makes cfg3's residual-only assembly an fp64-vector-issue problem, not an HBM one
+            pmc_r = recorded_pmc(workload, world, False, material)
+            pipe_r = (pmc_r or {}).get("pipe") or {}
+            valu = sum(v["valu_instructions_per_element"] for v in pipe_r.values()) if pipe_r else None
+            binding_r = None if valu is None else {
+                "resource": "vector instruction issue (fp64 pipe)", "valu_instructions_per_element": valu,
+                "issued_frac": valu * 4.0 * local_elements / (N_SIMD * CLOCK_HZ * residual_ms * 1e-3),
+                "issued_frac_at_4.9_cycles": valu * 4.9 * local_elements / (N_SIMD * CLOCK_HZ * residual_ms * 1e-3),
+                "how": "recorded SQ_INSTS_VALU per element x 4 cycles (the pipe's rate; 4.9 = what one wave's instruction takes, "
+                       "DESIGN 4.2) x elements / (1024 SIMDs x 2.4 GHz x the measured time)",
+                "measured_bytes": pmc_r.get("bytes_per_step"), "source": pmc_r.get("traffic_source")}
             result["residual_only"] = {"ms": residual_ms, "value": n_elements / (residual_ms * 1e-3),
                                        "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
                                                     "frac": ach / 8000.0, "algorithmic_bytes_per_element": b_res,
+                                                    "binding": binding_r,
                                                     "how": "mean of 10 AddDomainResidual calls after the timed region, host clock "
                                                            "around a device synchronisation"}}
         if post_ms is not None:

@@ -1,4 +1,4 @@
-"""profiles/r04_traffic.json from rocprofv3 PMC passes (run on the GPU box by scratch/profile_round.sh).
+"""profiles/rNN_traffic.json from rocprofv3 PMC passes (run on the GPU box by scratch/profile_round.sh).
 usage: python scratch/make_traffic_json.py OUT.json KEY:DIR_PIPE:DIR_FETCH:DIR_WRITE:ELEMENTS:B_ALG [...]
 Per kernel and dispatch: FETCH_SIZE (KB, doubled: gfx950 tallies 128-B requests at 64 B -- MI355X guide, HBM section; the
 factor holds for this code's 8-byte per-lane accesses, profiles/r01_pmc_calibration.txt), WRITE_SIZE (KB, exact),
@@ -31,6 +31,8 @@ for spec in sys.argv[2:]:
     # (", 2>": the state-commit mode of the pre-pass kernel, DomainPostTimeAdvance -- timed by bench.py after the step)
     step = [k for k in names if not (k.startswith("tp3_point_kernel<0, 0>") or k.startswith("tp3_point_kernel<1, 0>") or k.startswith("tp3_gather_kernel<0>")
                                      or k.startswith("tensor_residual") or ", 2>" in k)]
+    if not grad:      # the residual-only assembly (bench.py --residual-only): its own kernels
+        step = [k for k in names if k.startswith(("tp3_point_kernel<0, 0>", "tp3_gather_kernel<0>", "tensor_residual"))]
     f_kb = {k: fetch[k].get("FETCH_SIZE", 0.0) for k in step}
     w_kb = {k: write[k].get("WRITE_SIZE", 0.0) for k in step}
     total = sum(2 * f_kb[k] + w_kb[k] for k in step) * 1024
