@@ -165,7 +165,7 @@ int mimi_hip_domain_add_residual_and_grad(mimi_hip_domain_t h, const double* u, 
  * does -- a slab assembles with mimi_hip_domain_add_residual_and_grad into its copy of the base).  This is operators::NonlinearSolid::ResidualAndGrad's "jacobian_ values <- mass values, then
  * AddMultGrad" (operators/nonlinear_solid.cpp:257-258) without the copy pass: with both arrays on the device the row
  * gathers read A_base where "+=" would read A_out -- no extra traffic.  A_base == A_out is the plain "+=".  Routes
- * without a row gather (colour kernel, atomics fallback) and host-resident arrays copy A_base into A_out first. */
+ * without a row gather (the atomics fallback of the general path) and host-resident arrays copy A_base into A_out first. */
 int mimi_hip_domain_add_residual_and_grad_from(mimi_hip_domain_t h, const double* u, double grad_factor,
                                                double* r, const double* A_base, double* A_out);
 /* DomainPostTimeAdvance(converged_u): commit material state (nonlinear_solid.cpp:179-199) */
@@ -199,7 +199,7 @@ int mimi_hip_domain_phase_ms(mimi_hip_domain_t h, double* phase1_ms, double* pha
 int mimi_hip_domain_phase_ms_detail(mimi_hip_domain_t h, double* prepass_ms, double* integration_ms, double* gather_ms);
 /* sizes: what = 0 n_elements, 1 n_quad, 2 n_dof, 3 nnz, 4 n_vdofs, 5 path (0 general, 1 tensor), 6 CSR kind (0 any,
  * 1 structured lexicographic, 2 structured permuted), 7 kernel family of the last assembly on the handle (0 none yet,
- * 1 two-phase tensor degree 2, 2 two-phase tensor degree 3, 3 small-element tensor, 4 general, 5 colour tensor) */
+ * 1 two-phase tensor degree 2, 2 two-phase tensor degree 3, 3 small-element tensor, 4 general) */
 int64_t mimi_hip_domain_info(mimi_hip_domain_t h, int what);
 
 /* ---- structured sparsity: PrecomputedData::PrepareSparsity (precomputed.cpp:151-174) ----
