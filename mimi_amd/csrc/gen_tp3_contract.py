@@ -23,7 +23,7 @@ and ends every element with `s_waitcnt vmcnt(0)` right behind its last stores.  
 
 Register map (fixed; the asm statement clobbers exactly these, the compiler keeps v0..v[V0-1], the low SGPRs):
   VGPR  D (S1 results) 144 | E (S2 accumulators; bS2 operands during S1) 32 | W, cb, ca 24 | TA..TD 8 | t2 16 | 19 ints
-  AGPR  aop 54 | two tile sets 64 | bS0, bS0x 12 | two sets of final entries 16
+  AGPR  aop 54 | two tile sets 64 + 8 staging (register 0 of the even tiles beside the odd ones': 16-byte stores) | bS0, bS0y 12 | final entries 32
 The parameter block arrives in LDS (the carry area, which the loop zeroes afterwards): slot k = 512 bytes, lane-indexed.
 
 usage: python gen_tp3_contract.py [out.inc]     (tests/test_isa_lint_cpu.py checks that the committed file is current)
@@ -51,10 +51,12 @@ VEND = VI + 19
 assert VEND <= 256, VEND
 
 AA = 0                       # aop[mn][t] = AA + 18 t + 2 mn (a 16-byte load fills mn = 2 q, 2 q + 1 of one t)
-AT = 56                      # tile set s, tile a1: AT + 32 s + 8 a1
-AB0 = 120                    # bS0[g] = AB0 + 2 g, bS0x[h] = AB0 + 8 + 2 h
-AF = 132                     # fin set s: AF + 8 s + 2 a1
-AEND = 148
+AT = 56                      # tile set 0 (even pair columns), tile a1: AT + 8 a1
+AT1 = AT + 32                # tile set 1 (odd pair columns): per a1 [2 registers: register 0 of the EVEN tile, moved here][the tile, 8]
+AB0 = 128                    # bS0[g] = AB0 + 2 g, bS0y = AB0 + 8
+AF = 140                     # final entries: pair h = b1 / 2, tile a1: AF + 16 (h & 1) + 4 a1 + 2 (b1 & 1)
+AEND = 172
+assert AT1 + 40 <= AB0 and AB0 + 12 <= AF
 
 S0 = 36                      # first SGPR of the asm block
 (S_REC0, S_REC1, S_REC2, S_RSTRIDE, S_CURA, S_CURB, S_CUR1, S_PRVA, S_PRVB, S_PRV1, S_PSTRIDE, S_B2, S_SPARE, S_TMP, S_EFF) = \
@@ -114,12 +116,17 @@ def AOP(mn, t):
 
 
 def TILE(s, a1, r=None):
-    base = AT + 32 * s + 8 * a1
+    base = AT + 8 * a1 if s == 0 else AT1 + 10 * a1 + 2
     return base if r is None else base + 2 * r
 
 
-def FIN(s, a1):
-    return AF + 8 * s + 2 * a1
+def STAGE(a1):
+    """four registers: [register 0 of even tile a1 (moved)][register 0 of odd tile a1 (in place)] = what one 16-byte store takes"""
+    return AT1 + 10 * a1
+
+
+def FIN(b1, a1):
+    return AF + 16 * ((b1 >> 1) & 1) + 4 * a1 + 2 * (b1 & 1)
 
 
 class Out:
@@ -193,7 +200,7 @@ def with_shadows(o, mfmas, shadow, per_shadow):
 
 
 # ---------------------------------------------------------------- pieces of the schedule
-def s2_pass(o, b1, plane):
+def s2_pass(o, b1, plane, after_first_slot=None):
     """S2 of pair column b1: the points q0 < 4 (five slots) or the plane q0 = 4 (three slots).  Per value the operations
     of tp3_contract_kernel's s2 lambda; ordered so that no instruction reads a register written by one of the two
     instructions before it (fp64 results take 8.5 cycles, an instruction issues every 4.9)."""
@@ -255,6 +262,8 @@ def s2_pass(o, b1, plane):
             o.emit(fmac_bc(E(2, a1), T, W2a, cD + a1))
         for a1 in range(NB):
             o.emit(fmac_bc(E(0, a1), T, W0a, cD + a1))
+        if s == 0 and after_first_slot is not None:
+            after_first_slot(o)          # (34 vector instructions behind the matrix instructions whose results it reads)
 
 
 def carry_in(b1, tset):
@@ -273,22 +282,31 @@ def carry_out(b1, tset):
     return out
 
 
-def finals_in(b1, fset):
-    return [f"ds_read_b64 {a2(FIN(fset, a1))}, v{I_FIN} offset:{(a1 * 16 + b1 * 4) * 512}" for a1 in range(NB)]
+def finals_in(b1):
+    return [f"ds_read_b64 {a2(FIN(b1, a1))}, v{I_FIN} offset:{(a1 * 16 + b1 * 4) * 512}" for a1 in range(NB)]
 
 
-def finals_store(b1, fset):
-    # out1_prev[a1 4 48 + b1 4]; the base register is piece + 2304 bytes so that the immediates fit 13 signed bits
-    return [f"global_store_dwordx2 v{I_OUT1}, {a2(FIN(fset, a1))}, {s2r(S_PRV1)} offset:{a1 * 1536 + b1 * 32 - 2304}"
+def finals_store(h):
+    # out1_prev[a1 4 48 + h 8 (+ b1 % 2)]: the finals of the pair columns 2 h, 2 h + 1 with one 16-byte store per tile; the base
+    # register is piece + 2304 bytes so that the immediates fit 13 signed bits
+    return [f"global_store_dwordx4 v{I_OUT1}, a[{FIN(2 * h, a1)}:{FIN(2 * h, a1) + 3}], {s2r(S_PRV1)} offset:{a1 * 1536 + h * 64 - 2304}"
             for a1 in range(NB)]
 
 
-def out_store(b1, tset, prev):
-    # out0[a1 4 192 + b1 16] = register 0 of tile a1; bases A (a1 = 0, 1) and B (a1 = 2, 3) sit 3072 bytes inside their range
+def stage_even(o, tset_unused=None):
+    """register 0 of the even pair column's four tiles -> beside register 0 of the odd one's (vector instructions: in a vector stretch)"""
+    for a1 in range(NB):
+        o.emit(f"v_accvgpr_mov_b32 a{STAGE(a1)}, a{TILE(0, a1, 0)}")
+        o.emit(f"v_accvgpr_mov_b32 a{STAGE(a1) + 1}, a{TILE(0, a1, 0) + 1}")
+
+
+def out_store(h, prev):
+    # out0[a1 4 192 + h 32 (+ b1 % 2)] = register 0 of tile a1 of the pair columns 2 h, 2 h + 1; bases A (a1 = 0, 1) and B (a1 = 2, 3)
+    # sit 3072 bytes inside their range
     out = []
     for a1 in range(NB):
         base = (S_PRVA if prev else S_CURA) if a1 < 2 else (S_PRVB if prev else S_CURB)
-        out.append(f"global_store_dwordx2 v{I_OUT0}, {a2(TILE(tset, a1, 0))}, {s2r(base)} offset:{(a1 & 1) * 6144 - 3072 + b1 * 128}")
+        out.append(f"global_store_dwordx4 v{I_OUT0}, a[{STAGE(a1)}:{STAGE(a1) + 3}], {s2r(base)} offset:{(a1 & 1) * 6144 - 3072 + h * 256}")
     return out
 
 
@@ -453,9 +471,9 @@ def generate(opts=None):
     o.emit(f"v_mov_b32 v{I_ZERO1}, 0")
     for k in range(64):
         o.emit(f"ds_write_b64 v{I_CL}, {v2(I_ZERO0)} offset:{k * 512}")
+    for r in range(40):
+        o.emit(f"v_accvgpr_write_b32 a{AT1 + r}, 0")
     for r in range(32):
-        o.emit(f"v_accvgpr_write_b32 a{AT + 32 + r}, 0")
-    for r in range(16):
         o.emit(f"v_accvgpr_write_b32 a{AF + r}, 0")
     for x in carry_in(0, 0):
         o.emit(x)
@@ -484,7 +502,7 @@ def generate(opts=None):
             ops.append([kind, lo, hi, x])
 
     # outputs of the previous element's pair column 3 (tile set 1, `prev` bases) -- before tile set 1 is read into again
-    for i, x in enumerate(out_store(3, 1, prev=True)):
+    for i, x in enumerate(out_store(1, prev=True)):
         add("vm", i, 35, [x])
     add("lds", 0, 35, carry_out(3, 1))
     # next element's operands (operand_loads); the tables' registers are free once the B operands are formed
@@ -501,13 +519,15 @@ def generate(opts=None):
         # first half of the S3 main shadows: the outputs of pair column b1 - 1 (the other tile set) and the finals the next pair
         # column will store; second half: this pair column's finals (found by the previous one, waited for at the head of S3
         # main) and -- once nothing reads the other tile set any more -- the start values of the next pair column's tiles
-        if b1 > 0:
-            for i, x in enumerate(out_store(b1 - 1, 1 - tset, prev=False)):
+        if b1 == 2:
+            for i, x in enumerate(out_store(0, prev=False)):      # pair columns 0, 1 (the odd one's tiles are read into again from m + 8)
                 add("vm", m + store_spread * i, m + 7, [x])
+        if b1 > 0:
             add("lds", m, m + 7, carry_out(b1 - 1, 1 - tset))
-        add("lds", m, m + 7, finals_in((b1 + 1) % 4, 1 - tset))
-        for i, x in enumerate(finals_store(b1, tset)):
-            add("vm", m + 8 + store_spread * i, pl - 1, [x])
+        add("lds", m, m + 7, finals_in((b1 + 1) % 4))
+        if b1 & 1:
+            for i, x in enumerate(finals_store(b1 >> 1)):         # the finals of pair columns b1 - 1, b1 (found by the shadows before)
+                add("vm", m + 8 + store_spread * i, pl - 1, [x])
         add("lds", m + 8 if b1 > 0 else m, pl + NP - 1, carry_in((b1 + 1) % 4, 1 - tset))
     add("sc", p_of(3), n_slot - 1, rotate_piece_bases())
     # assignment: slot by slot, per kind the eligible instructions with the earliest deadline first
@@ -533,7 +553,7 @@ def generate(opts=None):
         if k >= 36 and (k - 36) % (NM + NP) == 0:
             b1 = (k - 36) // (NM + NP)
             o.comment(f"pair column b1 = {b1}: S2 (points q0 < 4), S3 main")
-            s2_pass(o, b1, plane=False)
+            s2_pass(o, b1, plane=False, after_first_slot=stage_even if b1 & 1 else None)
             o.emit("s_waitcnt lgkmcnt(0)")
         if k >= 36 and (k - 36) % (NM + NP) == NM:
             b1 = (k - 36) // (NM + NP)
@@ -551,7 +571,7 @@ def generate(opts=None):
     o.comment("flush: the last element's pair column 3 (the piece bases were rotated: it is `prev`)")
     o.emit("s_nop 15")
     o.emit("s_nop 3")
-    for x in out_store(3, 1, prev=True) + carry_out(3, 1):
+    for x in out_store(1, prev=True) + carry_out(3, 1):
         o.emit(x)
     o.emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
     return o

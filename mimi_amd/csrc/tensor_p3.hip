@@ -619,9 +619,10 @@ MH_DEV void t3_results_guard() { asm volatile("s_nop 15" ::: "memory"); }
 // and a v_permlane32_swap pair -- 116 matrix instructions per block; rounds 2-4: two k-steps with the partial sums of two
 // variants each, 132).
 //
-// Piece of (element, i), 5376 doubles -- what phase 2 reads contiguously:
-//   [0, 3072)     rows a2 = 0:  (a0 + 4 a1) 192 + j 64 + b1 16 + b2 4 + b0
-//   [3072, 5376)  rows a2 >= 1, b2 = 0:  3072 + (a0 + 4 a1 + 16 (a2 - 1)) 48 + j 16 + b1 4 + b0
+// Piece of (element, i), 5376 doubles -- what phase 2 reads contiguously (round 5: the pair columns b1 = 2 h, 2 h + 1 ADJACENT, so
+// that a lane of the contraction stores its two values of a pair with one 16-byte store):
+//   [0, 3072)     rows a2 = 0:  (a0 + 4 a1) 192 + j 64 + (b1 / 2) 32 + b2 8 + b0 2 + b1 % 2
+//   [3072, 5376)  rows a2 >= 1, b2 = 0:  3072 + (a0 + 4 a1 + 16 (a2 - 1)) 48 + j 16 + (b1 / 2) 8 + b0 2 + b1 % 2
 // and per (column, i) the tail of its last element, rows a2 >= 1, b2 >= 1:
 //   (a0 + 4 a1 + 16 (a2 - 1)) 144 + j 48 + b1 12 + (b2 - 1) 4 + b0
 __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
@@ -763,9 +764,9 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
     request(es + 1 < n_seq ? es + 1 : es);   // (the last element once more: no branch in the loop)
     const int64_t e = e0 + e_step * es;
     double* piece = p.scratch_k + (e * 3 + I) * (int64_t)T3_PIECE;
-    double* out0 = piece + pa * 192 + J * 64 + kk * 4 + pb;                       // + 4 a1 192 + b1 16
+    double* out0 = piece + pa * 192 + J * 64 + kk * 8 + pb * 2;                   // + 4 a1 192 + (b1 / 2) 32 + b1 % 2
     // lane groups 1..3 hold one final entry with b2 = 0 (register 4 - kk); lane group 0 none
-    double* out1 = piece + 3072 + (pa + 16 * (3 - (kk ? kk : 1))) * 48 + J * 16 + pb;   // + 4 a1 48 + b1 4
+    double* out1 = piece + 3072 + (pa + 16 * (3 - (kk ? kk : 1))) * 48 + J * 16 + pb * 2;   // + 4 a1 48 + (b1 / 2) 8 + b1 % 2
     t3_for(std::make_integer_sequence<int, 4>{}, [&](auto b1_c) {
       constexpr int b1 = decltype(b1_c)::value;
       __builtin_amdgcn_sched_barrier(0);   // one b1 at a time: interleaved they need more registers than there are
@@ -832,10 +833,10 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
         double fin[4];
         t3_finals_in<b1>(fin_addr, fin);
         if (es > 0 && kk > 0) {
-          out1_prev[0 * 4 * 48 + b1 * 4] = fin[0];
-          out1_prev[1 * 4 * 48 + b1 * 4] = fin[1];
-          out1_prev[2 * 4 * 48 + b1 * 4] = fin[2];
-          out1_prev[3 * 4 * 48 + b1 * 4] = fin[3];
+          out1_prev[0 * 4 * 48 + (b1 / 2) * 8 + b1 % 2] = fin[0];
+          out1_prev[1 * 4 * 48 + (b1 / 2) * 8 + b1 % 2] = fin[1];
+          out1_prev[2 * 4 * 48 + (b1 / 2) * 8 + b1 % 2] = fin[2];
+          out1_prev[3 * 4 * 48 + (b1 / 2) * 8 + b1 % 2] = fin[3];
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -860,10 +861,10 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
       // (a2 - 1, b2 - 1): register r -> slot r - 1 of the carry.  Register r >= 1 is stored by the lane group with b2 = 0
       // (under its execution mask: no selects) and written to the carry by every lane; the next element's read skips
       // what the storing lane group wrote (t3_carry_in).
-      out0[0 * 4 * 192 + b1 * 16] = K0[0];
-      out0[1 * 4 * 192 + b1 * 16] = K1[0];
-      out0[2 * 4 * 192 + b1 * 16] = K2[0];
-      out0[3 * 4 * 192 + b1 * 16] = K3[0];
+      out0[0 * 4 * 192 + (b1 / 2) * 32 + b1 % 2] = K0[0];
+      out0[1 * 4 * 192 + (b1 / 2) * 32 + b1 % 2] = K1[0];
+      out0[2 * 4 * 192 + (b1 / 2) * 32 + b1 % 2] = K2[0];
+      out0[3 * 4 * 192 + (b1 / 2) * 32 + b1 % 2] = K3[0];
       t3_for(std::make_integer_sequence<int, 3>{}, [&](auto rr_c) {
         constexpr int r = decltype(rr_c)::value + 1;
         t3_carry_out<b1, r>(cl_addr, K0[r], K1[r], K2[r], K3[r]);   // (every lane: see t3_carry_in, t3_finals_in)
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(64) void tp3_contract_kernel(TensorArgs p) {
 #pragma unroll
     for (int ab = 0; ab < 16; ++ab) {
       const double v = fl[ab * 4 * 64];
-      if (kk > 0) out1_prev[(ab / NB) * 4 * 48 + (ab % NB) * 4] = v;
+      if (kk > 0) out1_prev[(ab / NB) * 4 * 48 + ((ab % NB) / 2) * 8 + (ab % NB) % 2] = v;
     }
   }
   // what the last element of the column would have passed on: rows a2 >= 1, b2 >= 1 -> the tail of (column, i)
@@ -992,8 +993,8 @@ __global__ __launch_bounds__(64) void tp3_contract_asm_kernel(TensorArgs p) {
   // the final entry with b2 = 0 of lane groups 1..3 (register 4 - kk -> slot 3 - kk); lane group 0 has none and doubles
   // lane group 1's (same slot of lane + 16, same destination: the same value stored twice, no execution mask)
   put_int(T3A_P_INT + 11, kk == 0 ? cl_addr + 16u * 8u + 2u * 512u : cl_addr + (unsigned)(3 - kk) * 512u);
-  put_int(T3A_P_INT + 12, 8u * (unsigned)(pa * 192 + J * 64 + kk * 4 + pb));                            // rows a2 = 0: + 4 a1 192 + b1 16
-  put_int(T3A_P_INT + 13, 8u * (unsigned)((pa + 16 * (3 - (kk ? kk : 1))) * 48 + J * 16 + pb));        // rows a2 >= 1, b2 = 0: + 4 a1 48 + b1 4
+  put_int(T3A_P_INT + 12, 8u * (unsigned)(pa * 192 + J * 64 + kk * 8 + pb * 2));                        // rows a2 = 0: + 4 a1 192 + (b1 / 2) 32 (+ b1 % 2)
+  put_int(T3A_P_INT + 13, 8u * (unsigned)((pa + 16 * (3 - (kk ? kk : 1))) * 48 + J * 16 + pb * 2));    // rows a2 >= 1, b2 = 0: + 4 a1 48 + (b1 / 2) 8 (+ b1 % 2)
   put_int(T3A_P_INT + 14, kk == 0 ? 0xffffffffu : 0u);
   put_int(T3A_P_INT + 15, kk == 1 ? 0xffffffffu : 0u);
   const int64_t e0 = eu + (int64_t)p.box_n[0] * ev;
@@ -1008,14 +1009,14 @@ __global__ __launch_bounds__(64) void tp3_contract_asm_kernel(TensorArgs p) {
   // (the loop ends on s_waitcnt vmcnt(0) lgkmcnt(0): the carry of the last element lies in LDS)
   const double* cl = par;
   double* out1_prev = p.scratch_k + ((e0 + e_step * (n_seq - 1)) * 3 + I) * (int64_t)T3_PIECE + 3072 +
-                      (pa + 16 * (3 - (kk ? kk : 1))) * 48 + J * 16 + pb;
+                      (pa + 16 * (3 - (kk ? kk : 1))) * 48 + J * 16 + pb * 2;
   // the b2 = 0 entries of the last element
   {
     const double* fl = cl + (kk == 0 ? 3 : 3 - kk) * 64;
 #pragma unroll
     for (int ab = 0; ab < 16; ++ab) {
       const double v = fl[ab * 4 * 64];
-      if (kk > 0) out1_prev[(ab / NB) * 4 * 48 + (ab % NB) * 4] = v;
+      if (kk > 0) out1_prev[(ab / NB) * 4 * 48 + ((ab % NB) / 2) * 8 + (ab % NB) % 2] = v;
     }
   }
   // what the last element of the column would have passed on: rows a2 >= 1, b2 >= 1 -> the tail of (column, i)
@@ -1068,8 +1069,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int t = lane; t < L; t += 64) img[t] = 0.0;
     // lane = position in a row of a piece.  Rows a2 = 0: [b1][b2][b0] per load, the three loads are j = 0, 1, 2;
     // rows a2 >= 1: [j][b1][b0] (b2 = 0) in one load; tail rows: [b1][b2 - 1][b0] per load, 48 lanes
-    const int toff_full = 3 * ((lane & 3) + w0 * ((lane >> 4) + w1 * ((lane >> 2) & 3)));
-    const int toff_b20 = 3 * ((lane & 3) + w0 * ((lane >> 2) & 3)) + (lane >> 4);
+    // (b1 = 2 (lane >> 5) + (lane & 1), b2 = (lane >> 3) & 3, b0 = (lane >> 1) & 3  |  j = lane >> 4, b1 = 2 ((lane >> 3) & 1) + (lane & 1))
+    const int toff_full = 3 * (((lane >> 1) & 3) + w0 * ((2 * (lane >> 5) + (lane & 1)) + w1 * ((lane >> 3) & 3)));
+    const int toff_b20 = 3 * (((lane >> 1) & 3) + w0 * (2 * ((lane >> 3) & 1) + (lane & 1))) + (lane >> 4);
     const int toff_tail = 3 * ((lane & 3) + w0 * (lane / 12 + w1 * ((lane >> 2) % 3 + 1)));
     const int last_ez = bx2 + p.box_n[2] - 1;
     __builtin_amdgcn_wave_barrier();
