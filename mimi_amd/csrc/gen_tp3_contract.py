@@ -2,24 +2,31 @@
 """Generator of the hand-scheduled column loop of tp3_contract_asm_kernel (csrc/tensor_p3.hip) -> tp3_contract_loop.inc.
 
 What the loop computes is documented at tp3_contract_kernel (the C++ form of the same arithmetic: S1 / S2 / S3, the carry
-along the column); this file only decides WHERE every instruction goes.  The facts it is built on (scratch/issue_bench.hip,
-DESIGN 4.2): on gfx950, with the one 512-register wave per SIMD this kernel runs at, no vector instruction overlaps a
-`v_mfma_f64_16x16x4` (64 cycles) -- but LDS, global-memory and scalar instructions placed directly behind a matrix
-instruction issue in its shadow for free, and cost ~4 issue cycles each anywhere else.  The compiler's schedule of the C++
-form leaves ~540 such instructions, 54 register-file moves and ~140 address computations per block in the vector stretches
-and ends every element with `s_waitcnt vmcnt(0)` right behind its last stores.  Here:
+along the column); this file only decides WHERE every instruction goes and which register holds what.  The facts it is built
+on (scratch/issue_bench.hip): on gfx950, with the one 512-register wave per SIMD this kernel runs at, no vector
+instruction overlaps a `v_mfma_f64_16x16x4` (64 cycles) -- but LDS, global-memory and scalar instructions placed directly
+behind a matrix instruction issue in its shadow, and cost ~4 issue cycles each anywhere else.  The compiler's schedule of
+the C++ form leaves ~540 such instructions, 54 register-file moves and ~140 address computations per block in the vector
+stretches and ends every element with `s_waitcnt vmcnt(0)` right behind its last stores.  Here:
 
-  * every LDS / memory / scalar instruction of the loop sits behind a matrix instruction (1 - 3 per shadow);
+  * every LDS / memory / scalar instruction of the loop sits behind a matrix instruction (a slot scheduler deals them out: at
+    most one global-memory instruction, two LDS instructions and one group of scalar instructions per shadow);
   * the four accumulator tiles are double-buffered (tile set = b1 & 1): the stores and the carry writes of pair column b1
-    go out in the shadows of pair column b1 + 1, the carry reads of b1 + 1 in the shadows of b1's plane instructions;
+    go out in the shadows of pair column b1 + 1, the carry reads of b1 + 1 in the second half of b1's shadows;
+  * the pieces leave with 16-byte stores: the pair columns 2 h, 2 h + 1 are adjacent in a piece row, register 0 of the even
+    pair column's tiles is moved beside the odd one's (8 v_accvgpr_mov per pair), the finals are read from LDS into adjacent
+    registers -- 16 stores per block instead of 32 (a store that meets a full queue holds the wave, which has no second
+    wave behind it: profiles/r05_cfg3_contract_ablations_v*.txt, r05_cfg3_contract_x4_stores.txt);
   * addresses are scalar bases + one per-lane offset register + immediates: no vector address arithmetic in the loop;
   * ONE counted `s_waitcnt vmcnt(N)` per element at the loop top, N = the stores issued behind the last operand load
     (gfx9 has one in-order counter for global loads and stores -- no vscnt --, which is what the compiler's own counted
-    waits rely on; the C++ form ends every element with vmcnt(0) right behind its last stores);
-  * at most one global-memory instruction per shadow: the CU's address unit takes 16 - 21 cycles per wave instruction and
-    serves four waves (two stores in one shadow outlast it: profiles/r05_cfg3_contract_ablations_v1.txt);
+    waits rely on);
+  * the first element of a column has no predecessor to store for: its stand-in stores (zeros) go to its own piece and are
+    overwritten, in order, by the real ones -- no branch in the loop;
   * per value, the floating-point operations and their order are those of tp3_contract_kernel: the sums are bitwise equal
     (tests/test_tensor_p3_gpu.py compares the two kernels).
+
+--drop=store,load,lds,valu,swap,mfma leaves classes of loop instructions out: timing experiments (scratch/p3_asm_variants.sh).
 
 Register map (fixed; the asm statement clobbers exactly these, the compiler keeps v0..v[V0-1], the low SGPRs):
   VGPR  D (S1 results) 144 | E (S2 accumulators; bS2 operands during S1) 32 | W, cb, ca 24 | TA..TD 8 | t2 16 | 19 ints
@@ -146,16 +153,6 @@ class Out:
                    "swap" if op.startswith("v_permlane") else "valu" if op.startswith("v_") else "other")
             if cls in self.drop:
                 return
-        if self.in_loop and "x4probe" in self.drop and op.startswith("global_store"):
-            # timing probe: half as many store instructions, twice as wide (same bytes; the values are not the results)
-            self.n_store = getattr(self, "n_store", 0) + 1
-            if self.n_store % 2:
-                return
-            text = text.replace("global_store_dwordx2", "global_store_dwordx4")
-            import re as _re
-            m = _re.search(r"a\[(\d+):(\d+)\]", text)
-            lo = int(m.group(1)) & ~3
-            text = text.replace(m.group(0), f"a[{lo}:{lo + 3}]")
         self.lines.append(text)
         k = kind or ("mfma" if op.startswith("v_mfma") else "valu" if op.startswith("v_") else
                      "lds" if op.startswith("ds_") else "vmem" if op.startswith("global_") else "salu")
@@ -181,22 +178,6 @@ def mov_bc(dst, table, n):
 
 def mul(dst, x, y):
     return f"v_mul_f64 {v2(dst)}, {v2(x)}, {v2(y)}"
-
-
-def with_shadows(o, mfmas, shadow, per_shadow):
-    """the matrix instructions with the shadow instructions dealt out behind them, `per_shadow` at a time; a shadow
-    instruction may be a list (kept together).  Everything left goes behind the last one."""
-    shadow = list(shadow)
-    for k, m in enumerate(mfmas):
-        o.emit(m)
-        quota = per_shadow if k + 1 < len(mfmas) else len(shadow)
-        n = 0
-        while shadow and n < quota:
-            item = shadow.pop(0)
-            for x in (item if isinstance(item, list) else [item]):
-                o.emit(x)
-            n += 1
-    assert not shadow
 
 
 # ---------------------------------------------------------------- pieces of the schedule
@@ -293,7 +274,7 @@ def finals_store(h):
             for a1 in range(NB)]
 
 
-def stage_even(o, tset_unused=None):
+def stage_even(o):
     """register 0 of the even pair column's four tiles -> beside register 0 of the odd one's (vector instructions: in a vector stretch)"""
     for a1 in range(NB):
         o.emit(f"v_accvgpr_mov_b32 a{STAGE(a1)}, a{TILE(0, a1, 0)}")
@@ -418,8 +399,6 @@ def bs2_operands(o):
 
 def generate(opts=None):
     opts = opts or {}
-    per_s1 = opts.get("per_s1", 2)
-    per_s3 = opts.get("per_s3", 2)
     o = Out(opts.get("drop", ()))
     # ------------------------------------------------------------ prologue: parameters, zero carry, first requests
     o.comment("parameters (LDS slot k at 512 k + 8 lane; %0 = this lane's address of slot 0)")
