@@ -61,6 +61,12 @@ struct Dual {
   double v, d;
 };
 
+MH_DEV double pow_positive(double x, double q);
+
+// material_hardening.hpp:75-77,261-279,326-333.  The homologous temperature's power is the library's pow only where
+// pow_positive (below) is not defined: the library routine is ~ 350 instructions that every lane executes at every point of
+// every assembly -- 8 % of the degree-3 pre-pass's vector instructions in its residual-only mode (round 5) --, and in
+// the virgin state (T = T_ref at every point) it is handed 0, whose powers need no arithmetic at all.
 MH_DEV double thermo_contribution(const MaterialDev& md, double T) {
   const mimi_hip_material& m = md.m;
   if (m.hardening == MIMI_HIP_HARD_JC_TEMP_RATE) {
@@ -69,7 +75,10 @@ MH_DEV double thermo_contribution(const MaterialDev& md, double T) {
     } else if (T > m.melting_temperature) {
       c = 0.0;
     } else {
-      c -= pow((T - m.reference_temperature) / (m.melting_temperature - m.reference_temperature), m.m);
+      const double base = (T - m.reference_temperature) / (m.melting_temperature - m.reference_temperature);   // in [0, 1]
+      if (base > 0.0) c -= pow_positive(base, m.m);
+      else if (base == 0.0) c -= m.m > 0.0 ? 0.0 : (m.m == 0.0 ? 1.0 : __builtin_huge_val());   // pow(0, m)
+      else c -= pow(base, m.m);                                                                // (NaN: as pow answers it)
     }
     return c;
   }
