@@ -61,12 +61,14 @@ struct Dual {
   double v, d;
 };
 
+template<bool SC = false>
 MH_DEV double pow_positive(double x, double q);
 
 // material_hardening.hpp:75-77,261-279,326-333.  The homologous temperature's power is the library's pow only where
 // pow_positive (below) is not defined: the library routine is ~ 350 instructions that every lane executes at every point of
 // every assembly -- 8 % of the degree-3 pre-pass's vector instructions in its residual-only mode (round 5) --, and in
 // the virgin state (T = T_ref at every point) it is handed 0, whose powers need no arithmetic at all.
+template<bool SC = false>
 MH_DEV double thermo_contribution(const MaterialDev& md, double T) {
   const mimi_hip_material& m = md.m;
   if (m.hardening == MIMI_HIP_HARD_JC_TEMP_RATE) {
@@ -76,7 +78,7 @@ MH_DEV double thermo_contribution(const MaterialDev& md, double T) {
       c = 0.0;
     } else {
       const double base = (T - m.reference_temperature) / (m.melting_temperature - m.reference_temperature);   // in [0, 1]
-      if (base > 0.0) c -= pow_positive(base, m.m);
+      if (base > 0.0) c -= pow_positive<SC>(base, m.m);
       else if (base == 0.0) c -= m.m > 0.0 ? 0.0 : (m.m == 0.0 ? 1.0 : __builtin_huge_val());   // pow(0, m)
       else c -= pow(base, m.m);                                                                // (NaN: as pow answers it)
     }
@@ -110,6 +112,26 @@ MH_DEV double rate_contribution_derivative(const mimi_hip_material& m, double ra
 // instructions for the pair.  Error: a few ulp on ln x, hence |q ln x| x 3e-16 + 2e-16 relative on the power -- the
 // conditioning of exp(q ln x) itself; < 1e-14 for the plastic strains that occur (>= 1e-13), far inside the 1e-9
 // (state), 1e-11 (tangent) and 1e-12 (residual) bars the parity tests hold this path to.
+// one Horner step p x + c as ONE vector instruction with the coefficient as an operand of its own.  Written as
+// __builtin_fma the compiler forms the two-operand accumulate v_fmac_f64 and copies every (loop-invariant) coefficient into
+// the accumulator first: two vector instructions per step, 24 copies per call in the return-map Newton (round 5: a
+// quarter of pow_positive's instructions).  SC: the coefficient in a scalar register pair (two s_mov per step, which cost
+// no vector issue) instead of a vector pair held across the Newton loop -- 48 vector registers less, what gives a kernel
+// that parks its tensors (j2_stress, Park) a third / fourth wave per SIMD; without that extra wave the vector form is the
+// faster one (profiles/r05_cfg3_horner_ab.txt).  Same instruction, same operands, same bits either way.
+template<bool SC>
+MH_DEV double horner_step(double p, double x, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r;
+  if constexpr (SC) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(x), "s"(c));
+  else asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(x), "v"(c));
+  return r;
+#else
+  return __builtin_fma(p, x, c);
+#endif
+}
+
+template<bool SC>
 MH_DEV double pow_positive(double x, double q) {
   // arguments outside the range the reduction below is written for, answered as pow() answers them (a diverging
   // return-map Newton can produce them): x = +inf here, |q ln x| beyond the exponent range below
@@ -122,16 +144,16 @@ MH_DEV double pow_positive(double x, double q) {
   }
   const double t = (m - 1.0) / (m + 1.0), t2 = t * t;
   double p = 1.0 / 23.0;
-  p = __builtin_fma(p, t2, 1.0 / 21.0);
-  p = __builtin_fma(p, t2, 1.0 / 19.0);
-  p = __builtin_fma(p, t2, 1.0 / 17.0);
-  p = __builtin_fma(p, t2, 1.0 / 15.0);
-  p = __builtin_fma(p, t2, 1.0 / 13.0);
-  p = __builtin_fma(p, t2, 1.0 / 11.0);
-  p = __builtin_fma(p, t2, 1.0 / 9.0);
-  p = __builtin_fma(p, t2, 1.0 / 7.0);
-  p = __builtin_fma(p, t2, 1.0 / 5.0);
-  p = __builtin_fma(p, t2, 1.0 / 3.0);
+  p = horner_step<SC>(p, t2, 1.0 / 21.0);
+  p = horner_step<SC>(p, t2, 1.0 / 19.0);
+  p = horner_step<SC>(p, t2, 1.0 / 17.0);
+  p = horner_step<SC>(p, t2, 1.0 / 15.0);
+  p = horner_step<SC>(p, t2, 1.0 / 13.0);
+  p = horner_step<SC>(p, t2, 1.0 / 11.0);
+  p = horner_step<SC>(p, t2, 1.0 / 9.0);
+  p = horner_step<SC>(p, t2, 1.0 / 7.0);
+  p = horner_step<SC>(p, t2, 1.0 / 5.0);
+  p = horner_step<SC>(p, t2, 1.0 / 3.0);
   p = __builtin_fma(p * t2, 2.0 * t, 2.0 * t);                      // ln m = 2 t (1 + t^2 p)
   constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const double ed = (double)e;
@@ -145,31 +167,33 @@ MH_DEV double pow_positive(double x, double q) {
   double r = __builtin_fma(-k, ln2_hi, y);
   r = __builtin_fma(-k, ln2_lo, r);
   double c = 1.0 / 6227020800.0;
-  c = __builtin_fma(c, r, 1.0 / 479001600.0);
-  c = __builtin_fma(c, r, 1.0 / 39916800.0);
-  c = __builtin_fma(c, r, 1.0 / 3628800.0);
-  c = __builtin_fma(c, r, 1.0 / 362880.0);
-  c = __builtin_fma(c, r, 1.0 / 40320.0);
-  c = __builtin_fma(c, r, 1.0 / 5040.0);
-  c = __builtin_fma(c, r, 1.0 / 720.0);
-  c = __builtin_fma(c, r, 1.0 / 120.0);
-  c = __builtin_fma(c, r, 1.0 / 24.0);
-  c = __builtin_fma(c, r, 1.0 / 6.0);
-  c = __builtin_fma(c, r, 0.5);
+  c = horner_step<SC>(c, r, 1.0 / 479001600.0);
+  c = horner_step<SC>(c, r, 1.0 / 39916800.0);
+  c = horner_step<SC>(c, r, 1.0 / 3628800.0);
+  c = horner_step<SC>(c, r, 1.0 / 362880.0);
+  c = horner_step<SC>(c, r, 1.0 / 40320.0);
+  c = horner_step<SC>(c, r, 1.0 / 5040.0);
+  c = horner_step<SC>(c, r, 1.0 / 720.0);
+  c = horner_step<SC>(c, r, 1.0 / 120.0);
+  c = horner_step<SC>(c, r, 1.0 / 24.0);
+  c = horner_step<SC>(c, r, 1.0 / 6.0);
+  c = horner_step<SC>(c, r, 0.5);
   c = __builtin_fma(c * r, r, r);                                   // e^r - 1
   return __builtin_ldexp(1.0 + c, (int)k);
 }
 
 // utils/ad.inl:263-279: pow(x, n) = x * x^(n-1), derivative n * x^(n-1) * x'
+template<bool SC = false>
 MH_DEV Dual dual_pow(Dual b, double power) {
-  const double tmp = b.v > 0.0 ? pow_positive(b.v, power - 1.0) : pow(b.v, power - 1.0);
+  const double tmp = b.v > 0.0 ? pow_positive<SC>(b.v, power - 1.0) : pow(b.v, power - 1.0);
   return Dual{b.v * tmp, b.d * (power * tmp)};
 }
 
+template<bool SC = false>
 MH_DEV Dual hardening_evaluate(const mimi_hip_material& m, Dual eqps) {
   switch (m.hardening) {
   case MIMI_HIP_HARD_POWERLAW: {
-    Dual p = dual_pow(Dual{1.0 + eqps.v / m.eps0, eqps.d / m.eps0}, 1.0 / m.n);
+    Dual p = dual_pow<SC>(Dual{1.0 + eqps.v / m.eps0, eqps.d / m.eps0}, 1.0 / m.n);
     return Dual{m.sigma_y * p.v, m.sigma_y * p.d};
   }
   case MIMI_HIP_HARD_VOCE: {
@@ -179,7 +203,7 @@ MH_DEV Dual hardening_evaluate(const mimi_hip_material& m, Dual eqps) {
   }
   default: {
     if (fabs(eqps.v) < 1.e-13) return Dual{m.A, 0.0};
-    Dual p = dual_pow(eqps, m.n);
+    Dual p = dual_pow<SC>(eqps, m.n);
     return Dual{m.A + m.B * p.v, m.B * p.d};
   }
   }
@@ -201,11 +225,13 @@ struct RmPoint {
   double rc;   // rate contribution at x / dt
 };
 
+template<bool SC = false>
 MH_DEV RmPoint rm_eval(const mimi_hip_material& m, const ReturnMapCtx& c, double x) {
   RmPoint e;
   e.x = x;
-  e.H = hardening_evaluate(m, Dual{c.eqps_old + x, 1.0});
-  e.rc = rate_contribution(m, x / c.dt);
+  e.H = hardening_evaluate<SC>(m, Dual{c.eqps_old + x, 1.0});
+  // (the rate x / dt -- a division, 13 instructions in every iteration of the Newton below -- only where a rate term reads it)
+  e.rc = (m.hardening >= MIMI_HIP_HARD_JC_RATE && m.C != 0.0) ? rate_contribution(m, x / c.dt) : 1.0;
   const double fac = e.rc * c.thermo;
   e.R = Dual{c.q - c.slope * x - e.H.v * fac, -c.slope - e.H.d * fac};
   return e;
@@ -213,10 +239,11 @@ MH_DEV RmPoint rm_eval(const mimi_hip_material& m, const ReturnMapCtx& c, double
 
 // solvers/newton.hpp:53-169; status bit 1 = root not bracketed, bit 2 = not converged.  at_lower: the evaluation at
 // `lower`, which the caller already has; the evaluation at the returned x is left in `last`.
+template<bool SC = false>
 MH_DEV double scalar_solve(const mimi_hip_material& m, const ReturnMapCtx& c, const RmPoint& at_lower, double x0, double lower,
                            double upper, double xtol, double rtol, int max_iter, int& status, RmPoint& last) {
   const double fl = at_lower.R.v;
-  last = rm_eval(m, c, upper);
+  last = rm_eval<SC>(m, c, upper);
   const double fh = last.R.v;
   if (fabs(fl) < xtol) {
     last = at_lower;
@@ -237,7 +264,7 @@ MH_DEV double scalar_solve(const mimi_hip_material& m, const ReturnMapCtx& c, co
   double x = x0;
   double delta_x_old = fabs(upper - lower);
   double delta_x = delta_x_old;
-  last = x == lower ? at_lower : rm_eval(m, c, x);
+  last = x == lower ? at_lower : rm_eval<SC>(m, c, x);
   double fval = last.R.v, df_dx = last.R.d;
   bool converged = false;
   int iterations = 0;
@@ -256,7 +283,7 @@ MH_DEV double scalar_solve(const mimi_hip_material& m, const ReturnMapCtx& c, co
       delta_x = fval / df_dx;
       x -= delta_x;
     }
-    last = rm_eval(m, c, x);
+    last = rm_eval<SC>(m, c, x);
     fval = last.R.v;
     df_dx = last.R.d;
     converged = (fabs(delta_x) < xtol) || (fabs(fval) < rtol);
@@ -327,6 +354,7 @@ MH_DEV void neo_hookean_stress(const mimi_hip_material& m, const double* F, Poin
 // but they are live across it (F^-1 and the trial deviator: 36 registers in 3-D); a kernel that wants a third wave per SIMD
 // hands them to LDS for the duration of the solve (tp3_point_kernel, tensor_p3.hip).  NoPark: nothing happens.
 struct NoPark {
+  static constexpr bool scalar_coefficients = false;
   template<int DD> MH_DEV void save(const double (&)[DD], const double (&)[DD]) const {}
   template<int DD> MH_DEV void restore(double (&)[DD], double (&)[DD]) const {}
 };
@@ -366,10 +394,11 @@ MH_DEV int j2_stress(const MaterialDev& md, double dt, const double* F, double* 
   w.delta = 0;
   w.hprime = 0;
 
-  ReturnMapCtx c{eqps, q, thermo_contribution(md, temperature), dt, 3.0 * m.G};
+  constexpr bool SC = Park::scalar_coefficients;     // (horner_step)
+  ReturnMapCtx c{eqps, q, thermo_contribution<SC>(md, temperature), dt, 3.0 * m.G};
   const double tolerance = md.sigma_y_ref * 1.e-10;
   int status = 0;
-  const RmPoint at0 = rm_eval(m, c, 0.0);
+  const RmPoint at0 = rm_eval<SC>(m, c, 0.0);
   const bool yields = at0.R.v > tolerance;
   RmPoint sol;
   double delta = 0.0;
@@ -377,7 +406,7 @@ MH_DEV int j2_stress(const MaterialDev& md, double dt, const double* F, double* 
   if constexpr (ACCUMULATE) park.save(reinterpret_cast<double (&)[DD]>(*ep), s); else park.save(w.Finv, s);
   if (yields) {
     const double upper = (q - at0.H.v * c.thermo) / (3.0 * m.G);
-    delta = scalar_solve(m, c, at0, 0.0, 0.0, upper, 1.e-10, tolerance, 100, status, sol);
+    delta = scalar_solve<SC>(m, c, at0, 0.0, 0.0, upper, 1.e-10, tolerance, 100, status, sol);
   }
   if constexpr (ACCUMULATE) park.restore(reinterpret_cast<double (&)[DD]>(*ep), s); else park.restore(w.Finv, s);
 #pragma unroll

@@ -185,12 +185,17 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
 
 // What the J2 return mapping does not need while it iterates, handed to LDS for its duration (materials.hpp j2_stress, Park):
 // a 3 x 3 tensor (9) and the trial deviator (6: it is symmetric to the bit -- 0.5 (F_ij + F_ji) - ep_ij with ep built from
-// it), [k][128] in the pool behind PH.  Used by the state commit (GRAD 2: plastic strain + deviator): 158 registers instead
+// it), [k][128] in the pool behind PH.  Round 4, the state commit (GRAD 2: plastic strain + deviator): 158 registers instead
 // of 213, a third wave per SIMD, 5.67 -> 4.96 ms at BASELINE configuration 3 (the kernel is latency-bound: ONE wave per
-// SIMD costs 1.75 x, measured).  The assembling modes do not take it: parked (F^-1 + deviator) they need 179 / 181
-// registers, still two waves, and lose 0.3 - 0.4 ms to the detour; capped at 168 they spill 10 - 16 registers inside the
-// solve and gain nothing (profiles/r04_cfg3_prepass_variants.txt).
+// SIMD costs 1.75 x, measured); the residual-only mode parked still needed 179 registers -- two waves -- and lost 0.3 ms to
+// the detour (profiles/r04_cfg3_prepass_variants.txt).  Round 5: 48 of those registers held the coefficients of
+// pow_positive across the Newton loop; with them in scalar registers (scalar_coefficients, materials.hpp horner_step) and the
+// geometry factors read again behind the solve the residual-only mode needs 143 -- three waves per SIMD, 6.42 -> 4.96 ms --
+// and the commit 123 -- four, the LDS pool cut to 18.9 KB (W in PH's place): 4.68 -> 3.73 ms (profiles/r05_cfg3_horner_ab.txt).
+// The residual+Jacobian mode (195 parked) stays unparked with vector coefficients; the residual-only mode capped at 128
+// registers (amdgpu_waves_per_eu(4, 4): 12 spilled) is slower than at 145, 5.03 against 4.75 ms.
 struct T3Park {
+  static constexpr bool scalar_coefficients = true;     // (materials.hpp horner_step: what makes the parked kernels fit)
   double* slot;
   MH_DEV void save(const double (&Finv)[9], const double (&s)[9]) const {
 #pragma unroll
@@ -227,12 +232,16 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
   constexpr int FK = FAMILY >= 2 ? FAMILY : -1;
   __shared__ double ue[3 * ND];
   __shared__ double tab[6 * NB * NQ];       // [dir][B, D][a][q]
-  // one pool: PH | V | W | 300 more.  V, W and the tail are free while the points are evaluated (the grad u stages are done,
-  // the residual stages not begun): the J2 return mapping parks F^-1 and the trial deviator there (T3Park)
-  __shared__ double pool[9 * NPT + 9 * NB * NQ * NQ + 9 * NB * NB * NQ + 300];
+  // one pool: PH = W | V.  W holds the first grad u stage and the second residual stage; PH lives between them (written
+  // behind the point evaluation, dead once the first residual stage has read it), with one row of 128 per (i, m) so that a
+  // lane's entries are its own first nine T3Park slots.  V and the PH rows are free while the points are evaluated: the J2
+  // return mapping parks F^-1 and the trial deviator there (T3Park: 15 rows of 128).  18.9 KB in all: eight workgroups per CU.
+  constexpr int PHS = 128;                  // row stride of PH
+  __shared__ double pool[9 * PHS + 9 * NB * NQ * NQ];
+  static_assert(9 * PHS >= 9 * NB * NB * NQ && 9 * PHS + 9 * NB * NQ * NQ >= 15 * 128, "W and the park rows fit");
   double* PH = pool;                        // Phat [i*3 + m][point]
-  double* V = pool + 9 * NPT;               // [i*3 + m][a2][q0 + 5 q1]
-  double* W = V + 9 * NB * NQ * NQ;         // [i*3 + m][a1 + 4 a2][q0]
+  double* W = pool;                         // [i*3 + m][a1 + 4 a2][q0]
+  double* V = pool + 9 * PHS;               // [i*3 + m][a2][q0 + 5 q1]
   const int tid = threadIdx.x;
   const int64_t e = blockIdx.x;
   int el[3];
@@ -292,13 +301,14 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
         H[i * 3 + k] = sv;
       }
   }
-  if constexpr (GRAD == 2) __syncthreads();      // (V and W are free from here on: T3Park)
+  constexpr bool PARK = FAMILY == 0 && (GRAD == 2 || GRAD == 0);
+  if constexpr (PARK) __syncthreads();           // (V and W are free from here on: T3Park)
   if (tid < NPT) {
     const double* g = p.geo + e * 10 * NPT + tid;
     double Ji[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) Ji[k] = g[(int64_t)k * NPT];
-    const double wd = g[(int64_t)9 * NPT];
+    double wd = g[(int64_t)9 * NPT];
     double F[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
     if constexpr (GRAD == 2) {
       int st;
       if constexpr (FAMILY != 0) st = accumulate_other<3, FK>(p.mat, p.dt, p.state, e * NPT + tid, F);
-      else st = accumulate_state<3>(p.mat, p.dt, p.state, e * NPT + tid, F, T3Park{V + tid});
+      else st = accumulate_state<3>(p.mat, p.dt, p.state, e * NPT + tid, F, T3Park{pool + tid});
       if (st) atomicOr(p.status, st);
       return;
     }
@@ -360,7 +370,16 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
       status = evaluate_other<3, FK>(p.mat, p.dt, p.state, e * NPT + tid, F, Pk, nullptr, 1.0);
     } else {
       PointResult<3> w;
-      status = evaluate_pk1<3>(p.mat, p.dt, p.state, e * NPT + tid, F, w);
+      if constexpr (PARK) {
+        status = evaluate_pk1<3>(p.mat, p.dt, p.state, e * NPT + tid, F, w, T3Park{pool + tid});
+        // (the geometry factors are not held across the return mapping either: read again, from the cache)
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Ji[k] = g[(int64_t)k * NPT];
+        wd = g[(int64_t)9 * NPT];
+      } else {
+        status = evaluate_pk1<3>(p.mat, p.dt, p.state, e * NPT + tid, F, w);
+      }
 #pragma unroll
       for (int k = 0; k < 9; ++k) Pk[k] = w.P[k];
       if constexpr (GRAD == 1) t3_closed_form_record(p.mat.m, w, Ji, wd, p.scratch_pt + e * (int64_t)(T3_REC * PS), tid);
@@ -373,7 +392,7 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
         double t = 0.0;
 #pragma unroll
         for (int J = 0; J < 3; ++J) t += Pk[i + J * 3] * Ji[m * 3 + J];
-        PH[(i * 3 + m) * NPT + tid] = wd * t;
+        PH[(i * 3 + m) * PHS + tid] = wd * t;
       }
   }
   if constexpr (GRAD == 2) return;
@@ -384,7 +403,7 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
     const double* T2 = tab_ptr<3>(tab, 2, m == 2 ? 1 : 0) + a2 * NQ;
     double sv = 0.0;
 #pragma unroll
-    for (int q2 = 0; q2 < NQ; ++q2) sv += T2[q2] * PH[im * NPT + q01 + NQ * NQ * q2];
+    for (int q2 = 0; q2 < NQ; ++q2) sv += T2[q2] * PH[im * PHS + q01 + NQ * NQ * q2];
     V[t] = sv;
   }
   __syncthreads();
