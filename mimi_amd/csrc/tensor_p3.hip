@@ -261,28 +261,62 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
   __syncthreads();
   // grad_xi u at the 125 points by sum factorisation, one direction per stage through LDS (V and W are free until the
   // residual rows below): 9 x 4 multiply-adds per point and ~45 per lane in the two stages before, instead of 64 nodes
-  // x 12 per point (the direct sum was a sixth of this kernel's vector instructions)
+  // x 12 per point (the direct sum was a sixth of this kernel's vector instructions).
+  // Lane -> output maps of the stages (here and in the residual stages below): a lane owns ONE combination of the two
+  // indices that are not summed and not a tensor component, reads its table values once and walks the components with
+  // compile-time offsets.  (Round 5; before, the stages were loops t = tid, tid + 128, .. over the flat output index: 20 -
+  // 30 integer instructions of index arithmetic around the 4 - 5 multiply-adds of every output, a fifth of the kernel's
+  // vector instructions.  80 - 100 of the 128 lanes are busy now instead of all, at a third of the instructions; the sums
+  // run in the same order: same bits.)
   {
     double* SA = W;   // [variant of direction 0: B, D][i][q0][a1 + 4 a2]
     double* SB = V;   // [D0 B1, B0 D1, B0 B1][i][q0 + 5 q1][a2]
-    for (int t = tid; t < 2 * 3 * NQ * NB * NB; t += 128) {
-      const int a12 = t & 15, r = t >> 4, q0 = r % NQ, vi = r / NQ;
-      const double* T = tab_ptr<3>(tab, 0, vi / 3) + q0;
-      const double* U = ue + (vi % 3) * ND + NB * a12;
-      double sv = 0.0;
+    if (tid < NQ * NB * NB) {
+      const int a12 = tid & 15, q0 = tid >> 4;
+      double T[2][NB];
 #pragma unroll
-      for (int a0 = 0; a0 < NB; ++a0) sv += T[a0 * NQ] * U[a0];
-      SA[t] = sv;
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int a0 = 0; a0 < NB; ++a0) T[v][a0] = tab_ptr<3>(tab, 0, v)[a0 * NQ + q0];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double* U = ue + i * ND + NB * a12;
+        double u4[NB];
+#pragma unroll
+        for (int a0 = 0; a0 < NB; ++a0) u4[a0] = U[a0];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          double sv = 0.0;
+#pragma unroll
+          for (int a0 = 0; a0 < NB; ++a0) sv = __builtin_fma(T[v][a0], u4[a0], sv);
+          SA[(v * 3 + i) * (NQ * NB * NB) + tid] = sv;
+        }
+      }
     }
     __syncthreads();
-    for (int t = tid; t < 3 * 3 * NQ * NQ * NB; t += 128) {
-      const int a2 = t & 3, r = t >> 2, q01 = r % (NQ * NQ), wi = r / (NQ * NQ), w = wi / 3, i = wi % 3;
-      const double* T = tab_ptr<3>(tab, 1, w == 1 ? 1 : 0) + q01 / NQ;
-      const double* S = SA + (((w == 0 ? 1 : 0) * 3 + i) * NQ + q01 % NQ) * (NB * NB) + NB * a2;
-      double sv = 0.0;
+    if (tid < NQ * NQ * NB) {
+      const int a2 = tid & 3, q01 = tid >> 2, q0 = q01 % NQ, q1 = q01 / NQ;
+      double T[2][NB];
 #pragma unroll
-      for (int a1 = 0; a1 < NB; ++a1) sv += T[a1 * NQ] * S[a1];
-      SB[t] = sv;
+      for (int v = 0; v < 2; ++v)
+#pragma unroll
+        for (int a1 = 0; a1 < NB; ++a1) T[v][a1] = tab_ptr<3>(tab, 1, v)[a1 * NQ + q1];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        double sB[NB], sD[NB];   // the first stage's sums with the direction-0 values / derivatives
+#pragma unroll
+        for (int a1 = 0; a1 < NB; ++a1) {
+          sB[a1] = SA[((0 * 3 + i) * NQ + q0) * (NB * NB) + NB * a2 + a1];
+          sD[a1] = SA[((1 * 3 + i) * NQ + q0) * (NB * NB) + NB * a2 + a1];
+        }
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          double sv = 0.0;
+#pragma unroll
+          for (int a1 = 0; a1 < NB; ++a1) sv = __builtin_fma(T[w == 1 ? 1 : 0][a1], w == 0 ? sD[a1] : sB[a1], sv);
+          SB[(w * 3 + i) * (NQ * NQ * NB) + tid] = sv;
+        }
+      }
     }
     __syncthreads();
   }
@@ -397,36 +431,57 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
   }
   if constexpr (GRAD == 2) return;
   __syncthreads();
-  // element residual pieces R_i[a] = sum_q sum_m dN_a/dxi_m Phat_i[m], one direction at a time
-  for (int t = tid; t < 9 * NB * NQ * NQ; t += 128) {
-    const int q01 = t % (NQ * NQ), a2 = (t / (NQ * NQ)) % NB, im = t / (NB * NQ * NQ), m = im % 3;
-    const double* T2 = tab_ptr<3>(tab, 2, m == 2 ? 1 : 0) + a2 * NQ;
-    double sv = 0.0;
+  // element residual pieces R_i[a] = sum_q sum_m dN_a/dxi_m Phat_i[m], one direction at a time (lane -> output maps as in
+  // the grad u stages above)
+  if (tid < NB * NQ * NQ) {
+    const int q01 = tid % (NQ * NQ), a2 = tid / (NQ * NQ);
+    double T[2][NQ];
 #pragma unroll
-    for (int q2 = 0; q2 < NQ; ++q2) sv += T2[q2] * PH[im * PHS + q01 + NQ * NQ * q2];
-    V[t] = sv;
-  }
-  __syncthreads();
-  for (int t = tid; t < 9 * NB * NB * NQ; t += 128) {
-    const int q0 = t % NQ, a12 = (t / NQ) % (NB * NB), im = t / (NB * NB * NQ), m = im % 3;
-    const int a1 = a12 % NB, a2 = a12 / NB;
-    const double* T1 = tab_ptr<3>(tab, 1, m == 1 ? 1 : 0) + a1 * NQ;
-    double sw = 0.0;
+    for (int v = 0; v < 2; ++v)
 #pragma unroll
-    for (int q1 = 0; q1 < NQ; ++q1) sw += T1[q1] * V[(im * NB + a2) * NQ * NQ + q0 + NQ * q1];
-    W[t] = sw;
-  }
-  __syncthreads();
-  for (int t = tid; t < 3 * ND; t += 128) {
-    const int a = t % ND, i = t / ND, a0 = a % NB, a12 = a / NB;
-    double sr = 0.0;
+      for (int q2 = 0; q2 < NQ; ++q2) T[v][q2] = tab_ptr<3>(tab, 2, v)[a2 * NQ + q2];
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const double* T0 = tab_ptr<3>(tab, 0, m == 0 ? 1 : 0) + a0 * NQ;
+    for (int im = 0; im < 9; ++im) {
+      double sv = 0.0;
 #pragma unroll
-      for (int q0 = 0; q0 < NQ; ++q0) sr += T0[q0] * W[((i * 3 + m) * NB * NB + a12) * NQ + q0];
+      for (int q2 = 0; q2 < NQ; ++q2) sv = __builtin_fma(T[im % 3 == 2 ? 1 : 0][q2], PH[im * PHS + q01 + NQ * NQ * q2], sv);
+      V[im * (NB * NQ * NQ) + tid] = sv;
     }
-    p.scratch_r[(e * 3 + i) * ND + a] = sr;
+  }
+  __syncthreads();
+  if (tid < NB * NB * NQ) {
+    const int q0 = tid % NQ, a12 = tid / NQ, a1 = a12 % NB, a2 = a12 / NB;
+    double T[2][NQ];
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int q1 = 0; q1 < NQ; ++q1) T[v][q1] = tab_ptr<3>(tab, 1, v)[a1 * NQ + q1];
+#pragma unroll
+    for (int im = 0; im < 9; ++im) {
+      double sw = 0.0;
+#pragma unroll
+      for (int q1 = 0; q1 < NQ; ++q1) sw = __builtin_fma(T[im % 3 == 1 ? 1 : 0][q1], V[(im * NB + a2) * NQ * NQ + q0 + NQ * q1], sw);
+      W[im * (NB * NB * NQ) + tid] = sw;
+    }
+  }
+  __syncthreads();
+  {
+    // (the first wave takes components 0 and 1, the second component 2)
+    const int a = tid & (ND - 1), a0 = a % NB, a12 = a / NB;
+    double T[2][NQ];
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int q0 = 0; q0 < NQ; ++q0) T[v][q0] = tab_ptr<3>(tab, 0, v)[a0 * NQ + q0];
+    const int i_begin = tid < ND ? 0 : 2, i_end = tid < ND ? 2 : 3;
+    for (int i = i_begin; i < i_end; ++i) {
+      double sr = 0.0;
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int q0 = 0; q0 < NQ; ++q0) sr = __builtin_fma(T[m == 0 ? 1 : 0][q0], W[((i * 3 + m) * NB * NB + a12) * NQ + q0], sr);
+      p.scratch_r[(e * 3 + i) * ND + a] = sr;
+    }
   }
 }
 
