@@ -99,3 +99,22 @@ for lo, hi in zip(edges[:-1], edges[1:]):
     if m.any():
         print("  overstress (%g, %g]: %5.1f %% of the points, evaluations mean %.1f min %d max %d" % (lo, hi, 100 * m.mean(), ye[m].mean(), ye[m].min(), ye[m].max()))
 np.save("/tmp/rm_evals.npy", ev); np.save("/tmp/rm_key.npy", key)
+
+# round 5, second idea: every lane iterates K times where it is; the points not converged by then ("stragglers") are collected
+# over the workgroup (g elements) and finished packed into as few waves as they fill
+its = np.maximum(ev - 2, 0)            # loop iterations (evaluations minus the two before the loop)
+print("iterations per point: mean %.2f; histogram" % its.mean(), np.bincount(its.reshape(-1))[:40])
+for g in (1, 2, 4):
+    for K in (4, 5, 6, 7, 8):
+        tot = 0; groups = 0
+        for e0 in range(0, ne - ne % g, g):
+            a = its[e0:e0 + g].reshape(-1)
+            nw = 2 * g
+            first = sum(min(K, waves(its[e0 + k]).max() if False else 0) for k in range(0))  # (unused)
+            # phase 1: each wave runs min(K, its max) iterations
+            p1 = sum(np.minimum(waves(its[e0 + k]), K).sum() for k in range(g))
+            rest = np.sort(np.maximum(a - K, 0))[::-1]
+            rest = rest[rest > 0]
+            p2 = waves(rest).sum() if rest.size else 0      # packed, longest first
+            tot += p1 + p2; groups += 1
+        print("  %d element(s) per workgroup, K = %d: %.1f wave-iterations per element (shipped: %.1f)" % (g, K, tot / groups / g, sum(waves(its[e]).sum() for e in range(ne)) / ne))
