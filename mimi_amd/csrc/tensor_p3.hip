@@ -258,6 +258,18 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
     const int span = p.box_begin[dir] + el[dir];
     tab[tid] = ((isD ? p.tabD[dir] : p.tabB[dir]) + (int64_t)span * NB * NQ)[k];
   }
+  // the geometry factors of the lane's point, requested now in the residual-only mode: they are first used three barriers
+  // further down, and a load is not moved up across a barrier -- their round trip to memory would start only there
+  // (4.375 -> 4.30 ms; the commit would pay with its fourth wave per SIMD, 123 -> 143 registers, 3.43 -> 3.85 ms, and the
+  // residual+Jacobian mode gains nothing: profiles/r05_cfg3_horner_ab.txt)
+  const double* g = p.geo + e * 10 * NPT + (tid < NPT ? tid : 0);
+  double Ji[9], wd;
+  constexpr bool EARLY_GEO = GRAD == 0;
+  if constexpr (EARLY_GEO) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ji[k] = g[(int64_t)k * NPT];
+    wd = g[(int64_t)9 * NPT];
+  }
   __syncthreads();
   // grad_xi u at the 125 points by sum factorisation, one direction per stage through LDS (V and W are free until the
   // residual rows below): 9 x 4 multiply-adds per point and ~45 per lane in the two stages before, instead of 64 nodes
@@ -338,11 +350,11 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
   constexpr bool PARK = FAMILY == 0 && (GRAD == 2 || GRAD == 0);
   if constexpr (PARK) __syncthreads();           // (V and W are free from here on: T3Park)
   if (tid < NPT) {
-    const double* g = p.geo + e * 10 * NPT + tid;
-    double Ji[9];
+    if constexpr (!EARLY_GEO) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Ji[k] = g[(int64_t)k * NPT];
-    double wd = g[(int64_t)9 * NPT];
+      for (int k = 0; k < 9; ++k) Ji[k] = g[(int64_t)k * NPT];
+      wd = g[(int64_t)9 * NPT];
+    }
     double F[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
