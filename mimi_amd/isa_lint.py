@@ -250,6 +250,33 @@ def spill_counts(asm):
     return out
 
 
+def kernel_resources(asm):
+    """{kernel name: {"vgpr", "agpr", "lds", "spill"}} from the code-object metadata (what decides the waves per SIMD: 512
+    registers per lane and SIMD, 160 KB of LDS per CU on gfx950)"""
+    out = {}
+    md = asm[asm.index("amdhsa.kernels"):] if "amdhsa.kernels" in asm else ""
+    for ent in md.split("  - .agpr_count")[1:]:
+        ent = ".agpr_count" + ent
+        get = lambda key: re.search(r"\.%s:\s*(\S+)" % key, ent)
+        name = get("name")
+        if not name:
+            continue
+        out[name.group(1)] = {"agpr": int(get("agpr_count").group(1)), "vgpr": int(get("vgpr_count").group(1)),
+                              "lds": int(get("group_segment_fixed_size").group(1)), "spill": int(get("vgpr_spill_count").group(1))}
+    return out
+
+
+def waves_per_simd(res, threads_per_workgroup):
+    """resident waves per SIMD a kernel's registers and LDS allow (gfx950: 512 registers per lane, allocated in blocks of 8;
+    160 KB LDS per CU; at most 8 waves per SIMD)"""
+    regs = -(-max(res["vgpr"], 1) // 8) * 8
+    by_regs = min(8, 512 // regs)
+    waves_per_wg = max(1, threads_per_workgroup // 64)
+    wgs_by_lds = (160 * 1024) // res["lds"] if res["lds"] else 10 ** 6
+    by_lds = wgs_by_lds * waves_per_wg / 4.0
+    return min(by_regs, by_lds)
+
+
 _PROBE = r"""
 #include <hip/hip_runtime.h>
 typedef double d4 __attribute__((ext_vector_type(4)));

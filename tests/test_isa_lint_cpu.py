@@ -129,6 +129,27 @@ def test_no_shipped_kernel_spills_more_than_a_handful_of_registers():
     assert max(worst.values(), default=0) < 64, sorted(worst.items(), key=lambda t: -t[1])[:5]
 
 
+def test_the_degree3_prepass_kernels_keep_their_waves_per_simd():
+    """Round 5: the J2 modes of the degree-3 pre-pass are bound by the latency of the return-map iteration at the occupancy
+    their registers and LDS allow: the residual-only mode runs at three waves per SIMD (145 of <= 168
+    registers: F^-1 and the deviator parked, the coefficients of pow_positive in scalar registers), the state commit at four
+    (123 of <= 128), both with the 18.9 KB LDS pool (eight workgroups per CU).  An unrelated edit moved the commit from 123
+    to 143 registers in this round (3.43 -> 3.85 ms) without a test noticing: this is that test."""
+    res = L.kernel_resources(L.assembly("tensor_p3.hip"))
+    def one(tag):
+        names = [n for n in res if "tp3_point_kernelILi0ELi%d" % tag in n]
+        assert len(names) == 1, names
+        return res[names[0]]
+    for tag, waves in ((0, 3), (2, 4), (1, 2)):          # residual-only, commit, residual+Jacobian
+        r = one(tag)
+        assert r["spill"] == 0, (tag, r)
+        assert L.waves_per_simd(r, 128) >= waves, (tag, r, L.waves_per_simd(r, 128))
+    gather = [res[n] for n in res if "tp3_gather_kernelILi1" in n]
+    assert len(gather) == 1 and L.waves_per_simd(gather[0], 256) >= 4, gather
+    contract = [res[n] for n in res if "tp3_contract_asm_kernel" in n]
+    assert len(contract) == 1 and contract[0]["spill"] == 0 and contract[0]["vgpr"] <= 512, contract
+
+
 def test_the_generated_contraction_loop_is_current_and_waits_for_what_it_uses():
     """csrc/tp3_contract_loop.inc is generated (csrc/gen_tp3_contract.py): the committed file must be what the generator
     emits, and the generator's own walk over prologue + three unrolled elements + flush must find every register a memory
