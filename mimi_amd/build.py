@@ -41,7 +41,9 @@ def build(force=False, verbose=False, extra_flags=()):
 # kernels whose inline-asm matrix / DPP instructions nothing in the compiler pads: linted at the disassembly level (isa_lint.py)
 # as part of the build -- same compiler, same flags, the very assembly that went into the object (a compiler
 # bump or an unrelated edit must not ship a stale-result hazard because a test was not run)
-LINT_GATE = {"tensor_p3.hip": ["tp3_contract_kernel", "tp3_contract_asm_kernel"], "domain.hip": ["tensor_residual_col_kernel"]}
+LINT_GATE = {"tensor_p3.hip": ["tp3_contract_kernel", "tp3_contract_asm_kernel", "tp3_point_kernelILi0ELi0", "tp3_point_kernelILi0ELi1",
+                               "tp3_point_kernelILi0ELi2"],
+             "domain.hip": ["tensor_residual_col_kernel"]}
 
 
 def lint_gate(rebuilt, objdir, verbose=False):

@@ -151,6 +151,10 @@ def is_valu(ins):
     return ins.op.startswith("v_") and not is_mfma(ins)
 
 
+def is_trans(ins):
+    return ins.op.startswith(("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_"))
+
+
 def is_mem(ins):
     return ins.op.startswith(("global_", "buffer_", "flat_", "scratch_", "ds_"))
 
@@ -180,7 +184,8 @@ def lint_kernel(instrs, need, asm_only=False):
     Returns (violations, statistics)."""
     bad = []
     stats = {"mfma": 0, "mfma_from_asm": 0, "nearest_valu_read": None, "nearest_valu_write": None, "nearest_mem": None,
-             "nearest_mfma_ab": None, "nearest_exec_write": None, "nearest_valu_def": None, "nearest_dpp_def": None}
+             "nearest_mfma_ab": None, "nearest_exec_write": None, "nearest_valu_def": None, "nearest_dpp_def": None,
+             "nearest_trans_use": None, "valu_from_asm": 0}
 
     def note(key, dist):
         if stats[key] is None or dist < stats[key]:
@@ -220,6 +225,14 @@ def lint_kernel(instrs, need, asm_only=False):
                         check(ins, other, dist, "nearest_valu_write", need["valu_write"], "result overwritten by a vector instruction")
         elif is_valu(ins) and _vec(ins.defs):
             w = _vec(ins.defs)
+            stats["valu_from_asm"] += ins.from_asm
+            if is_trans(ins):
+                # (the compiler's own consumers are padded by its hazard recogniser; an inline-asm consumer is not)
+                for j, dist in _walk(instrs, i, 4):
+                    other = instrs[j]
+                    if other.from_asm and is_valu(other) and not is_trans(other) and _vec(other.uses) & w:
+                        check(ins, other, dist, "nearest_trans_use", need.get("trans_use", 1),
+                              "asm vector instruction reads the result of a transcendental-unit instruction")
             for j, dist in _walk(instrs, i, 4 * max(need["valu_def"], need["dpp_def"])):
                 other = instrs[j]
                 if is_mfma(other) and _vec(other.uses) & w and (other.from_asm or not asm_only):
@@ -333,6 +346,9 @@ def calibrate():
             "valu_write": 11,
             # vector write -> DPP read of the same register: 2 wait states (the ISA's rule for every DPP instruction)
             "dpp_def": 2,
+            # result of a transcendental-unit instruction (v_rcp / v_rsq / v_sqrt / v_exp / v_log / v_sin / v_cos) read by an
+            # ordinary vector instruction: one wait state on gfx940+ (LLVM pads its own instructions; not inline asm ones)
+            "trans_use": 1,
             "exec_valu": 4, "exec_salu": 8}
     return need
 

@@ -129,6 +129,67 @@ def test_no_shipped_kernel_spills_more_than_a_handful_of_registers():
     assert max(worst.values(), default=0) < 64, sorted(worst.items(), key=lambda t: -t[1])[:5]
 
 
+def test_horner_steps_from_inline_asm_never_read_a_transcendental_result_directly(need):
+    """Round 5: pow_positive's Horner steps are `v_fma_f64` from inline asm (csrc/materials.hpp horner_step) -- instructions
+    the compiler's hazard recogniser does not look into.  The one hazard that applies to an ordinary vector instruction on
+    gfx940+ is the transcendental-unit forwarding one: a result of v_rcp / v_rsq / v_sqrt / v_exp / v_log read by a
+    non-transcendental vector instruction needs one wait state.  By construction the operands of a Horner step come from
+    multiplies, multiply-adds and moves; the lint checks it on the shipped J2 kernels of the degree-3 pre-pass (189 asm vector
+    instructions each: nine inlined calls) and is part of the build's gate for them.  Red case: the same stream with a v_rcp_f64
+    writing a Horner step's operand right in front of it is flagged, and with one instruction in between it is not."""
+    asm = L.assembly("tensor_p3.hip")
+    for tag in (0, 1, 2):
+        instrs = L.parse_kernel(asm, "tp3_point_kernelILi0ELi%d" % tag)
+        bad, stats = L.lint_kernel(instrs, need, asm_only=True)
+        assert not bad, bad[:5]
+        assert stats["valu_from_asm"] >= 150 and (stats["nearest_trans_use"] is None or stats["nearest_trans_use"] >= need["trans_use"])
+    steps = [k for k, x in enumerate(instrs) if x.from_asm and x.op == "v_fma_f64"]
+
+    def mutated(pad):
+        out = []
+        k = steps[0]
+        x = instrs[k]
+        out.extend(instrs[:k])
+        w = L.Instr()
+        src = x.operands[1]
+        w.op, w.text, w.line, w.from_asm = "v_rcp_f64_e32", f"v_rcp_f64_e32 {src}, {src}", x.line, False
+        w.operands = [src, src]
+        w.defs = w.uses = L._regs(src)
+        w.nop, w.target = 1, None
+        out.append(w)
+        for _ in range(pad):
+            n = L.Instr()
+            n.op, n.text, n.line, n.from_asm, n.operands = "s_nop", "s_nop 0", x.line, False, ["0"]
+            n.defs, n.uses, n.nop, n.target = set(), set(), 1, None
+            out.append(n)
+        out.extend(instrs[k:steps[1]])
+        for y in out:
+            y.target = None
+        return out
+    bad, stats = L.lint_kernel(mutated(0), need, asm_only=True)
+    assert len([b for b in bad if "transcendental" in b[4]]) == 1 and stats["nearest_trans_use"] == 0
+    bad, stats = L.lint_kernel(mutated(1), need, asm_only=True)
+    assert not [b for b in bad if "transcendental" in b[4]]
+
+
+def test_every_kernel_with_asm_horner_steps_passes_the_lint(need):
+    """The same rule over every kernel of the other translation units that inlines pow_positive (the degree-2 J2 kernels, the
+    general path, the other materials: ~ 77 kernels, 16 000 asm vector instructions) -- about a minute."""
+    import re
+    n_kernels = n_asm = 0
+    for src in ("domain.hip", "contact.hip"):
+        asm = L.assembly(src)
+        for name in re.findall(r"^(_Z\w+):", asm, re.M):
+            instrs = L.parse_kernel(asm, name)
+            if not any(x.from_asm and x.op == "v_fma_f64" for x in instrs):
+                continue
+            bad, stats = L.lint_kernel(instrs, need, asm_only=True)
+            assert not [b for b in bad if "transcendental" in b[4]], (name, bad[:3])
+            n_kernels += 1
+            n_asm += stats["valu_from_asm"]
+    assert n_kernels >= 40 and n_asm >= 5000, (n_kernels, n_asm)
+
+
 def test_the_degree3_prepass_kernels_keep_their_waves_per_simd():
     """Round 5: the J2 modes of the degree-3 pre-pass are bound by the latency of the return-map iteration at the occupancy
     their registers and LDS allow: the residual-only mode runs at three waves per SIMD (145 of <= 168
