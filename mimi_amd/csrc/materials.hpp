@@ -67,7 +67,8 @@ MH_DEV double pow_positive(double x, double q);
 // material_hardening.hpp:75-77,261-279,326-333.  The homologous temperature's power is the library's pow only where
 // pow_positive (below) is not defined: the library routine is ~ 350 instructions that every lane executes at every point of
 // every assembly -- 8 % of the degree-3 pre-pass's vector instructions in its residual-only mode (round 5) --, and in
-// the virgin state (T = T_ref at every point) it is handed 0, whose powers need no arithmetic at all.
+// the virgin state (T = T_ref at every point) it is handed 0, whose powers need no arithmetic at all.  (No call of the
+// library's pow is left in this file: see pow_any.)
 template<bool SC = false>
 MH_DEV double thermo_contribution(const MaterialDev& md, double T) {
   const mimi_hip_material& m = md.m;
@@ -80,7 +81,7 @@ MH_DEV double thermo_contribution(const MaterialDev& md, double T) {
       const double base = (T - m.reference_temperature) / (m.melting_temperature - m.reference_temperature);   // in [0, 1]
       if (base > 0.0) c -= pow_positive<SC>(base, m.m);
       else if (base == 0.0) c -= m.m > 0.0 ? 0.0 : (m.m == 0.0 ? 1.0 : __builtin_huge_val());   // pow(0, m)
-      else c -= pow(base, m.m);                                                                // (NaN: as pow answers it)
+      else c -= m.m == 0.0 ? 1.0 : base;                                                       // (base is NaN here: as pow answers it)
     }
     return c;
   }
@@ -182,10 +183,32 @@ MH_DEV double pow_positive(double x, double q) {
   return __builtin_ldexp(1.0 + c, (int)k);
 }
 
+// x^q for any x, as pow() answers it, WITHOUT the library routine: a return-map equation only ever asks for powers of a
+// positive base (accumulated plastic strain + the increment, which the bracket keeps >= 0; 1 + strain / eps0), but the
+// other cases must be answered, and the library's pow -- inlined into every kernel that evaluates a hardening law: ~ 230
+// instructions and 25 registers at each of nine call sites -- was what set the register count of the degree-3 pre-pass
+// (residual-only mode 145 -> 120 registers, a fourth wave per SIMD; commit 123 -> 98; 6 745 -> 4 795 instructions; round 5).
+// Zero: pow's limits; negative base: +- |x|^q for an integer q (|x|^q by pow_positive: a few ulp, where the library rounds
+// correctly), NaN otherwise; q = 0: 1.
+template<bool SC = false>
+MH_DEV double pow_any(double x, double q) {
+  const double r = pow_positive<SC>(__builtin_fabs(x), q);     // (one inlined copy serves the negative bases too)
+  if (x > 0.0) return r;
+  if (q == 0.0) return 1.0;
+  const bool integer = q == __builtin_rint(q);
+  const bool odd = integer && (0.5 * q != __builtin_rint(0.5 * q));
+  if (x == 0.0) {
+    const double z = q < 0.0 ? __builtin_huge_val() : 0.0;
+    return odd ? __builtin_copysign(z, x) : z;
+  }
+  if (x < 0.0 && integer) return odd ? -r : r;
+  return __builtin_nan("");
+}
+
 // utils/ad.inl:263-279: pow(x, n) = x * x^(n-1), derivative n * x^(n-1) * x'
 template<bool SC = false>
 MH_DEV Dual dual_pow(Dual b, double power) {
-  const double tmp = b.v > 0.0 ? pow_positive<SC>(b.v, power - 1.0) : pow(b.v, power - 1.0);
+  const double tmp = pow_any<SC>(b.v, power - 1.0);
   return Dual{b.v * tmp, b.d * (power * tmp)};
 }
 
