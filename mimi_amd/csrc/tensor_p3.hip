@@ -148,9 +148,10 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
     hG[k] = hbw * G[k];
     hN[k] = hbw * N[k];
   }
+  // (S and Ts of all three i first: the stress and the deviator are dead before the 81 entries are formed)
+  double S[9], Ts[9];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    double S[3], Ts[3], KG[3];
+  for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
       double a = 0.0, b = 0.0;
@@ -159,10 +160,16 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
         a += w.sigma[i + k * 3] * G[m * 3 + k];
         b += w.s_trial[i + k * 3] * G[m * 3 + k];
       }
-      S[m] = wdJ * a;
-      Ts[m] = ggw * b;
-      KG[m] = Kw * G[m * 3 + i];
+      S[i * 3 + m] = wdJ * a;
+      Ts[i * 3 + m] = ggw * b;
     }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(S[k]), "+v"(Ts[k]));
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double KG[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) KG[m] = Kw * G[m * 3 + i];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       double blk[9];
@@ -170,12 +177,12 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
       for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
-          double v = G[n * 3 + j] * S[m];
-          v = __builtin_fma(-G[m * 3 + j], S[n], v);
+          double v = G[n * 3 + j] * S[i * 3 + m];
+          v = __builtin_fma(-G[m * 3 + j], S[i * 3 + n], v);
           v = __builtin_fma(KG[m], Ji[n * 3 + j], v);
           v = __builtin_fma(hG[m * 3 + j], Ji[n * 3 + i], v);
           if (i == j) v += hN[m * 3 + n];
-          v = __builtin_fma(-Ts[m], Q[n * 3 + j], v);
+          v = __builtin_fma(-Ts[i * 3 + m], Q[n * 3 + j], v);
           blk[m * 3 + n] = v;
         }
       t3_store_block_at(rec + t3_rec_block(i, j), pt, blk);
@@ -192,8 +199,9 @@ MH_DEV void t3_closed_form_record(const mimi_hip_material& mm, const PointResult
 // pow_positive across the Newton loop; with them in scalar registers (scalar_coefficients, materials.hpp horner_step) and the
 // geometry factors read again behind the solve the residual-only mode needs 143 -- three waves per SIMD, 6.42 -> 4.96 ms --
 // and the commit 123 -- four, the LDS pool cut to 18.9 KB (W in PH's place): 4.68 -> 3.73 ms (profiles/r05_cfg3_horner_ab.txt).
-// The residual+Jacobian mode (195 parked) stays unparked with vector coefficients; the residual-only mode capped at 128
-// registers (amdgpu_waves_per_eu(4, 4): 12 spilled) is slower than at 145, 5.03 against 4.75 ms.
+// With the library's pow gone from the hardening laws (materials.hpp pow_any: its inlined copies had set the register count)
+// the residual-only mode needs 123 -- four waves too, 4.33 -> 3.81 ms -- and the residual+Jacobian mode 177 parked: held to
+// 168 (three waves; ten doubles go to scratch memory once per point) it runs 6.33 -> 5.9 - 6.0 ms, parked at two waves 6.7.
 struct T3Park {
   static constexpr bool scalar_coefficients = true;     // (materials.hpp horner_step: what makes the parked kernels fit)
   double* slot;
@@ -226,8 +234,12 @@ struct T3Park {
 // none.  GRAD 0: residual pieces only;
 // 2: DomainPostTimeAdvance (nonlinear_solid.cpp:179-199) -- F at the points as for an assembly, then the material's state
 // commit, nothing else (the degree-2 commit kernel's direct 64-node sum per point spilled 821 registers at degree 3)
+// (closed-form family, residual+Jacobian mode: held to three waves per SIMD -- 168 registers; parked it needs 177, and the ten
+// doubles that go to scratch memory do so once per point, around the record: 6.33 -> 5.9 - 6.0 ms, profiles/r05_cfg3_horner_ab.txt)
 template<int FAMILY, int GRAD>
-__global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
+__global__ __launch_bounds__(128)
+__attribute__((amdgpu_waves_per_eu(FAMILY == 0 && GRAD == 1 ? 3 : 1, FAMILY == 0 && GRAD == 1 ? 3 : 8)))
+void tp3_point_kernel(TensorArgs p) {
   constexpr int NB = T3_NB, NQ = T3_NQ, ND = T3_ND, NPT = T3_NPT, PS = T3_PS;
   constexpr int FK = FAMILY >= 2 ? FAMILY : -1;
   __shared__ double ue[3 * ND];
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(128) void tp3_point_kernel(TensorArgs p) {
         H[i * 3 + k] = sv;
       }
   }
-  constexpr bool PARK = FAMILY == 0 && (GRAD == 2 || GRAD == 0);
+  constexpr bool PARK = FAMILY == 0;
   if constexpr (PARK) __syncthreads();           // (V and W are free from here on: T3Park)
   if (tid < NPT) {
     if constexpr (!EARLY_GEO) {

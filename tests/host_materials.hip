@@ -50,3 +50,8 @@ extern "C" int host_accumulate(const mimi_hip_material* m, double sigma_y_ref, i
 extern "C" void host_pow_positive(int n, const double* x, const double* q, double* out) {
   for (int k = 0; k < n; ++k) out[k] = pow_positive(x[k], q[k]);
 }
+
+// x^q for any x (materials.hpp pow_any: what the hardening laws call -- no library pow behind it)
+extern "C" void host_pow_any(int n, const double* x, const double* q, double* out) {
+  for (int k = 0; k < n; ++k) out[k] = pow_any(x[k], q[k]);
+}

@@ -192,18 +192,19 @@ def test_every_kernel_with_asm_horner_steps_passes_the_lint(need):
 
 def test_the_degree3_prepass_kernels_keep_their_waves_per_simd():
     """Round 5: the J2 modes of the degree-3 pre-pass are bound by the latency of the return-map iteration at the occupancy
-    their registers and LDS allow: the residual-only mode runs at three waves per SIMD (145 of <= 168
-    registers: F^-1 and the deviator parked, the coefficients of pow_positive in scalar registers), the state commit at four
-    (123 of <= 128), both with the 18.9 KB LDS pool (eight workgroups per CU).  An unrelated edit moved the commit from 123
-    to 143 registers in this round (3.43 -> 3.85 ms) without a test noticing: this is that test."""
+    their registers and LDS allow: the residual-only mode and the state commit run at four waves per SIMD (123 /
+    119 of <= 128 registers: F^-1 and the deviator parked, the coefficients of pow_positive in scalar registers, no inlined
+    library pow), the residual+Jacobian mode at three (held to 168; a few doubles in scratch memory around the record), all
+    with the 18.9 KB LDS pool (eight workgroups per CU).  An unrelated edit moved the commit from 123 to 143 registers in this
+    round (3.43 -> 3.85 ms) without a test noticing: this is that test."""
     res = L.kernel_resources(L.assembly("tensor_p3.hip"))
     def one(tag):
         names = [n for n in res if "tp3_point_kernelILi0ELi%d" % tag in n]
         assert len(names) == 1, names
         return res[names[0]]
-    for tag, waves in ((0, 3), (2, 4), (1, 2)):          # residual-only, commit, residual+Jacobian
+    for tag, waves, spills in ((0, 4, 0), (2, 4, 0), (1, 3, 32)):          # residual-only, commit, residual+Jacobian
         r = one(tag)
-        assert r["spill"] == 0, (tag, r)
+        assert r["spill"] <= spills, (tag, r)
         assert L.waves_per_simd(r, 128) >= waves, (tag, r, L.waves_per_simd(r, 128))
     gather = [res[n] for n in res if "tp3_gather_kernelILi1" in n]
     assert len(gather) == 1 and L.waves_per_simd(gather[0], 256) >= 4, gather

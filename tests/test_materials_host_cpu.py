@@ -125,3 +125,25 @@ def test_pow_positive_outside_its_reduction_range(host_lib):
     assert np.array_equal(np.isnan(out), np.isnan(ref))
     ok = ~np.isnan(ref)
     assert np.array_equal(out[ok], ref[ok])
+
+
+def test_pow_any_answers_non_positive_bases_as_pow_does(host_lib):
+    """csrc/materials.hpp pow_any (round 5): the hardening laws no longer inline the library's pow for the bases a return-map
+    equation never produces -- zero (exactly), negative, NaN.  Same answers as pow: the limits at zero (signed for odd
+    integer exponents), +- |x|^q for an integer q (to the few ulp of pow_positive), NaN for a negative base with a
+    non-integer exponent, 1 for q = 0 whatever the base; positive bases are pow_positive's to the bit."""
+    x = np.array([0.0, 0.0, 0.0, -0.0, -0.0, 0.0, -2.0, -2.0, -2.0, -2.0, -1.5, -1e-3, np.nan, np.nan, -np.inf, 3.0, 1e-9])
+    q = np.array([2.5, -0.7165, 0.0, -1.0, 3.0, -2.0, 2.0, 3.0, -1.0, 0.5, -0.7165, 4.0, 0.0, 1.5, 0.0, -0.7165, -0.7165])
+    out, pos = np.empty(x.size), np.empty(x.size)
+    host_lib.host_pow_any(x.size, x.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    with np.errstate(all="ignore"):
+        ref = np.power(x, q)
+    assert np.array_equal(np.isnan(out), np.isnan(ref)), (out, ref)
+    ok = ~np.isnan(ref)
+    exact = ok & (np.isinf(ref) | (ref == 0.0) | (q == 0.0))
+    assert np.array_equal(out[exact], ref[exact]) and np.array_equal(np.signbit(out[exact]), np.signbit(ref[exact]))
+    rest = ok & ~exact
+    assert np.all(np.abs(out[rest] - ref[rest]) <= 4e-15 * np.abs(ref[rest]))
+    xp = np.abs(x[-2:]); qp = q[-2:]
+    host_lib.host_pow_positive(2, xp.ctypes.data_as(C.c_void_p), qp.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out[-2:], pos[:2])
