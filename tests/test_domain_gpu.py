@@ -125,6 +125,50 @@ def test_residual_and_tangent_parity(case, matname, creator):
         G.SetTangentMode(0)
 
 
+@pytest.mark.parametrize("matname", ["j2", "j2simo", "j2log"])
+@pytest.mark.parametrize("case", [((3, 4), 2, None, "bspline"), ((3, 2, 2), 2, None, "bspline"), ((2, 3, 2), 3, None, "bspline"),
+                                  ((3, 2, 2), 2, None, "tables")], ids=lambda c: "x".join(map(str, c[0])) + f"p{c[1]}-{c[3]}")
+def test_rate_dependent_johnson_cook_parity(case, matname, monkeypatch):
+    """The RATE term of the Johnson-Cook law, 1 + C ln(rate / eps0_dot) (material_hardening.hpp:261-279): the reference's own
+    tests never set C, so with their parameters the factor is 1 and the logarithm inside every trip of the
+    return-map Newton -- and its derivative C / rate in the hardening slope -- never runs.  Here C = 0.04 and a time step
+    for which most yielding points exceed the reference rate: committed state, residual, residual + analytic tangent
+    against the oracle, on the tensor kernels of degree 2 and 3 (2-D, 3-D) and the general kernels, for the three J2 models
+    that take a hardening law."""
+    import _cases as cases
+    from oracle import ref_path as rp
+    monkeypatch.setitem(cases.JC_TEST, "C", 0.04)
+    n_el, p, lengths, creator = case
+    P, D, G = make_pair(n_el, p, lengths, matname, creator)
+    dt = 0.05
+    D.set_dt(dt)
+    G.dt_ = dt
+    u0 = synthetic_u(P, scale=0.03, seed=7)
+    D.domain_post_time_advance(u0)
+    G.DomainPostTimeAdvance(u0)
+    assert D.eqps.max() / dt > 10 * cases.JC_TEST["eps0_dot"]            # (the rate term is active)
+    assert np.allclose(G.State("accumulated_plastic_strain"), D.eqps, rtol=1e-9, atol=1e-13)
+    assert np.allclose(G.State("temperature"), D.temperature, rtol=1e-12, atol=1e-12)
+    u = synthetic_u(P, scale=0.02)
+    r_o, r_g = np.zeros(P.n_vdofs), np.zeros(P.n_vdofs)
+    D.add_domain_residual(u, r_o)
+    G.AddDomainResidual(u, r_g)
+    assert relmax(r_g, r_o) < 1e-12
+    r_o, r_g, A_o, A_g = np.zeros(P.n_vdofs), np.zeros(P.n_vdofs), np.zeros(D.nnz), np.zeros(D.nnz)
+    D.add_domain_residual_and_grad(u, 0.37, r_o, A_o, rp.TANGENT_EXACT)
+    G.AddDomainResidualAndGrad(u, 0.37, r_g, A_g)
+    assert relmax(r_g, r_o) < 1e-12
+    assert relmax(A_g, A_o) < 1e-11
+    # and the factor is not 1: the same assembly with C = 0 differs
+    monkeypatch.setitem(cases.JC_TEST, "C", 0.0)
+    P2, D2, G2 = make_pair(n_el, p, lengths, matname, creator)
+    D2.set_dt(dt)
+    D2.domain_post_time_advance(u0)
+    r_c0 = np.zeros(P.n_vdofs)
+    D2.add_domain_residual(u, r_c0)
+    assert relmax(r_c0, r_o) > 1e-4
+
+
 def test_device_pointers_and_stream():
     """u / r / A as torch tensors on the GPU: used in place, asynchronous on the given stream."""
     import torch
