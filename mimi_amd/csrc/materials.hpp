@@ -89,12 +89,17 @@ MH_DEV double thermo_contribution(const MaterialDev& md, double T) {
   return 1.0;
 }
 
+template<bool SC = false>
+MH_DEV double ln_positive(double x);
+
+template<bool SC = false>
 MH_DEV double rate_contribution(const mimi_hip_material& m, double rate) {
   if (m.hardening >= MIMI_HIP_HARD_JC_RATE) {
     double v = 1.0;
-    // (C == 0 -- the reference's tests never set C, SURVEY 8c: 1 + 0 log(..) is 1 to the bit; the logarithm, ~150
-    // instructions in every iteration of the return-map Newton, is skipped)
-    if (m.C != 0.0 && rate > m.eps0_dot) v += m.C * log(rate / m.eps0_dot);
+    // (C == 0 -- the reference's tests never set C, SURVEY 8c: 1 + 0 log(..) is 1 to the bit, and the logarithm in every
+    // trip of the return-map Newton is skipped.  C != 0: ln_positive, ~ 40 instructions and a few ulp, instead of the
+    // library's log -- ~ 150 instructions inlined at every call site; tests/test_domain_gpu.py, rate-dependent parity)
+    if (m.C != 0.0 && rate > m.eps0_dot) v += m.C * ln_positive<SC>(rate / m.eps0_dot);
     return v;
   }
   return 1.0;
@@ -132,11 +137,10 @@ MH_DEV double horner_step(double p, double x, double c) {
 #endif
 }
 
+// ln x for x > 0 (+inf -> +inf), a few ulp: the first half of pow_positive, also what the Johnson-Cook rate term calls
 template<bool SC>
-MH_DEV double pow_positive(double x, double q) {
-  // arguments outside the range the reduction below is written for, answered as pow() answers them (a diverging
-  // return-map Newton can produce them; ADVICE round 3): x = +inf here, |q ln x| beyond the exponent range below
-  if (x > 1.79769313486231570815e+308) return q > 0.0 ? x : (q < 0.0 ? 0.0 : 1.0);
+MH_DEV double ln_positive(double x) {
+  if (x > 1.79769313486231570815e+308) return x;
   int e;
   double m = __builtin_frexp(x, &e);   // [1/2, 1)
   if (m < 0.70710678118654752440) {
@@ -158,7 +162,16 @@ MH_DEV double pow_positive(double x, double q) {
   p = __builtin_fma(p * t2, 2.0 * t, 2.0 * t);                      // ln m = 2 t (1 + t^2 p)
   constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const double ed = (double)e;
-  const double lnx = __builtin_fma(ed, ln2_hi, p) + ed * ln2_lo;
+  return __builtin_fma(ed, ln2_hi, p) + ed * ln2_lo;
+}
+
+template<bool SC>
+MH_DEV double pow_positive(double x, double q) {
+  // arguments outside the range the reduction below is written for, answered as pow() answers them (a diverging
+  // return-map Newton can produce them; ADVICE round 3): x = +inf here, |q ln x| beyond the exponent range below
+  if (x > 1.79769313486231570815e+308) return q > 0.0 ? x : (q < 0.0 ? 0.0 : 1.0);
+  const double lnx = ln_positive<SC>(x);
+  constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   double y = q * lnx;
   // e^y over- / underflows long before +-1500: clamped so that k fits an int and the remainder stays small; ldexp then
   // returns inf / 0 as pow() does (a NaN passes through both comparisons and comes out as NaN)
@@ -254,7 +267,7 @@ MH_DEV RmPoint rm_eval(const mimi_hip_material& m, const ReturnMapCtx& c, double
   e.x = x;
   e.H = hardening_evaluate<SC>(m, Dual{c.eqps_old + x, 1.0});
   // (the rate x / dt -- a division, 13 instructions in every iteration of the Newton below -- only where a rate term reads it)
-  e.rc = (m.hardening >= MIMI_HIP_HARD_JC_RATE && m.C != 0.0) ? rate_contribution(m, x / c.dt) : 1.0;
+  e.rc = (m.hardening >= MIMI_HIP_HARD_JC_RATE && m.C != 0.0) ? rate_contribution<SC>(m, x / c.dt) : 1.0;
   const double fac = e.rc * c.thermo;
   e.R = Dual{c.q - c.slope * x - e.H.v * fac, -c.slope - e.H.d * fac};
   return e;
