@@ -153,3 +153,29 @@ def test_p3_frame_indifference(matname):
         y = M @ np.cross(omega, x).ravel()
         assert np.abs(y - np.cross(omega, rr).ravel()).max() < 1e-11 * scale
         assert np.abs(y).max() > 1e-3 * np.abs(rr).max()
+
+
+def test_p3_committed_plastic_strain_is_symmetric_to_the_bit():
+    """What T3Park (csrc/tensor_p3.hip) relies on: every J2 mode of the degree-3 pre-pass hands F^-1 and the trial deviator
+    to LDS over the return mapping and keeps six of the deviator's nine entries -- exact as long as
+    s = 2G dev(0.5 (F + F^T) - I - eps_p) is symmetric TO THE BIT, i.e. as long as the plastic strain is: it starts at zero
+    and grows by delta n with n built from s.  Two committed steps (the second one starts from a non-trivial eps_p) leave a
+    plastic strain that equals its transpose bitwise at every point, and agrees with the oracle's (which parks nothing)."""
+    n_el = (3, 3, 4)
+    P, D, G = make_pair(n_el, 3, None, "j2", "bspline")
+    D.set_dt(0.5)
+    G.dt_ = 0.5
+    for seed, scale in ((7, 0.03), (8, 0.045)):
+        u0 = synthetic_u(P, scale=scale, seed=seed)
+        D.domain_post_time_advance(u0)
+        G.DomainPostTimeAdvance(u0)
+        ep = G.State("plastic_strain").reshape(-1, 3, 3)
+        assert np.abs(ep).max() > 1e-4
+        assert np.array_equal(ep, np.swapaxes(ep, 1, 2))
+        assert np.allclose(G.State("plastic_strain"), D.plastic_strain, rtol=1e-9, atol=1e-13)
+    # and the assemblies from that state (parked in all three modes) against the oracle
+    u = synthetic_u(P, scale=0.02)
+    r_o, r_g = np.zeros(P.n_vdofs), np.zeros(P.n_vdofs)
+    D.add_domain_residual(u, r_o)
+    G.AddDomainResidual(u, r_g)
+    assert relmax(r_g, r_o) < 1e-12
