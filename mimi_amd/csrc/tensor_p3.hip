@@ -5,7 +5,7 @@
 //
 //   pre-pass   tp3_point_kernel     one lane per quadrature point: F, material, and -- pulled back to the reference
 //                                   element and weighted -- Ahat_i[m][j][n], Phat_i[m] -> record [element][90][128];
-//                                   the element residual pieces by sum factorisation -> scratch_r[element][i][64].
+//                                   the element residual pieces by sum factorisation -> scratch_r[element][64][i].
 //   phase 1    tp3_contract_kernel  one WAVE per (element, i), no LDS, no barriers: per column component j the block
 //                                   K[(a, i), (b, j)] = sum_q sum_mn dN_a/dxi_m Ahat_i[m][j][n] dN_b/dxi_n
 //                                   one parametric direction at a time,
@@ -504,7 +504,7 @@ void tp3_point_kernel(TensorArgs p) {
       for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int q0 = 0; q0 < NQ; ++q0) sr = __builtin_fma(T[m == 0 ? 1 : 0][q0], W[((i * 3 + m) * NB * NB + a12) * NQ + q0], sr);
-      p.scratch_r[(e * 3 + i) * ND + a] = sr;
+      p.scratch_r[(e * ND + a) * 3 + i] = sr;       // [element][a][i]: see tp3_gather_kernel
     }
   }
 }
@@ -1269,16 +1269,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
   }
   // residual row: lane = element (dz, dy, dx) of the 4 x 4 x 4 neighbourhood, fixed-shape tree sum
+  // (a tangent assembly keeps its residual rows here, hidden behind the value rows: as a launch of their own -- the kernel below --
+  // they cost 0.4 ms more, profiles/r05_cfg3_horner_ab.txt)
   {
     const int dz = lane >> 4, dy = (lane >> 2) & 3, dx = lane & 3;
     const int ez = ez_lo + dz, ey = ey_lo + dy, ex = ex_lo + dx;
     const bool in = ez <= ez_hi && ey <= ey_hi && ex <= ex_hi;
     const int a = in ? (A0 - ex) + NB * ((A1 - ey) + NB * (A2 - ez)) : 0;
     const int64_t el = in ? elem(ex, ey, ez) : 0;
-    double rs = in ? p.scratch_r[(el * 3 + I) * ND + a] : 0.0;
+    // [element][a][i], i fastest: the three rows of a node -- three waves of this workgroup -- read the same 64 sectors (one
+    // 8-byte read per element and row is a 32-byte sector fetched; with [element][i][a] the residual rows cost 3.2 GB of
+    // fetch per assembly for 0.4 GB of pieces)
+    double rs = in ? p.scratch_r[(el * ND + a) * 3 + I] : 0.0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) rs += __shfl_down(rs, off, 64);
     if (lane == 0) p.r[(p.perm ? p.perm[A] : A) * 3 + I] += rs;
+  }
+}
+
+// residual-only assemblies: one wave per NODE (its three rows), lane = element (dz, dy, dx) of the 4 x 4 x 4 neighbourhood --
+// the three values a lane needs are 24 adjacent bytes of scratch_r[element][a][i]; the same fixed-shape tree sums as the
+// per-row form above (tp3_gather_kernel<0>: three waves per node, each with one 8-byte read per lane), i.e. the same bits
+__global__ __launch_bounds__(256) void tp3_residual_gather_kernel(TensorArgs p, int64_t n_nodes) {
+  constexpr int P = 3, NB = T3_NB, ND = T3_ND;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t Al = (int64_t)blockIdx.x * 4 + wave;
+  if (Al >= n_nodes) return;
+  const int n0 = p.n_ctrl[0], n1 = p.n_ctrl[1];
+  const int m0 = p.win_n[0], m1 = p.win_n[1];
+  const int A0 = p.win_begin[0] + (int)(Al % m0), A1 = p.win_begin[1] + (int)((Al / m0) % m1);
+  const int A2 = p.win_begin[2] + (int)(Al / ((int64_t)m0 * m1));
+  const int64_t A = A0 + (int64_t)n0 * (A1 + (int64_t)n1 * A2);
+  const int bx0 = p.box_begin[0], bx1 = p.box_begin[1], bx2 = p.box_begin[2];
+  const int ex_lo = max(A0 - P, bx0), ex_hi = min(A0, bx0 + p.box_n[0] - 1);
+  const int ey_lo = max(A1 - P, bx1), ey_hi = min(A1, bx1 + p.box_n[1] - 1);
+  const int ez_lo = max(A2 - P, bx2), ez_hi = min(A2, bx2 + p.box_n[2] - 1);
+  if (ex_lo > ex_hi || ey_lo > ey_hi || ez_lo > ez_hi) return;
+  const int dz = lane >> 4, dy = (lane >> 2) & 3, dx = lane & 3;
+  const int ez = ez_lo + dz, ey = ey_lo + dy, ex = ex_lo + dx;
+  const bool in = ez <= ez_hi && ey <= ey_hi && ex <= ex_hi;
+  const int a = in ? (A0 - ex) + NB * ((A1 - ey) + NB * (A2 - ez)) : 0;
+  const int64_t el = in ? (ex - bx0) + (int64_t)p.box_n[0] * ((ey - bx1) + (int64_t)p.box_n[1] * (ez - bx2)) : 0;
+  const double* q = p.scratch_r + (el * ND + a) * 3;
+  double rs[3];
+#pragma unroll
+  for (int I = 0; I < 3; ++I) rs[I] = in ? q[I] : 0.0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+    for (int I = 0; I < 3; ++I) rs[I] += __shfl_down(rs[I], off, 64);
+  if (lane == 0) {
+    double* r = p.r + (p.perm ? p.perm[A] : A) * 3;
+#pragma unroll
+    for (int I = 0; I < 3; ++I) r[I] += rs[I];
   }
 }
 
@@ -1345,7 +1388,7 @@ void launch_tensor_p3(mimi_hip_domain_s* h, int grad, TensorArgs a) {
   } else if (grad)
     hipLaunchKernelGGL(tp3_gather_kernel<1>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, h->stream, a, n_rows);
   else
-    hipLaunchKernelGGL(tp3_gather_kernel<0>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, h->stream, a, n_rows);
+    hipLaunchKernelGGL(tp3_residual_gather_kernel, dim3((unsigned)((n_rows / 3 + 3) / 4)), dim3(256), 0, h->stream, a, n_rows / 3);
   MH_HIP(hipGetLastError());
   if (h->phase_timing) MH_HIP(hipEventRecord(h->phase_ev[2], h->stream));
 }
