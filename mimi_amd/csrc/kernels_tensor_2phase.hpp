@@ -8,7 +8,7 @@
 // kernel that owns CSR rows gathers them and does ONE coalesced read-modify-write per row.
 //
 //   phase 1  stores, for every element, a block of 3 x 2187 slots in scratch_k -- the pieces of the three row components I,
-//            interleaved ROW BY ROW -- and the residual piece scratch_r[element][i][a].  Entries shared with the next
+//            interleaved ROW BY ROW -- and the residual piece scratch_r[element][a][i].  Entries shared with the next
 //            element of the walked (third) axis are carried inside the kernel, so each (node pair, element column) is
 //            stored exactly once, by the highest element of the column that contains both nodes.  Block layout (P2Block;
 //            a = a0 + 3 a1 + 9 a2 local row node, (b2,b1,b0) local column node, j column component):
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int64_t e = in ? elem(ex, ey, ez) : 0;
     double rs[3];
 #pragma unroll
-    for (int I = 0; I < 3; ++I) rs[I] = in ? p.scratch_r[(e * 3 + I) * ND + a] : 0.0;
+    for (int I = 0; I < 3; ++I) rs[I] = in ? p.scratch_r[(e * ND + a) * 3 + I] : 0.0;     // (three adjacent doubles: one sector per element instead of three)
 #pragma unroll
     for (int I = 0; I < 3; ++I) {
 #pragma unroll

@@ -3,7 +3,7 @@
 //
 //   phase 1  tensor_residual_kernel: one wave per element, lane = quadrature point: gather u, F, P(F),
 //            then per component i the element residual piece by sum factorisation (through LDS)
-//            -> scratch_r[element][i][a].
+//            -> scratch_r[element][a][i].
 //   phase 2  tensor_residual_gather_kernel: one wave per node: lane = element of the 3 x 3 x 3
 //            neighbourhood, fixed-shape tree sum, r[node, i] += sum.
 #pragma once
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void tensor_residual_kernel(TensorArgs p, int 
 #pragma unroll
         for (int q0 = 0; q0 < NQ; ++q0) sr += T0[q0] * W[(m * NB2 + a12) * NQ + q0];
       }
-      p.scratch_r[(e * 3 + I) * ND + lane] = sr;
+      p.scratch_r[(e * ND + lane) * 3 + I] = sr;
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void tensor_residual_gather_kernel(TensorArgs 
   const int64_t e = in ? (ex - bx0) + (int64_t)p.box_n[0] * ((ey - bx1) + (int64_t)p.box_n[1] * (ez - bx2)) : 0;
   double rs[3];
 #pragma unroll
-  for (int I = 0; I < 3; ++I) rs[I] = in ? p.scratch_r[(e * 3 + I) * ND + a] : 0.0;
+  for (int I = 0; I < 3; ++I) rs[I] = in ? p.scratch_r[(e * ND + a) * 3 + I] : 0.0;
 #pragma unroll
   for (int I = 0; I < 3; ++I) {
 #pragma unroll

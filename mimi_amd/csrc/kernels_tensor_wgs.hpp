@@ -502,7 +502,7 @@ MH_DEV void wgs_x_row(const TensorArgs& p, double* lds, int lane, int64_t e, int
 #pragma unroll
       for (int q0 = 0; q0 < NQ; ++q0) sr += T0[q0] * W[(m * NB2 + a12) * NQ + q0];
     }
-    p.scratch_r[(e * 3 + I) * ND + lane] = sr;
+    p.scratch_r[(e * ND + lane) * 3 + I] = sr;
   }
   __builtin_amdgcn_wave_barrier();
 }

@@ -118,7 +118,7 @@ MH_DEV void wgsym_x_rows(const TensorArgs& p, double* lds, int lane, int64_t e, 
 #pragma unroll
       for (int q0 = 0; q0 < NQ; ++q0) sr += T0[q0] * W[((I * 3 + m) * NB2 + a12) * NQ + q0];
     }
-    p.scratch_r[(e * 3 + I) * ND + a] = sr;
+    p.scratch_r[(e * ND + a) * 3 + I] = sr;       // [element][a][i]: tensor_p2_kernel reads a node's three rows from one sector
   }
   __builtin_amdgcn_wave_barrier();
 }
