@@ -89,36 +89,62 @@ MH_DEV void wgsym_x_rows(const TensorArgs& p, double* lds, int lane, int64_t e, 
 #pragma unroll
   for (int k = 0; k < 9; ++k) PH[k * NQ3 + lane] = s.Phat[k];   // k = I * 3 + m
   __builtin_amdgcn_wave_barrier();
+  // Lane -> output maps of the three stages (round 5, as in the degree-3 pre-pass): a lane owns ONE pair of the indices that are
+  // neither summed nor a tensor component, reads its table values once and walks (I, m) with compile-time offsets -- 48 / 36 /
+  // 54 of the 64 lanes busy, a third of the instructions of the loops over the flat output index they replace (20 - 30 integer
+  // instructions of index arithmetic per four multiply-adds); the sums run in the same order: same bits.
   // V[I m][a2][q0 q1] = sum_q2 T2^m[a2][q2] PH[I m][q0 q1 q2]
-  for (int t = lane; t < 9 * NB * NQ * NQ; t += 64) {
-    const int q01 = t % (NQ * NQ), a2 = (t / (NQ * NQ)) % NB, im = t / (NB * NQ * NQ), m = im % 3;
-    const double* T2 = tab_ptr<P>(tab, 2, m == 2 ? 1 : 0) + a2 * NQ;
-    double sv = 0.0;
+  if (lane < NB * NQ * NQ) {
+    const int q01 = lane & 15, a2 = lane >> 4;
+    double T[2][NQ];
 #pragma unroll
-    for (int q2 = 0; q2 < NQ; ++q2) sv += T2[q2] * PH[im * NQ3 + q01 + NQ * NQ * q2];
-    V[t] = sv;   // t = (im * NB + a2) * 16 + q01
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int q2 = 0; q2 < NQ; ++q2) T[v][q2] = tab_ptr<P>(tab, 2, v)[a2 * NQ + q2];
+#pragma unroll
+    for (int im = 0; im < 9; ++im) {
+      double sv = 0.0;
+#pragma unroll
+      for (int q2 = 0; q2 < NQ; ++q2) sv = __builtin_fma(T[im % 3 == 2 ? 1 : 0][q2], PH[im * NQ3 + q01 + NQ * NQ * q2], sv);
+      V[im * (NB * NQ * NQ) + lane] = sv;   // (im * NB + a2) * 16 + q01
+    }
   }
   __builtin_amdgcn_wave_barrier();
   // W[I m][a1 a2][q0] = sum_q1 T1^m[a1][q1] V[I m][a2][q0 q1]
-  for (int t = lane; t < 9 * NB2 * NQ; t += 64) {
-    const int q0 = t % NQ, a12 = (t / NQ) % NB2, a1 = a12 % NB, a2 = a12 / NB, im = t / (NB2 * NQ), m = im % 3;
-    const double* T1 = tab_ptr<P>(tab, 1, m == 1 ? 1 : 0) + a1 * NQ;
-    double sw = 0.0;
+  if (lane < NB2 * NQ) {
+    const int q0 = lane & 3, a12 = lane >> 2, a1 = a12 % NB, a2 = a12 / NB;
+    double T[2][NQ];
 #pragma unroll
-    for (int q1 = 0; q1 < NQ; ++q1) sw += T1[q1] * V[(im * NB + a2) * NQ * NQ + q0 + NQ * q1];
-    W[t] = sw;   // t = (im * NB2 + a12) * 4 + q0
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int q1 = 0; q1 < NQ; ++q1) T[v][q1] = tab_ptr<P>(tab, 1, v)[a1 * NQ + q1];
+#pragma unroll
+    for (int im = 0; im < 9; ++im) {
+      double sw = 0.0;
+#pragma unroll
+      for (int q1 = 0; q1 < NQ; ++q1) sw = __builtin_fma(T[im % 3 == 1 ? 1 : 0][q1], V[(im * NB + a2) * NQ * NQ + q0 + NQ * q1], sw);
+      W[im * (NB2 * NQ) + lane] = sw;   // (im * NB2 + a12) * 4 + q0
+    }
   }
   __builtin_amdgcn_wave_barrier();
-  for (int t = lane; t < 3 * ND; t += 64) {
-    const int a = t % ND, I = t / ND, a0 = a % NB, a12 = a / NB;
-    double sr = 0.0;
+  // rows: lanes 0..26 take I = 0 and then I = 2, lanes 27..53 take I = 1
+  if (lane < 2 * ND) {
+    const int a = lane < ND ? lane : lane - ND, a0 = a % NB, a12 = a / NB;
+    double T[2][NQ];
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
-      const double* T0 = tab_ptr<P>(tab, 0, m == 0 ? 1 : 0) + a0 * NQ;
+    for (int v = 0; v < 2; ++v)
 #pragma unroll
-      for (int q0 = 0; q0 < NQ; ++q0) sr += T0[q0] * W[((I * 3 + m) * NB2 + a12) * NQ + q0];
+      for (int q0 = 0; q0 < NQ; ++q0) T[v][q0] = tab_ptr<P>(tab, 0, v)[a0 * NQ + q0];
+    const int n_rows = lane < ND ? 2 : 1;
+    for (int k = 0; k < n_rows; ++k) {
+      const int I = lane < ND ? 2 * k : 1;
+      double sr = 0.0;
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int q0 = 0; q0 < NQ; ++q0) sr = __builtin_fma(T[m == 0 ? 1 : 0][q0], W[((I * 3 + m) * NB2 + a12) * NQ + q0], sr);
+      p.scratch_r[(e * ND + a) * 3 + I] = sr;       // [element][a][i]: tensor_p2_kernel reads a node's three rows from one sector
     }
-    p.scratch_r[(e * ND + a) * 3 + I] = sr;       // [element][a][i]: tensor_p2_kernel reads a node's three rows from one sector
   }
   __builtin_amdgcn_wave_barrier();
 }
