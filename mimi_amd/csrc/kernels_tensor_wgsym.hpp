@@ -163,40 +163,71 @@ MH_DEV void wgsym_x_loop(const TensorArgs& p, double* lds, int col0, int n_cols,
   // (unit index = column * segments-per-column + segment): sequence index g = unit-in-workgroup * seg_len + position
   const int sl = p.seg_len, nseg = p.box_n[2] / sl;
   const int n_seq = n_cols * sl;
-  auto ez_at = [&](int g) -> int { return ((col0 + g / sl) % nseg) * sl + g % sl; };
-  auto element_at = [&](int g) -> int64_t {
-    const int col = (col0 + g / sl) / nseg;
-    return col % p.box_n[0] + (int64_t)p.box_n[0] * (col / p.box_n[0] + (int64_t)p.box_n[1] * ez_at(g));
+  // The element of sequence index g, its spans and its layer, kept by a cursor that moves one element at a time (round 5: the
+  // point wave asked for them by division -- g / sl, % nseg, col % n0, col / n0 at every use: ~ 12 run-time integer divisions,
+  // 300 - 400 scalar instructions per element; the contraction waves went incremental in round 4): the unit's column by
+  // division when a unit begins, then one layer further per step.
+  struct Cursor {
+    int g, pos, unit, cx, cy, ez;
+    int64_t e;
   };
-  auto table_src = [&](int g, int t) -> const double* {
+  const int64_t e_step = (int64_t)p.box_n[0] * p.box_n[1];
+  auto cursor_at_unit = [&](int g, int u) -> Cursor {
+    Cursor c;
+    c.g = g;
+    c.pos = 0;
+    c.unit = u;
+    const int un = col0 + u, col = un / nseg;
+    c.cx = col % p.box_n[0];
+    c.cy = col / p.box_n[0];
+    c.ez = (un % nseg) * sl;
+    c.e = c.cx + (int64_t)p.box_n[0] * (c.cy + (int64_t)p.box_n[1] * c.ez);
+    return c;
+  };
+  auto advance = [&](Cursor& c) {
+    ++c.g;
+    if (++c.pos == sl) {
+      c = cursor_at_unit(c.g, c.unit + 1);
+    } else {
+      ++c.ez;
+      c.e += e_step;
+    }
+  };
+  auto table_src = [&](const Cursor& c, int t) -> const double* {
     const int dir = t / (2 * NB * NQ);
     const int rem = t % (2 * NB * NQ);
     const int isD = rem / (NB * NQ);
     const int k = rem % (NB * NQ);
-    const int col = (col0 + g / sl) / nseg;
-    const int span = (dir == 0 ? p.box_begin[0] + col % p.box_n[0] : dir == 1 ? p.box_begin[1] + col / p.box_n[0] : p.box_begin[2] + ez_at(g));
+    const int span = (dir == 0 ? p.box_begin[0] + c.cx : dir == 1 ? p.box_begin[1] + c.cy : p.box_begin[2] + c.ez);
     return (isD ? (dir == 0 ? p.tabD[0] : dir == 1 ? p.tabD[1] : p.tabD[2])
                 : (dir == 0 ? p.tabB[0] : dir == 1 ? p.tabB[1] : p.tabB[2])) + (int64_t)span * NB * NQ + k;
   };
-  int32_t node_n = lane < ND ? p.dofs[element_at(0) * ND + lane] : 0;
+  Cursor cq = cursor_at_unit(0, 0);      // the element whose operands are requested next
+  Cursor cs = cq;                        // the element of the next quadrature-point stage
+  Cursor cr = cq;                        // the element whose rows are written next
+  int32_t node_n = lane < ND ? p.dofs[cq.e * ND + lane] : 0;
   double ue_r[3], tab_r[TROUNDS], geo_r[10];
-  auto request = [&](int es) {
-    const int64_t e_n = element_at(es);
+  // requests the operands of the element at cq (the cursor moves on), and the node ids of the one after it
+  auto request = [&]() {
 #pragma unroll
     for (int c = 0; c < 3; ++c) ue_r[c] = p.u[(int64_t)node_n * 3 + c];
 #pragma unroll
     for (int rd = 0; rd < TROUNDS; ++rd) {
       const int t = rd * 64 + lane;
-      tab_r[rd] = *table_src(es, t < 6 * NB * NQ ? t : 0);
+      tab_r[rd] = *table_src(cq, t < 6 * NB * NQ ? t : 0);
     }
-    const double* g = p.geo + e_n * 10 * NQ3 + lane;
+    const double* g = p.geo + cq.e * 10 * NQ3 + lane;
 #pragma unroll
     for (int k = 0; k < 10; ++k) geo_r[k] = g[(int64_t)k * NQ3];
-    if (es + 1 < n_seq) node_n = lane < ND ? p.dofs[element_at(es + 1) * ND + lane] : 0;
+    if (cq.g + 1 < n_seq) {
+      advance(cq);
+      node_n = lane < ND ? p.dofs[cq.e * ND + lane] : 0;
+    }
   };
   WgsPoint<KIND> s;
   // quadrature-point stage of element es from the requested operands (tables -> LDS parity es & 1)
-  auto point_stage = [&](int es) {
+  auto point_stage = [&]() {
+    const int es = cs.g;
     double* tab = lds + L::off_tab + (es & 1) * 6 * NB * NQ;
     if (lane < ND) {
 #pragma unroll
@@ -259,26 +290,30 @@ MH_DEV void wgsym_x_loop(const TensorArgs& p, double* lds, int col0, int n_cols,
           F[i + J * 3] = sf;
         }
     }
-    status |= wgs_x_point<KIND>(p, element_at(es) * NQ3 + lane, F, Ji, wd, s);
+    status |= wgs_x_point<KIND>(p, cs.e * NQ3 + lane, F, Ji, wd, s);
     __builtin_amdgcn_wave_barrier();
+    if (cs.g + 1 < n_seq) advance(cs);
   };
 
-  request(0);
-  point_stage(0);
-  if (1 < n_seq) request(1);
+  request();
+  point_stage();
+  if (1 < n_seq) request();
   // ---- prologue: rows of element 0 ---------------------------------------------------------------------------
-  wgsym_x_rows<KIND>(p, lds, lane, element_at(0), 0, s);
+  wgsym_x_rows<KIND>(p, lds, lane, cr.e, 0, s);
   wgs_barrier();
   for (int it = 0; it < n_seq; ++it) {
     // ---- D(it), free running: quadrature-point stage of element it + 1 (touches nothing the other waves read
     // before the next barrier: its own ue / point data and the table buffer of the OTHER parity) -----------------
     if (it + 1 < n_seq) {
-      point_stage(it + 1);
-      if (it + 2 < n_seq) request(it + 2);
+      point_stage();
+      if (it + 2 < n_seq) request();
     }
     // ---- O(it), lock step: rows of element it + 1 once every contraction wave holds its operands of element it --
     wgs_barrier();
-    if (it + 1 < n_seq) wgsym_x_rows<KIND>(p, lds, lane, element_at(it + 1), (it + 1) & 1, s);
+    if (it + 1 < n_seq) {
+      advance(cr);
+      wgsym_x_rows<KIND>(p, lds, lane, cr.e, (it + 1) & 1, s);
+    }
     wgs_barrier();
   }
 }
