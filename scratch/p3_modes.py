@@ -39,4 +39,9 @@ for k in range(4):
     e0.record(cur); G.DomainPostTimeAdvance(u); e1.record(cur); e1.synchronize()
     if k: t_c += e0.elapsed_time(e1) / 3
 G.ResetState(); r.zero_(); G.AddDomainResidual(u, r); G.Synchronize()
-print(os.path.basename(os.environ.get("MIMI_HIP_LIBRARY", "default")), "R+J: pre-pass %.3f contraction %.3f gather %.3f = %.3f ms | residual-only %.3f ms | commit %.3f ms | sum|r| %.17e" % (*acc, acc.sum(), t_r, t_c, float(r.abs().sum())))
+s0 = float(r.abs().sum())
+# a second checksum behind a state commit (what DomainPostTimeAdvance wrote is read by this assembly)
+G.DomainPostTimeAdvance(u); r.zero_(); G.AddDomainResidual(1.1 * u, r); G.Synchronize()
+s1 = float(r.abs().sum())
+G.ResetState()
+print(os.path.basename(os.environ.get("MIMI_HIP_LIBRARY", "default")), "R+J: pre-pass %.3f contraction %.3f gather %.3f = %.3f ms | residual-only %.3f ms | commit %.3f ms | sum|r| %.17e | after a commit %.17e" % (*acc, acc.sum(), t_r, t_c, s0, s1))
