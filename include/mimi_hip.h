@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MIMI_HIP_ABI_VERSION 11
+#define MIMI_HIP_ABI_VERSION 12
 
 /* ---- errors ---------------------------------------------------------------- */
 const char* mimi_hip_last_error(void);
@@ -228,6 +228,16 @@ int mimi_hip_rows_pack(void* stream, const int64_t* rowptr, const int64_t* rows,
                        const double* r, const double* A_values, double* message);
 int mimi_hip_rows_unpack_add(void* stream, const int64_t* rowptr, const int64_t* rows, const int64_t* offsets, int64_t n_rows,
                              const double* message, double* r, double* A_values);
+/* The same message with the rows trimmed to the entries the sender's elements can have written (ABI 12): of a shared row
+ * only the columns inside the sender's own node planes are not zero by construction (3 of the 5 column planes of a degree-2
+ * row), so only those travel: [n_rows residual entries][A_values[positions[0..n_positions)]].  positions (device int64,
+ * distinct) are places in the value array; sender and receiver list the same (row, column) pairs in the same order, each in
+ * its own array (mimi_amd/parallel.py InterfaceExchange builds both from the slab bounds).  A_values == NULL: residual
+ * entries only. */
+int mimi_hip_entries_pack(void* stream, const int64_t* rows, int64_t n_rows, const int64_t* positions, int64_t n_positions,
+                          const double* r, const double* A_values, double* message);
+int mimi_hip_entries_unpack_add(void* stream, const int64_t* rows, int64_t n_rows, const int64_t* positions, int64_t n_positions,
+                                const double* message, double* r, double* A_values);
 
 /* ---- contact integrator: integrators::MortarContact ------------------------------ */
 typedef struct mimi_hip_contact_s* mimi_hip_contact_t;

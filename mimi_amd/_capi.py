@@ -80,6 +80,7 @@ EXPORTS = [
     "mimi_hip_linear_gmres", "mimi_hip_linear_cg",
     "mimi_hip_domain_integrate", "mimi_hip_domain_gather",
     "mimi_hip_rows_zero", "mimi_hip_rows_pack", "mimi_hip_rows_unpack_add",
+    "mimi_hip_entries_pack", "mimi_hip_entries_unpack_add",
 ]
 
 
@@ -152,6 +153,9 @@ def lib():
     L.mimi_hip_rows_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mimi_hip_rows_unpack_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                            C.c_void_p]
+    L.mimi_hip_entries_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mimi_hip_entries_unpack_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
     L.mimi_hip_material_set_young_poisson.argtypes = [C.c_void_p, C.c_double, C.c_double]
     L.mimi_hip_material_set_young_poisson.restype = None
     L.mimi_hip_contact_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

@@ -196,10 +196,18 @@ class InterfaceExchange:
     first p//2 belong to k and the rest to k+1; each rank sends only the rows the neighbour owns and
     adds what it receives into the rows it owns -- half the traffic of "replicate"."""
 
-    def __init__(self, shard, r, A, device=None, mode="replicate", loopback=False):
+    def __init__(self, shard, r, A, device=None, mode="replicate", loopback=False, trim=True):
         """loopback: every message goes to this process itself (send and receive on the caller's own rank of the
         communicator) -- a transport check on one GPU: what a neighbour would have received is added into the rows
-        this rank would have received into (tests/test_rccl_loopback_gpu.py)."""
+        this rank would have received into (tests/test_rccl_loopback_gpu.py).
+
+        trim (round 5): a message carries of every row only the entries the SENDER's elements can have written -- an element
+        layer l touches the node planes l .. l + p, so entry (row plane a, column plane c) of a rank whose layers are
+        [b, e) is zero by construction unless some l in [b, e) has max(a, c) - p <= l <= min(a, c).  Of a degree-2 row
+        in owner mode 3 of the 5 column planes remain: 12.6 instead of 21 MB per neighbour and direction at the
+        north-star size on 8 ranks -- what has to hide behind the last gather.  Sender and receiver list the
+        same (row, column) pairs in the same order, each from the slab bounds alone.  False: whole rows (csrc/exchange.hip's
+        row kernels)."""
         import torch
         import torch.distributed as dist
         if mode not in ("replicate", "owner"):
@@ -220,19 +228,39 @@ class InterfaceExchange:
         self._hip = bool(r.is_cuda)
         self._rowptr = rowptr
         self._comm_stream = None
+        self.trim = bool(trim)
+        p_ax = int(shard.patch.degrees[shard.axis])
+        if self.trim:
+            col = shard.pattern.col
+            if not isinstance(col, torch.Tensor):
+                col = torch.from_numpy(np.ascontiguousarray(col))
+            col = col.to(device)
+            plane_of_node = torch.from_numpy(np.ascontiguousarray(mi_axis, dtype=np.int64)).to(device)
 
-        def row_sets(planes):
+        whole_rows = []
+
+        def row_sets(planes, layers):
+            """rows of the node planes `planes`, and where their travelling values are: `layers` = (b, e), the element layers
+            of the rank whose contributions the message carries (the sender's own, or the neighbour's on the receiving side)"""
             nodes = torch.from_numpy(np.nonzero(np.isin(mi_axis, planes))[0]).to(device)
             rows = (nodes[:, None] * dim + torch.arange(dim, device=device)[None, :]).reshape(-1).contiguous()
             start = rowptr[rows]
             length = rowptr[rows + 1] - start
             total = int(length.sum().item()) if rows.numel() else 0
             offs = torch.cumsum(length, 0) - length
-            if self._hip:
+            if self._hip and not self.trim:
                 # message layout: [rows.numel() residual entries][values row after row]
                 return rows, _RowRuns(total, (offs + rows.numel()).contiguous())
             # positions of all values of those rows, row after row
             idx = torch.repeat_interleave(start - offs, length) + torch.arange(total, device=device)
+            if not self._hip:
+                whole_rows.append(idx)             # (zero_interface zeroes the shared rows whole, trimmed messages or not)
+            if self.trim and total:
+                a = torch.repeat_interleave(plane_of_node[rows // dim], length)
+                c = plane_of_node[col[idx].long() // dim]
+                first = torch.clamp(torch.maximum(a, c) - p_ax, min=int(layers[0]))
+                last = torch.clamp(torch.minimum(a, c), max=int(layers[1]) - 1)
+                idx = idx[first <= last].contiguous()
             return rows, idx
 
         self.sides = []
@@ -246,8 +274,8 @@ class InterfaceExchange:
                 k = len(planes) // 2
                 lower, upper = planes[:k], planes[k:]          # owned by the lower / the upper rank
                 send_planes, recv_planes = (upper, lower) if nb > shard.rank else (lower, upper)
-            srows, sidx = row_sets(send_planes)
-            rrows, ridx = row_sets(recv_planes)
+            srows, sidx = row_sets(send_planes, (shard.starts[shard.rank], shard.starts[shard.rank + 1]))
+            rrows, ridx = row_sets(recv_planes, (shard.starts[nb], shard.starts[nb + 1]))
             self.sides.append(dict(peer=dist.get_rank() if loopback else nb, srows=srows, sidx=sidx, rrows=rrows, ridx=ridx,
                                    send=torch.empty(srows.numel() + sidx.numel(), dtype=r.dtype, device=device),
                                    recv=torch.empty(rrows.numel() + ridx.numel(), dtype=r.dtype, device=device)))
@@ -255,11 +283,10 @@ class InterfaceExchange:
         if self.sides:
             if mode == "replicate":
                 self._zero_rows = torch.cat([s["srows"] for s in self.sides])
-                parts = [s["sidx"] for s in self.sides]
             else:
                 self._zero_rows = torch.cat([t for s in self.sides for t in (s["srows"], s["rrows"])])
-                parts = [t for s in self.sides for t in (s["sidx"], s["ridx"])]
-            self._zero_idx = None if self._hip else torch.cat(parts)
+            # (host tensors: the positions of those rows' values -- in "replicate" mode the sent and the received rows are the same)
+            self._zero_idx = None if self._hip else torch.unique(torch.cat(whole_rows))
 
     def _stream(self):
         from ._capi import torch_stream_of
@@ -267,12 +294,22 @@ class InterfaceExchange:
 
     def _pack(self, s, with_grad):
         from ._capi import check, lib, ptr
+        if self.trim:
+            check(lib().mimi_hip_entries_pack(self._stream(), ptr(s["srows"], "int64"), s["srows"].numel(), ptr(s["sidx"], "int64"),
+                                              s["sidx"].numel(), ptr(self.r, "float64"),
+                                              ptr(self.A, "float64") if with_grad else None, ptr(s["send"], "float64")))
+            return
         check(lib().mimi_hip_rows_pack(self._stream(), ptr(self._rowptr, "int64"), ptr(s["srows"], "int64"),
                                        ptr(s["sidx"].offsets, "int64"), s["srows"].numel(), ptr(self.r, "float64"),
                                        ptr(self.A, "float64") if with_grad else None, ptr(s["send"], "float64")))
 
     def _unpack_add(self, s, with_grad):
         from ._capi import check, lib, ptr
+        if self.trim:
+            check(lib().mimi_hip_entries_unpack_add(self._stream(), ptr(s["rrows"], "int64"), s["rrows"].numel(),
+                                                    ptr(s["ridx"], "int64"), s["ridx"].numel(), ptr(s["recv"], "float64"),
+                                                    ptr(self.r, "float64"), ptr(self.A, "float64") if with_grad else None))
+            return
         check(lib().mimi_hip_rows_unpack_add(self._stream(), ptr(self._rowptr, "int64"), ptr(s["rrows"], "int64"),
                                              ptr(s["ridx"].offsets, "int64"), s["rrows"].numel(), ptr(s["recv"], "float64"),
                                              ptr(self.r, "float64"), ptr(self.A, "float64") if with_grad else None))

@@ -38,7 +38,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert not missing, missing
     assert sorted(_capi.EXPORTS) == declared_functions()
     lib.mimi_hip_abi_version.restype = ctypes.c_int
-    assert lib.mimi_hip_abi_version() == 11
+    assert lib.mimi_hip_abi_version() == 12
     # plain C ABI: no C++ / torch symbols leak through the public names
     out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
     public = [l.split()[-1] for l in out.splitlines() if " T " in l]

@@ -69,3 +69,51 @@ def test_rows_zero_pack_unpack():
     assert L.mimi_hip_rows_pack(stream, ptr(rowptr, "int64"), ptr(rows, "int64"), None, rows.numel(), ptr(r, "float64"),
                                 ptr(A, "float64"), ptr(msg, "float64")) != 0          # A without offsets
     assert b"offsets" in L.mimi_hip_last_error()
+
+
+def test_entries_pack_unpack():
+    """the trimmed form of the same message (ABI 12): [n residual entries][A[positions]] -- pack reads only, unpack_add adds
+    exactly once at every listed place (more entries than one pass of the grid covers), A == NULL moves residual entries
+    only, empty lists are a no-op, missing arguments are refused"""
+    import torch
+    from mimi_amd import _capi
+    from mimi_amd._capi import check, ptr
+    L = _capi.lib()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(6)
+    n, nnz = 4000, 20_000_000                                  # (65536 workgroups x 256 lanes = 16.8 M: the grid strides)
+    r0 = torch.from_numpy(rng.standard_normal(n)).to(dev)
+    A0 = torch.randn(nnz, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(6))
+    rows = torch.from_numpy(np.unique(rng.integers(0, n, size=700)).astype(np.int64)).to(dev)
+    pos = torch.randperm(nnz, device=dev, generator=torch.Generator(device=dev).manual_seed(7))[:17_500_000].contiguous()
+    msg = torch.full((rows.numel() + pos.numel() + 3,), 7.0, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream or _capi.STREAM_NULL
+    r, A = r0.clone(), A0.clone()
+    check(L.mimi_hip_entries_pack(stream, ptr(rows, "int64"), rows.numel(), ptr(pos, "int64"), pos.numel(), ptr(r, "float64"),
+                                  ptr(A, "float64"), ptr(msg, "float64")))
+    torch.cuda.synchronize()
+    assert torch.equal(msg[:rows.numel()], r0[rows]) and torch.equal(msg[rows.numel():-3], A0[pos])
+    assert float(msg[-3:].min()) == 7.0 and torch.equal(r, r0) and torch.equal(A, A0)
+    check(L.mimi_hip_entries_unpack_add(stream, ptr(rows, "int64"), rows.numel(), ptr(pos, "int64"), pos.numel(), ptr(msg, "float64"),
+                                        ptr(r, "float64"), ptr(A, "float64")))
+    torch.cuda.synchronize()
+    fr = torch.ones(n, dtype=torch.float64, device=dev)
+    fr[rows] = 2.0
+    fA = torch.ones(nnz, dtype=torch.float64, device=dev)
+    fA[pos] = 2.0
+    assert torch.equal(r, fr * r0) and torch.equal(A, fA * A0)
+    # residual entries only
+    r, A = r0.clone(), A0.clone()
+    msg.fill_(7.0)
+    check(L.mimi_hip_entries_pack(stream, ptr(rows, "int64"), rows.numel(), ptr(pos, "int64"), pos.numel(), ptr(r, "float64"), None,
+                                  ptr(msg, "float64")))
+    check(L.mimi_hip_entries_unpack_add(stream, ptr(rows, "int64"), rows.numel(), ptr(pos, "int64"), pos.numel(), ptr(msg, "float64"),
+                                        ptr(r, "float64"), None))
+    torch.cuda.synchronize()
+    assert float(msg[rows.numel():].min()) == 7.0 and torch.equal(r, fr * r0) and torch.equal(A, A0)
+    # nothing to do / bad arguments
+    check(L.mimi_hip_entries_pack(stream, None, 0, None, 0, None, None, None))
+    assert L.mimi_hip_entries_pack(stream, ptr(rows, "int64"), rows.numel(), None, 5, ptr(r, "float64"), ptr(A, "float64"),
+                                   ptr(msg, "float64")) != 0                              # A without positions
+    assert L.mimi_hip_entries_unpack_add(stream, ptr(rows, "int64"), rows.numel(), ptr(pos, "int64"), pos.numel(), None,
+                                         ptr(r, "float64"), ptr(A, "float64")) != 0        # no message

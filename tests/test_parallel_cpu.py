@@ -376,3 +376,55 @@ def test_loopback_pairs_sends_with_receives_of_their_own_length(p, mode, expect,
                                          torch.zeros(int(rowptr[-1]), dtype=torch.float64), mode=mode, loopback=True)
         with pytest.raises(RuntimeError, match="cannot be paired"):
             ex0.loopback_pairs()
+
+
+@pytest.mark.parametrize("p,mode", [(2, "owner"), (2, "replicate"), (3, "owner")])
+def test_trimmed_messages_drop_structural_zeros_only(p, mode, monkeypatch):
+    """round 5: a message carries of every shared row only the entries the sender's element layers can have written
+    (InterfaceExchange(trim=True), the default).  On an oracle-integrated slab: every entry of the whole-row message that the
+    trimmed one leaves out IS zero, the trimmed one is the expected fraction of it (degree 2, owner mode: 3 of the 5 column
+    planes of a row), and the receiving side lists as many entries as the neighbour sends."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import mimi_amd
+    from mimi_amd import parallel
+    from mimi_amd.integrators import CSRPattern
+    from oracle import iga, ref_path as rp
+    from _cases import oracle_material, synthetic_u
+    monkeypatch.setattr(dist, "get_rank", lambda *a, **k: 0)
+    n_el = (2, 2, 12)
+    P = iga.Patch.block(n_el, p)
+    rowptr, col = P.sparsity()
+    patch = mimi_amd.BSplinePatch.block(n_el, p)
+    exs = {}
+    for rank in (1, 2):
+        shard = parallel.SlabShard(patch, CSRPattern(rowptr, col, rowptr[-1]), rank, 3)
+        em = P.element_multi_index()
+        b, e = shard.element_box
+        own = np.nonzero((em[shard.axis] >= b[shard.axis]) & (em[shard.axis] < e[shard.axis]))[0]
+        D = rp.DomainOracle(P, oracle_material("neohook"), elements=own)
+        r, A = np.zeros(P.n_vdofs), np.zeros(D.nnz)
+        D.add_domain_residual_and_grad(synthetic_u(P), 1.0, r, A, rp.TANGENT_EXACT)
+        tr, tA = torch.from_numpy(r), torch.from_numpy(A)
+        full = parallel.InterfaceExchange(shard, tr, tA, mode=mode, loopback=True, trim=False)
+        trimmed = parallel.InterfaceExchange(shard, tr, tA, mode=mode, loopback=True)
+        assert trimmed.trim and not full.trim
+        for sf, st in zip(full.sides, trimmed.sides):
+            assert torch.equal(sf["srows"], st["srows"]) and torch.equal(sf["rrows"], st["rrows"])
+            kept = torch.zeros(tA.numel(), dtype=torch.bool)
+            kept[st["sidx"]] = True
+            assert bool(kept[sf["sidx"]].sum() == st["sidx"].numel())            # a subset of the whole rows, ...
+            dropped = sf["sidx"][~kept[sf["sidx"]]]
+            assert dropped.numel() > 0 and bool((tA[dropped] == 0.0).all())        # ... what it leaves out is zero, ...
+            assert bool((tA[st["sidx"]] != 0.0).float().mean() > 0.9)             # ... and what it keeps (mostly) is not
+            if (p, mode) == (2, "owner"):
+                assert st["sidx"].numel() * 5 == sf["sidx"].numel() * 3
+        exs[rank] = trimmed
+    # rank 1's upper side talks to rank 2's lower side: what one lists to send the other lists to receive
+    up, down = exs[1].sides[1], exs[2].sides[0]
+    assert up["sidx"].numel() == down["ridx"].numel() and up["ridx"].numel() == down["sidx"].numel()
+    assert up["srows"].numel() == down["rrows"].numel()
+    # (both ranks index the whole patch's pattern here: the same pairs in the same order are the same positions)
+    assert torch.equal(up["sidx"], down["ridx"]) and torch.equal(up["ridx"], down["sidx"])

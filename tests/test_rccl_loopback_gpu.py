@@ -112,7 +112,13 @@ def _worker(port, n_el, p, fake_rank, fake_world, mode, scheme, q):
             s, t = ex.sides[i], ex.sides[j]
             assert s["peer"] == 0 and s["srows"].numel() == t["rrows"].numel() and s["sidx"].numel() == t["ridx"].numel()
             r_exp.index_add_(0, t["rrows"], r1[s["srows"]])
-            A_exp.index_add_(0, positions(t["rrows"]), A1[positions(s["srows"])])
+            if ex.trim:
+                # (trimmed messages, round 5: the entries the sender lists land where the receiving side lists them -- in loop-back
+                # those are this rank's own two lists, cut for different neighbours; that the lists of two REAL neighbours
+                # name the same pairs is what tests/test_parallel_{cpu,gpu}.py check against a whole-patch assembly)
+                A_exp.index_add_(0, t["ridx"], A1[s["sidx"]])
+            else:
+                A_exp.index_add_(0, positions(t["rrows"]), A1[positions(s["srows"])])
         shared_rows = torch.cat([s["rrows"] for s in ex.sides])
         shared_idx = positions(shared_rows)
         er = float((r[shared_rows] - r_exp[shared_rows]).abs().max() / r1.abs().max())
