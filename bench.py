@@ -749,7 +749,10 @@ def measure(args, workload, rank, world, local_rank, backend, with_extras, loopb
                                    if world > 1 else "")
                                    + (", exchange overlapped with the interior elements" if boundary else "")
                                    + (", rows that leave the rank gathered first and sent while the others are gathered"
-                                      if scheme == "gather" else ""),
+                                      if scheme == "gather" else "")
+                                   + (f", messages trimmed to the entries the sender's elements can have written "
+                                      f"({max(s['sidx'].numel() + s['srows'].numel() for s in exchange.sides) * 8 / 1e6:.1f} MB per neighbour and direction)"
+                                      if exchange is not None and exchange.trim and exchange.sides else ""),
                     "kernel_path": "tensor" if integ.path_ == 1 else "general",
                     "u": f"{0.01 if workload == 'cfg4' else 0.05}*N(0,1), seed 20241008, face x=0 clamped"},
             roofline={"bound": "hbm", "bound_note": "the HBM roofline of SURVEY 8d's algorithmic bytes, as the contract asks; the "
