@@ -204,7 +204,7 @@ class InterfaceExchange:
         trim (round 5): a message carries of every row only the entries the SENDER's elements can have written -- an element
         layer l touches the node planes l .. l + p, so entry (row plane a, column plane c) of a rank whose layers are
         [b, e) is zero by construction unless some l in [b, e) has max(a, c) - p <= l <= min(a, c).  Of a degree-2 row
-        in owner mode 3 of the 5 column planes remain: 12.6 instead of 21 MB per neighbour and direction at the
+        in owner mode 3 of the 5 column planes remain: 11.7 instead of 19.5 MB per neighbour and direction at the
         north-star size on 8 ranks -- what has to hide behind the last gather.  Sender and receiver list the
         same (row, column) pairs in the same order, each from the slab bounds alone.  False: whole rows (csrc/exchange.hip's
         row kernels)."""
