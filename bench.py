@@ -156,7 +156,11 @@ def binding_rooflines(p, elements, phase_ms, pmc):
               "useful_flop_per_element": useful_flop(p),
               "issued_frac": cycles * elements / (N_SIMD * CLOCK_HZ * t1) if integ and t1 > 0 else None,
               "issued_cycles_per_element": cycles if integ else None,
-              "peak": "78.6 TFLOP/s = 1024 SIMDs x 32 flop/cycle x 2.4 GHz"}
+              "peak": "78.6 TFLOP/s = 1024 SIMDs x 32 flop/cycle x 2.4 GHz",
+              "clock_note": "recorded engine clock under this load (rocm-smi every 3 s over 35-s runs, profiles/r05_clock_under_load.txt): "
+                            + ("2.15-2.18 GHz at 1.30 kW -- the chip is at its power limit on this workload, the pipe's own "
+                               "peak is 0.90 of the figure above and the issued share correspondingly higher" if p == 3 else
+                               "2.35-2.38 GHz at 1.19 kW (0.98-0.99 of the 2.4 GHz the peak above assumes)")}
     bytes2 = sum(raw[k] for k in gath) if gath else None
     phase2 = {"resource": "hbm", "ms": phase_ms[1], "measured_bytes": bytes2,
               "frac": bytes2 / t2 / 8e12 if bytes2 and t2 > 0 else None, "peak": "8 TB/s"}
